@@ -1,0 +1,744 @@
+/*
+ * bq_oracle.c -- CPU restatement of the Bayesian-quadrature GP hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle for the HIP
+ * library in ../bayesian-quadrature_amd/csrc.  Only tests/, the smoke check in
+ * __graft_entry__.py and bench.py's cpu_baseline leg may load it.  Nothing in
+ * the product path links, imports or calls it.
+ *
+ * What it restates (reference = jhamrick/bayesian-quadrature v0.2.0):
+ *   - bayesian_quadrature/linalg_c.pyx:55-210   cho_factor / cho_solve / logdet
+ *     (the reference forwards to ATLAS clapack_dpotrf / clapack_dpotrs, a
+ *     system dependency that is absent here; the algorithm restated is the
+ *     published LAPACK dpotrf/dpotf2 lower Cholesky and dpotrs two-sweep solve)
+ *   - the un-vendored third-party package gaussian_processes==1.0.5 (import
+ *     name `gp`, requirements.txt:2): Gaussian kernel h^2 N(x1|x2, diag(w^2)),
+ *     Kxx = K + s^2 I, Lxx, inv_Kxx_y, mean, diag(cov), log_lh -- formulas from
+ *     docs/ipynb/bq_mean.ipynb cell 4 and gauss_c.pyx:106-110, call sites in
+ *     bq.py:147-162,200,227-228,282,334-335,546,942-943
+ *   - bayesian_quadrature/gauss_c.pyx:20-164,235-339,416-531,617-713,796-855
+ *     closed-form Gaussian-kernel integrals
+ *   - bayesian_quadrature/bq_c.pyx:63-97,127-213,264-355,425-535,601-649
+ *
+ * Pinning: tests/test_oracle_known_answers.py checks this file against the
+ * seven printed known answers of docs/ipynb/visual-tests.ipynb and against
+ * the property contracts of the reference's own tests (tests/test_linalg_c.py,
+ * tests/test_gauss_c.py).  log_lh and the noise form s^2 I have no printed
+ * value anywhere in the reference: for those two items parity is UNPINNED
+ * (see DESIGN.md).
+ *
+ * Storage: every matrix is column-major (Fortran order) like the reference's
+ * float64_t[::1, :] memoryviews; points are d x n (gauss_c.pyx:116-117).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define A_(M, ld, i, j) ((M)[(size_t)(i) + (size_t)(j) * (size_t)(ld)])
+
+static int g_threads = 1;
+
+/* number of OpenMP threads the blocked routines may use (1 = scalar port) */
+void bqo_set_threads(int t)
+{
+    g_threads = t < 1 ? 1 : t;
+#ifdef _OPENMP
+    omp_set_num_threads(g_threads);
+#endif
+}
+
+int bqo_get_threads(void) { return g_threads; }
+
+int bqo_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_num_procs();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------ */
+/* linalg_c.pyx                                                        */
+/* ------------------------------------------------------------------ */
+
+/* Unblocked lower Cholesky, in place (LAPACK dpotf2, right-looking column
+ * form).  Returns 0, or j+1 if the leading minor of order j+1 is not positive
+ * definite -- the dpotrf `info` the reference maps to LinAlgError
+ * (linalg_c.pyx:86-91).  The strict upper triangle is left untouched
+ * ("upper values could be anything", linalg_c.pyx:58-59). */
+int bqo_potf2(double *A, int n, int lda)
+{
+    for (int j = 0; j < n; ++j) {
+        double ajj = A_(A, lda, j, j);
+        if (!(ajj > 0.0) || isnan(ajj))
+            return j + 1;
+        ajj = sqrt(ajj);
+        A_(A, lda, j, j) = ajj;
+        const double r = 1.0 / ajj;
+        double *cj = &A_(A, lda, 0, j);
+        for (int i = j + 1; i < n; ++i)
+            cj[i] *= r;
+        for (int k = j + 1; k < n; ++k) {
+            const double lkj = cj[k];
+            double *ck = &A_(A, lda, 0, k);
+            for (int i = k; i < n; ++i)
+                ck[i] -= lkj * cj[i];
+        }
+    }
+    return 0;
+}
+
+/* Blocked right-looking lower Cholesky in place (LAPACK dpotrf structure:
+ * potf2 on the diagonal block, trsm on the panel, syrk on the trailing
+ * matrix).  nb <= 0 selects 64. */
+int bqo_potrf(double *A, int n, int lda, int nb)
+{
+    if (nb <= 0)
+        nb = 64;
+    if (n <= nb)
+        return bqo_potf2(A, n, lda);
+    for (int k0 = 0; k0 < n; k0 += nb) {
+        const int kb = (n - k0 < nb) ? n - k0 : nb;
+        int info = bqo_potf2(&A_(A, lda, k0, k0), kb, lda);
+        if (info)
+            return k0 + info;
+        const int r0 = k0 + kb; /* first trailing row */
+        const int m = n - r0;
+        if (m <= 0)
+            break;
+        /* panel: A21 <- A21 * L11^-T, row chunks are independent */
+#pragma omp parallel for schedule(static) if (g_threads > 1 && m > 256)
+        for (int c0 = 0; c0 < m; c0 += 128) {
+            const int cm = (m - c0 < 128) ? m - c0 : 128;
+            for (int j = 0; j < kb; ++j) {
+                double *xj = &A_(A, lda, r0 + c0, k0 + j);
+                for (int p = 0; p < j; ++p) {
+                    const double l = A_(A, lda, k0 + j, k0 + p);
+                    const double *xp = &A_(A, lda, r0 + c0, k0 + p);
+                    for (int i = 0; i < cm; ++i)
+                        xj[i] -= l * xp[i];
+                }
+                const double r = 1.0 / A_(A, lda, k0 + j, k0 + j);
+                for (int i = 0; i < cm; ++i)
+                    xj[i] *= r;
+            }
+        }
+        /* trailing: A22 <- A22 - A21 A21^T (lower triangle), 4 columns at a
+         * time so each panel column is streamed once per 4 outputs */
+#pragma omp parallel for schedule(dynamic, 1) if (g_threads > 1 && m > 256)
+        for (int jb = 0; jb < m; jb += 4) {
+            const int jw = (m - jb < 4) ? m - jb : 4;
+            for (int jj = 0; jj < jw; ++jj) {
+                /* ragged head of each column inside the 4-wide strip */
+                const int j = jb + jj;
+                double *c = &A_(A, lda, r0, r0 + j);
+                for (int i = j; i < jb + jw; ++i) {
+                    double acc = 0.0;
+                    for (int p = 0; p < kb; ++p)
+                        acc += A_(A, lda, r0 + i, k0 + p) * A_(A, lda, r0 + j, k0 + p);
+                    c[i] -= acc;
+                }
+            }
+            const int i0 = jb + jw;
+            if (i0 >= m)
+                continue;
+            double *c0p = &A_(A, lda, r0, r0 + jb);
+            double *c1p = jw > 1 ? &A_(A, lda, r0, r0 + jb + 1) : c0p;
+            double *c2p = jw > 2 ? &A_(A, lda, r0, r0 + jb + 2) : c0p;
+            double *c3p = jw > 3 ? &A_(A, lda, r0, r0 + jb + 3) : c0p;
+            for (int p = 0; p < kb; ++p) {
+                const double *a = &A_(A, lda, r0, k0 + p);
+                const double b0 = a[jb];
+                const double b1 = jw > 1 ? a[jb + 1] : 0.0;
+                const double b2 = jw > 2 ? a[jb + 2] : 0.0;
+                const double b3 = jw > 3 ? a[jb + 3] : 0.0;
+                if (jw == 4) {
+                    for (int i = i0; i < m; ++i) {
+                        const double ai = a[i];
+                        c0p[i] -= ai * b0;
+                        c1p[i] -= ai * b1;
+                        c2p[i] -= ai * b2;
+                        c3p[i] -= ai * b3;
+                    }
+                } else {
+                    for (int i = i0; i < m; ++i) {
+                        const double ai = a[i];
+                        c0p[i] -= ai * b0;
+                        if (jw > 1) c1p[i] -= ai * b1;
+                        if (jw > 2) c2p[i] -= ai * b2;
+                    }
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* cho_factor(C, L): copy unless aliased, then factor (linalg_c.pyx:55-93). */
+int bqo_cho_factor(const double *C, double *L, int n)
+{
+    if (C != L)
+        memcpy(L, C, sizeof(double) * (size_t)n * (size_t)n);
+    return bqo_potrf(L, n, n, 64);
+}
+
+/* dpotrs: solve (L L^T) X = B in place, B is n x nrhs column-major
+ * (linalg_c.pyx:96-179 after the copy). */
+void bqo_potrs(const double *L, int n, int ldl, double *B, int nrhs, int ldb)
+{
+#pragma omp parallel for schedule(static) if (g_threads > 1 && nrhs > 1)
+    for (int r = 0; r < nrhs; ++r) {
+        double *b = &A_(B, ldb, 0, r);
+        /* forward: column-oriented so the L column is contiguous */
+        for (int j = 0; j < n; ++j) {
+            const double *lj = &A_(L, ldl, 0, j);
+            const double v = b[j] / lj[j];
+            b[j] = v;
+            for (int i = j + 1; i < n; ++i)
+                b[i] -= v * lj[i];
+        }
+        /* backward: L^T x = y, dot-product form down contiguous column j */
+        for (int j = n - 1; j >= 0; --j) {
+            const double *lj = &A_(L, ldl, 0, j);
+            double acc = b[j];
+            for (int i = j + 1; i < n; ++i)
+                acc -= lj[i] * b[i];
+            b[j] = acc / lj[j];
+        }
+    }
+}
+
+/* forward sweep only: B <- L^-1 B */
+void bqo_trsm_lower(const double *L, int n, int ldl, double *B, int nrhs, int ldb)
+{
+#pragma omp parallel for schedule(static) if (g_threads > 1 && nrhs > 1)
+    for (int r = 0; r < nrhs; ++r) {
+        double *b = &A_(B, ldb, 0, r);
+        for (int j = 0; j < n; ++j) {
+            const double *lj = &A_(L, ldl, 0, j);
+            const double v = b[j] / lj[j];
+            b[j] = v;
+            for (int i = j + 1; i < n; ++i)
+                b[i] -= v * lj[i];
+        }
+    }
+}
+
+int bqo_cho_solve_vec(const double *L, const double *b, double *x, int n)
+{
+    if (b != x)
+        memcpy(x, b, sizeof(double) * (size_t)n);
+    bqo_potrs(L, n, n, x, 1, n);
+    return 0;
+}
+
+int bqo_cho_solve_mat(const double *L, const double *B, double *X, int n, int nrhs)
+{
+    if (B != X)
+        memcpy(X, B, sizeof(double) * (size_t)n * (size_t)nrhs);
+    bqo_potrs(L, n, n, X, nrhs, n);
+    return 0;
+}
+
+/* logdet = 2 sum log L_ii, sequential (linalg_c.pyx:182-210). */
+double bqo_logdet(const double *L, int n)
+{
+    double s = 0.0;
+    for (int i = 0; i < n; ++i)
+        s += log(A_(L, n, i, i));
+    return 2.0 * s;
+}
+
+/* dot11 with the n in {1,2} fast paths of linalg_c.pyx:236-243 */
+double bqo_dot11(const double *x, const double *y, int n)
+{
+    if (n == 1)
+        return x[0] * y[0];
+    if (n == 2)
+        return (x[0] * y[0]) + (x[1] * y[1]);
+    double s = 0.0;
+    for (int i = 0; i < n; ++i)
+        s += x[i] * y[i];
+    return s;
+}
+
+/* vecdiff, linalg_c.pyx:373-408 */
+double bqo_vecdiff(const double *x, const double *y, int n)
+{
+    if (n == 1)
+        return fabs(x[0] - y[0]);
+    double s = 0.0;
+    for (int i = 0; i < n; ++i)
+        s += (x[i] - y[i]) * (x[i] - y[i]);
+    return sqrt(s);
+}
+
+/* ------------------------------------------------------------------ */
+/* gp package restatement                        */
+/* ------------------------------------------------------------------ */
+
+/* prior scale k(x,x) = h^2 / ((2 pi)^(d/2) prod w) */
+double bqo_kernel_scale(int d, double h, const double *w)
+{
+    double c = h * h;
+    for (int k = 0; k < d; ++k)
+        c /= (sqrt(2.0 * M_PI) * w[k]);
+    return c;
+}
+
+/* K[i,j] = h^2 N(x1_i | x2_j, diag(w^2)); x1 is d x n1, x2 is d x n2, K is
+ * n1 x n2 column-major. */
+void bqo_gram_gauss_cross(const double *x1, int n1, const double *x2, int n2, int d,
+                          double h, const double *w, double *K)
+{
+    const double c = bqo_kernel_scale(d, h, w);
+    double iw2[16];
+    for (int k = 0; k < d && k < 16; ++k)
+        iw2[k] = 0.5 / (w[k] * w[k]);
+#pragma omp parallel for schedule(static) if (g_threads > 1 && (size_t)n1 * n2 > 65536)
+    for (int j = 0; j < n2; ++j) {
+        double *kj = &A_(K, n1, 0, j);
+        if (d == 1) {
+            const double xj = x2[j], a = iw2[0];
+            for (int i = 0; i < n1; ++i) {
+                const double t = x1[i] - xj;
+                kj[i] = c * exp(-(t * t) * a);
+            }
+        } else {
+            for (int i = 0; i < n1; ++i) {
+                double q = 0.0;
+                for (int k = 0; k < d; ++k) {
+                    const double t = x1[k + (size_t)i * d] - x2[k + (size_t)j * d];
+                    q += (t * t) * iw2[k];
+                }
+                kj[i] = c * exp(-q);
+            }
+        }
+    }
+}
+
+/* Kxx = K(x,x) + s^2 I  (full symmetric matrix, as gp.GP.Kxx materialises) */
+void bqo_gram_gauss(const double *x, int n, int d, double h, const double *w, double s,
+                    double *K)
+{
+    bqo_gram_gauss_cross(x, n, x, n, d, h, w, K);
+    const double s2 = s * s;
+    for (int i = 0; i < n; ++i)
+        A_(K, n, i, i) += s2;
+}
+
+/* fit: K (n x n) is overwritten by its lower Cholesky factor, alpha = Kxx^-1 y,
+ * logml = -1/2 y'alpha - 1/2 log|Kxx| - n/2 log 2pi.  Returns dpotrf info. */
+int bqo_gp_fit(const double *x, const double *y, int d, int n, double h, const double *w,
+               double s, double *L, double *alpha, double *logml)
+{
+    bqo_gram_gauss(x, n, d, h, w, s, L);
+    int info = bqo_potrf(L, n, n, 64);
+    if (info)
+        return info;
+    memcpy(alpha, y, sizeof(double) * (size_t)n);
+    bqo_potrs(L, n, n, alpha, 1, n);
+    double yta = 0.0, sl = 0.0;
+    for (int i = 0; i < n; ++i) {
+        yta += y[i] * alpha[i];
+        sl += log(A_(L, n, i, i));
+    }
+    *logml = -0.5 * yta - sl - 0.5 * (double)n * log(2.0 * M_PI);
+    return 0;
+}
+
+/* posterior mean and marginal variance at M points xo (d x M):
+ *   mean_i = k*_i' alpha,  var_i = k(x,x) - || L^-1 k*_i ||^2
+ * (gp.GP.mean, diag(gp.GP.cov) as consumed at bq.py:200,227-228,942-943).
+ * work is n x M doubles. */
+void bqo_gp_predict(const double *x, int d, int n, double h, const double *w, const double *L,
+                    const double *alpha, const double *xo, int M, double *mean, double *var,
+                    double *work)
+{
+    bqo_gram_gauss_cross(x, n, xo, M, d, h, w, work); /* n x M: column i = k*_i */
+    if (mean)
+        for (int i = 0; i < M; ++i) {
+            const double *k = &A_(work, n, 0, i);
+            double m = 0.0;
+            for (int j = 0; j < n; ++j)
+                m += k[j] * alpha[j];
+            mean[i] = m;
+        }
+    if (var) {
+        const double k0 = bqo_kernel_scale(d, h, w);
+        bqo_trsm_lower(L, n, n, work, M, n);
+        for (int i = 0; i < M; ++i) {
+            const double *v = &A_(work, n, 0, i);
+            double q = 0.0;
+            for (int j = 0; j < n; ++j)
+                q += v[j] * v[j];
+            var[i] = k0 - q;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* gauss_c.pyx, closed forms                                           */
+/* ------------------------------------------------------------------ */
+
+#define DMAX 8 /* the reference is d-generic; BQ only ever uses d=1 */
+
+static const double BQO_MAX = 707.00287872323153; /* log(exp2(maxexp-4)), gauss_c.pyx:16 */
+
+double bqo_max_exp_arg(void) { return log(exp2(1024.0 - 4.0)); }
+
+/* mvn_logpdf, gauss_c.pyx:20-62: L is the d x d Cholesky factor */
+double bqo_mvn_logpdf(const double *x, const double *m, const double *L, double logdet, int d)
+{
+    double diff[2 * DMAX], buf[2 * DMAX];
+    const double c = log(2.0 * M_PI) * d + logdet;
+    for (int i = 0; i < d; ++i)
+        diff[i] = x[i] - m[i];
+    bqo_cho_solve_vec(L, diff, buf, d);
+    return -0.5 * (c + bqo_dot11(diff, buf, d));
+}
+
+/* int_exp_norm, gauss_c.pyx:65-92 */
+double bqo_int_exp_norm(double c, double m, double S)
+{
+    double out = (c * m) + (0.5 * c * c * S);
+    if (out > BQO_MAX)
+        return INFINITY;
+    return exp(out);
+}
+
+/* int_K, gauss_c.pyx:95-164 */
+int bqo_int_K(double *out, const double *x, int d, int n, double h, const double *w,
+              const double *mu, const double *cov)
+{
+    double W[DMAX * DMAX];
+    if (d > DMAX)
+        return -1;
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j)
+            A_(W, d, i, j) = A_(cov, d, i, j) + (i == j ? w[i] * w[i] : 0.0);
+    int info = bqo_cho_factor(W, W, d);
+    if (info)
+        return info;
+    const double logdet = bqo_logdet(W, d);
+    const double h2 = h * h;
+    for (int i = 0; i < n; ++i)
+        out[i] = h2 * exp(bqo_mvn_logpdf(&x[(size_t)i * d], mu, W, logdet, d));
+    return 0;
+}
+
+/* int_K1_K2, gauss_c.pyx:235-339: out is n1 x n2 column-major */
+int bqo_int_K1_K2(double *out, const double *x1, int n1, const double *x2, int n2, int d,
+                  double h1, const double *w1, double h2, const double *w2, const double *mu,
+                  const double *cov)
+{
+    double m[2 * DMAX], C[4 * DMAX * DMAX], xx[2 * DMAX];
+    const int D = 2 * d;
+    if (d > DMAX)
+        return -1;
+    for (int i = 0; i < d; ++i) {
+        m[i] = mu[i];
+        m[i + d] = mu[i];
+    }
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) {
+            const double c = A_(cov, d, i, j);
+            A_(C, D, i, j) = c + (i == j ? w1[i] * w1[i] : 0.0);
+            A_(C, D, i + d, j + d) = c + (i == j ? w2[i] * w2[i] : 0.0);
+            A_(C, D, i, j + d) = c;
+            A_(C, D, i + d, j) = c;
+        }
+    int info = bqo_cho_factor(C, C, D);
+    if (info)
+        return info;
+    const double logdet = bqo_logdet(C, D);
+    const double hh = (h1 * h1) * (h2 * h2);
+    for (int i = 0; i < n1; ++i)
+        for (int j = 0; j < n2; ++j) {
+            for (int k = 0; k < d; ++k) {
+                xx[k] = x1[k + (size_t)i * d];
+                xx[k + d] = x2[k + (size_t)j * d];
+            }
+            A_(out, n1, i, j) = hh * exp(bqo_mvn_logpdf(xx, m, C, logdet, D));
+        }
+    return 0;
+}
+
+/* small dense helpers for the d x d algebra below */
+static void mat_mul(const double *X, const double *Y, double *XY, int m, int n, int p)
+{
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < p; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k)
+                s += A_(X, m, i, k) * A_(Y, n, k, j);
+            A_(XY, m, i, j) = s;
+        }
+}
+
+/* int_int_K1_K2_K1, gauss_c.pyx:416-531: out is n x n column-major */
+int bqo_int_int_K1_K2_K1(double *out, const double *x, int d, int n, double h1,
+                         const double *w1, double h2, const double *w2, const double *mu,
+                         const double *cov)
+{
+    double W1c[DMAX * DMAX], L[DMAX * DMAX], Am[DMAX * DMAX], C[DMAX * DMAX], buf[DMAX];
+    if (d > DMAX)
+        return -1;
+    double *B = (double *)malloc(sizeof(double) * (size_t)d * n);
+    double *N1 = (double *)malloc(sizeof(double) * (size_t)n);
+    if (!B || !N1) {
+        free(B);
+        free(N1);
+        return -2;
+    }
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j)
+            A_(W1c, d, i, j) = A_(cov, d, i, j) + (i == j ? w1[i] * w1[i] : 0.0);
+    /* A = cov (W1+cov)^-1 cov */
+    int info = bqo_cho_factor(W1c, L, d);
+    if (info) {
+        free(B);
+        free(N1);
+        return info;
+    }
+    double logdet = bqo_logdet(L, d);
+    bqo_cho_solve_mat(L, cov, W1c, d, d);
+    mat_mul(cov, W1c, Am, d, d, d);
+    /* B = cov (W1+cov)^-1 x ; N1 = log N(x | mu, W1+cov) */
+    for (int i = 0; i < n; ++i) {
+        bqo_cho_solve_vec(L, &x[(size_t)i * d], buf, d);
+        mat_mul(cov, buf, &B[(size_t)i * d], d, d, 1);
+        N1[i] = bqo_mvn_logpdf(&x[(size_t)i * d], mu, L, logdet, d);
+    }
+    /* C = W2 + 2 cov - 2 A */
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j)
+            A_(C, d, i, j) = (i == j ? w2[i] * w2[i] : 0.0) + 2 * A_(cov, d, i, j) -
+                             2 * A_(Am, d, i, j);
+    info = bqo_cho_factor(C, L, d);
+    if (info) {
+        free(B);
+        free(N1);
+        return info;
+    }
+    logdet = bqo_logdet(L, d);
+    const double hh = (h1 * h1 * h1 * h1) * (h2 * h2);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const double n2 = bqo_mvn_logpdf(&B[(size_t)i * d], &B[(size_t)j * d], L, logdet, d);
+            A_(out, n, i, j) = hh * exp(N1[i] + N1[j] + n2);
+        }
+    free(B);
+    free(N1);
+    return 0;
+}
+
+/* int_int_K1_K2, gauss_c.pyx:617-713 */
+int bqo_int_int_K1_K2(double *out, const double *x, int d, int n, double h1, const double *w1,
+                      double h2, const double *w2, const double *mu, const double *cov)
+{
+    double W[DMAX * DMAX], C[DMAX * DMAX], buf[DMAX * DMAX], z[DMAX];
+    if (d > DMAX)
+        return -1;
+    memset(z, 0, sizeof z);
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j)
+            A_(W, d, i, j) = 2 * A_(cov, d, i, j) + (i == j ? w1[i] * w1[i] : 0.0);
+    int info = bqo_cho_factor(W, W, d);
+    if (info)
+        return info;
+    const double N = bqo_mvn_logpdf(z, z, W, bqo_logdet(W, d), d);
+    bqo_cho_solve_mat(W, cov, buf, d, d);
+    mat_mul(cov, buf, C, d, d, d);
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j)
+            A_(C, d, i, j) = (i == j ? w2[i] * w2[i] : 0.0) + A_(cov, d, i, j) - A_(C, d, i, j);
+    info = bqo_cho_factor(C, C, d);
+    if (info)
+        return info;
+    const double logdet = bqo_logdet(C, d);
+    const double hh = (h1 * h1) * (h2 * h2);
+    for (int i = 0; i < n; ++i)
+        out[i] = hh * exp(N + bqo_mvn_logpdf(&x[(size_t)i * d], mu, C, logdet, d));
+    return 0;
+}
+
+/* int_int_K, gauss_c.pyx:796-855 */
+double bqo_int_int_K(int d, double h, const double *w, const double *mu, const double *cov)
+{
+    double W[DMAX * DMAX], z[DMAX];
+    (void)mu;
+    if (d > DMAX)
+        return NAN;
+    memset(z, 0, sizeof z);
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j)
+            A_(W, d, i, j) = 2 * A_(cov, d, i, j) + (i == j ? w[i] * w[i] : 0.0);
+    if (bqo_cho_factor(W, W, d))
+        return NAN;
+    return (h * h) * exp(bqo_mvn_logpdf(z, z, W, bqo_logdet(W, d), d));
+}
+
+/* ------------------------------------------------------------------ */
+/* bq_c.pyx, exact branch                                              */
+/* ------------------------------------------------------------------ */
+
+/* p_x_gaussian, bq_c.pyx:63-97 */
+int bqo_p_x_gaussian(double *p, const double *x, int d, int n, const double *mu,
+                     const double *cov)
+{
+    double L[DMAX * DMAX];
+    if (d > DMAX)
+        return -1;
+    int info = bqo_cho_factor(cov, L, d);
+    if (info)
+        return info;
+    const double logdet = bqo_logdet(L, d);
+    for (int i = 0; i < n; ++i)
+        p[i] = exp(bqo_mvn_logpdf(&x[(size_t)i * d], mu, L, logdet, d));
+    return 0;
+}
+
+/* Z_mean, bq_c.pyx:157-213 */
+double bqo_Z_mean(const double *x_sc, int d, int nsc, const double *alpha_l, double h_l,
+                  const double *w_l, const double *mu, const double *cov)
+{
+    double *ik = (double *)malloc(sizeof(double) * (size_t)nsc);
+    if (!ik)
+        return NAN;
+    if (bqo_int_K(ik, x_sc, d, nsc, h_l, w_l, mu, cov)) {
+        free(ik);
+        return NAN;
+    }
+    const double m = bqo_dot11(ik, alpha_l, nsc);
+    free(ik);
+    return m;
+}
+
+/* Z_var, bq_c.pyx:264-355 */
+double bqo_Z_var(const double *x_s, int ns, const double *x_sc, int nsc, int d,
+                 const double *alpha_l, const double *L_tl, double h_l, const double *w_l,
+                 double h_tl, const double *w_tl, const double *mu, const double *cov)
+{
+    double *I3 = (double *)malloc(sizeof(double) * (size_t)nsc * nsc);
+    double *I2 = (double *)malloc(sizeof(double) * (size_t)ns * nsc);
+    double *beta = (double *)malloc(sizeof(double) * (size_t)ns);
+    double *Lb = (double *)malloc(sizeof(double) * (size_t)ns);
+    double *ai = (double *)malloc(sizeof(double) * (size_t)nsc);
+    double V = NAN;
+    if (I3 && I2 && beta && Lb && ai &&
+        !bqo_int_int_K1_K2_K1(I3, x_sc, d, nsc, h_l, w_l, h_tl, w_tl, mu, cov) &&
+        !bqo_int_K1_K2(I2, x_s, ns, x_sc, nsc, d, h_tl, w_tl, h_l, w_l, mu, cov)) {
+        /* alpha_int = alpha' I3 (dot12), then alpha_int . alpha */
+        for (int j = 0; j < nsc; ++j)
+            ai[j] = bqo_dot11(alpha_l, &A_(I3, nsc, 0, j), nsc);
+        const double aia = bqo_dot11(ai, alpha_l, nsc);
+        /* beta = I2 alpha (dot21) */
+        for (int i = 0; i < ns; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < nsc; ++j)
+                s += A_(I2, ns, i, j) * alpha_l[j];
+            beta[i] = s;
+        }
+        bqo_cho_solve_vec(L_tl, beta, Lb, ns); /* full K^-1 beta, bq_c.pyx:348 */
+        V = aia - bqo_dot11(beta, Lb, ns);
+    }
+    free(I3);
+    free(I2);
+    free(beta);
+    free(Lb);
+    free(ai);
+    return V;
+}
+
+/* _esm_and_em + expected_squared_mean_and_mean, bq_c.pyx:425-535.
+ * L_l is the (nsc+1)^2 Cholesky factor of the bordered, jittered Gram. */
+int bqo_esm_and_em(double *out2, const double *l_sc, const double *L_l, double tm_a, double tC_a,
+                   const double *x_sca, int d, int nca, double h_l, const double *w_l,
+                   const double *mu, const double *cov)
+{
+    double *ik = (double *)malloc(sizeof(double) * (size_t)nca);
+    double *A = (double *)malloc(sizeof(double) * (size_t)nca);
+    if (!ik || !A) {
+        free(ik);
+        free(A);
+        return -2;
+    }
+    int info = bqo_int_K(ik, x_sca, d, nca, h_l, w_l, mu, cov);
+    if (info) {
+        free(ik);
+        free(A);
+        return info;
+    }
+    bqo_cho_solve_vec(L_l, ik, A, nca);
+    const double A_a = A[nca - 1];
+    const double A_sc_l = bqo_dot11(A, l_sc, nca - 1);
+    free(ik);
+    free(A);
+    const double e1 = bqo_int_exp_norm(1, tm_a, tC_a);
+    if (isinf(e1)) {
+        out2[0] = out2[1] = INFINITY;
+        return 0;
+    }
+    const double E_m = A_sc_l + A_a * e1;
+    const double e2 = bqo_int_exp_norm(2, tm_a, tC_a);
+    if (isinf(e2)) {
+        out2[0] = INFINITY;
+        out2[1] = E_m;
+        return 0;
+    }
+    out2[0] = (A_sc_l * A_sc_l) + (2 * A_sc_l * A_a * e1) + (A_a * A_a * e2);
+    out2[1] = E_m;
+    return 0;
+}
+
+/* filter_candidates, bq_c.pyx:601-649: in-place NaN marking */
+void bqo_filter_candidates(double *x_c, int nc, const double *x_s, int ns, double thresh)
+{
+    int done = 0;
+    while (!done) {
+        done = 1;
+        for (int i = 0; i < nc; ++i) {
+            if (isnan(x_c[i]))
+                continue;
+            for (int j = i + 1; j < nc; ++j) {
+                if (isnan(x_c[j]))
+                    continue;
+                if (fabs(x_c[i] - x_c[j]) < thresh) {
+                    x_c[i] = (x_c[i] + x_c[j]) / 2.0;
+                    x_c[j] = NAN;
+                    done = 0;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < nc; ++i) {
+        if (isnan(x_c[i]))
+            continue;
+        for (int j = 0; j < ns; ++j)
+            if (fabs(x_c[i] - x_s[j]) < thresh)
+                x_c[i] = NAN;
+    }
+}
+
+/* improve_covariance_conditioning, bq_c.pyx:127-140 (M is n x n, symmetric
+ * diagonal access so the storage order does not matter). */
+void bqo_improve_covariance_conditioning(double *M, int n, double *jitters, const int64_t *idx,
+                                         int nidx)
+{
+    double mx = M[0];
+    for (size_t k = 1; k < (size_t)n * n; ++k)
+        if (M[k] > mx)
+            mx = M[k];
+    const double eps = 2.220446049250313e-16;
+    const double j = fmax(eps, mx) * 1e-4;
+    for (int i = 0; i < nidx; ++i) {
+        jitters[idx[i]] += j;
+        A_(M, n, idx[i], idx[i]) += j;
+    }
+}
