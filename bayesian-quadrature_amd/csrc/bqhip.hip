@@ -1,0 +1,1540 @@
+// bqhip.hip -- host side of libbqhip.so: the C ABI declared in include/bqhip.h.
+//
+// Design: a GP "fit + posterior + log-ML" is ONE partial Cholesky
+// of a bordered matrix
+//
+//        [ Kxx + s^2 I                       ]      n (padded to 64 with I)
+//    B = [ K(xo,x)        K(xo,xo)           ]      M prediction points
+//        [ y^T            0            0     ]      1 row (padded to 64)
+//
+// Eliminating the first npad columns with the blocked right-looking algorithm
+// (potf2 on the 64x64 diagonal, row-per-lane panel solve, MFMA trailing
+// update) leaves, in the Schur complement, the posterior covariance of xo,
+// -mean(xo) in the y row and -y'Kxx^-1 y in its corner; z = L^-1 y appears in
+// the y row of the factored panel.  No separate triangular solve is needed
+// for the posterior or the log marginal likelihood; alpha = L^-T z is
+// produced on demand by a backward sweep.  Every kernel is batched over
+// independent problems (blockIdx.z).
+#include "../../include/bqhip.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+// RAII device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t alloc(size_t b)
+    {
+        release();
+        if (b == 0)
+            b = 8;
+        hipError_t e = hipMalloc(&p, b);
+        if (e == hipSuccess)
+            bytes = b;
+        else
+            p = nullptr;
+        return e;
+    }
+    double *d() const { return static_cast<double *>(p); }
+    int *i() const { return static_cast<int *>(p); }
+};
+
+struct ProfEvent {
+    hipEvent_t a, b;
+    int cls;
+};
+
+} // namespace
+
+struct bq_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int cus = 256;
+    int nb_override = 0;
+    char err[512] = {0};
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool prof = false;
+    std::vector<ProfEvent> prof_events;
+    double prof_ms[BQ_K_NCLASS] = {0};
+    int64_t prof_n[BQ_K_NCLASS] = {0};
+    DevBuf gbuf;   // GaussParams of the single-problem entry points
+    DevBuf dinv64; // potf2 reciprocal-diagonal scratch
+};
+
+namespace {
+
+int fail(bq_ctx *c, int code, const char *fmt, ...)
+{
+    if (c) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(c->err, sizeof c->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                        \
+    do {                                                                                       \
+        hipError_t e__ = (call);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return fail((c), e__ == hipErrorOutOfMemory ? BQ_ERR_NOMEM : BQ_ERR_HIP,           \
+                        "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,      \
+                        __LINE__);                                                             \
+    } while (0)
+
+#define BQCHK(call)                                                                            \
+    do {                                                                                       \
+        int s__ = (call);                                                                      \
+        if (s__ != BQ_OK)                                                                      \
+            return s__;                                                                        \
+    } while (0)
+
+inline long roundup(long v, long q) { return (v + q - 1) / q * q; }
+
+// leading dimension for an ntot x ntot column-major matrix: even, and nudged
+// off large powers of two so that the 4 columns of an MFMA fragment do not
+// all map to the same HBM channel / L2 set
+inline long pick_ld(long ntot)
+{
+    long ld = ntot;
+    if (ntot >= 1024 && (ntot % 512) == 0)
+        ld += 64;
+    return ld;
+}
+
+GaussParams make_params(int d, double h, const double *w, double s)
+{
+    GaussParams g;
+    std::memset(&g, 0, sizeof g);
+    double c = h * h;
+    for (int k = 0; k < d; ++k) {
+        c /= (std::sqrt(2.0 * M_PI) * w[k]);
+        g.nh[k] = -0.5 / (w[k] * w[k]);
+    }
+    g.c = c;
+    g.s2 = s * s;
+    return g;
+}
+
+// ---- profiling brackets -------------------------------------------------
+struct Bracket {
+    bq_ctx *c;
+    ProfEvent ev;
+    bool on;
+    Bracket(bq_ctx *ctx, int cls) : c(ctx), on(ctx->prof)
+    {
+        if (on) {
+            ev.cls = cls;
+            if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) {
+                on = false;
+                return;
+            }
+            (void)hipEventRecord(ev.a, c->stream);
+        }
+    }
+    ~Bracket()
+    {
+        if (on) {
+            (void)hipEventRecord(ev.b, c->stream);
+            c->prof_events.push_back(ev);
+        }
+    }
+};
+
+int prof_collect(bq_ctx *c)
+{
+    if (c->prof_events.empty())
+        return BQ_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto &e : c->prof_events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            c->prof_ms[e.cls] += ms;
+            c->prof_n[e.cls] += 1;
+        }
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    c->prof_events.clear();
+    return BQ_OK;
+}
+
+// ---- launch helpers -------------------------------------------------------
+template <int D>
+void launch_gram_sym_d(bq_ctx *c, const double *x, long xstride, const GaussParams *gp,
+                       int gpstride, double *K, long ldk, long kstride, int n, int batch)
+{
+    dim3 grid((n + 127) / 128, (n + 63) / 64, batch);
+    hipLaunchKernelGGL(gram_sym_kernel<D>, grid, dim3(256), 0, c->stream, x, xstride, gp, gpstride,
+                       K, ldk, kstride, n);
+}
+
+int launch_gram_sym(bq_ctx *c, int d, const double *x, long xstride, const GaussParams *gp,
+                    int gpstride, double *K, long ldk, long kstride, int n, int batch)
+{
+    Bracket br(c, BQ_K_GRAM);
+    switch (d) {
+    case 1: launch_gram_sym_d<1>(c, x, xstride, gp, gpstride, K, ldk, kstride, n, batch); break;
+    case 2: launch_gram_sym_d<2>(c, x, xstride, gp, gpstride, K, ldk, kstride, n, batch); break;
+    case 3: launch_gram_sym_d<3>(c, x, xstride, gp, gpstride, K, ldk, kstride, n, batch); break;
+    case 4: launch_gram_sym_d<4>(c, x, xstride, gp, gpstride, K, ldk, kstride, n, batch); break;
+    case 5: launch_gram_sym_d<5>(c, x, xstride, gp, gpstride, K, ldk, kstride, n, batch); break;
+    case 6: launch_gram_sym_d<6>(c, x, xstride, gp, gpstride, K, ldk, kstride, n, batch); break;
+    case 7: launch_gram_sym_d<7>(c, x, xstride, gp, gpstride, K, ldk, kstride, n, batch); break;
+    case 8: launch_gram_sym_d<8>(c, x, xstride, gp, gpstride, K, ldk, kstride, n, batch); break;
+    default: return fail(c, BQ_ERR_BAD_ARG, "d must be in 1..%d", BQ_MAXD);
+    }
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+template <int D>
+void launch_gram_cross_d(bq_ctx *c, const double *x1, int n1, const double *x2, int n2,
+                         const GaussParams &g, double *K, long ldk)
+{
+    dim3 grid((n1 + 63) / 64, (n2 + 63) / 64, 1);
+    hipLaunchKernelGGL(gram_cross_kernel<D>, grid, dim3(256), 0, c->stream, x1, n1, x2, n2, g, K,
+                       ldk);
+}
+
+int launch_gram_cross(bq_ctx *c, int d, const double *x1, int n1, const double *x2, int n2,
+                      const GaussParams &g, double *K, long ldk)
+{
+    if (n1 <= 0 || n2 <= 0)
+        return BQ_OK;
+    Bracket br(c, BQ_K_GRAM);
+    switch (d) {
+    case 1: launch_gram_cross_d<1>(c, x1, n1, x2, n2, g, K, ldk); break;
+    case 2: launch_gram_cross_d<2>(c, x1, n1, x2, n2, g, K, ldk); break;
+    case 3: launch_gram_cross_d<3>(c, x1, n1, x2, n2, g, K, ldk); break;
+    case 4: launch_gram_cross_d<4>(c, x1, n1, x2, n2, g, K, ldk); break;
+    case 5: launch_gram_cross_d<5>(c, x1, n1, x2, n2, g, K, ldk); break;
+    case 6: launch_gram_cross_d<6>(c, x1, n1, x2, n2, g, K, ldk); break;
+    case 7: launch_gram_cross_d<7>(c, x1, n1, x2, n2, g, K, ldk); break;
+    case 8: launch_gram_cross_d<8>(c, x1, n1, x2, n2, g, K, ldk); break;
+    default: return fail(c, BQ_ERR_BAD_ARG, "d must be in 1..%d", BQ_MAXD);
+    }
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+template <int D>
+void launch_assemble_d(bq_ctx *c, const double *pts, long pstride, const double *y, long ystride,
+                       const GaussParams *gp, int gpstride, double *A, long lda, long astride,
+                       Layout L, int batch)
+{
+    dim3 grid((L.ntot + 127) / 128, (L.ntot + 63) / 64, batch);
+    hipLaunchKernelGGL(assemble_kernel<D>, grid, dim3(256), 0, c->stream, pts, pstride, y, ystride,
+                       gp, gpstride, A, lda, astride, L);
+}
+
+int launch_assemble(bq_ctx *c, int d, const double *pts, long pstride, const double *y,
+                    long ystride, const GaussParams *gp, int gpstride, double *A, long lda,
+                    long astride, Layout L, int batch)
+{
+    Bracket br(c, BQ_K_GRAM);
+    switch (d) {
+    case 1: launch_assemble_d<1>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch); break;
+    case 2: launch_assemble_d<2>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch); break;
+    case 3: launch_assemble_d<3>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch); break;
+    case 4: launch_assemble_d<4>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch); break;
+    case 5: launch_assemble_d<5>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch); break;
+    case 6: launch_assemble_d<6>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch); break;
+    case 7: launch_assemble_d<7>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch); break;
+    case 8: launch_assemble_d<8>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch); break;
+    default: return fail(c, BQ_ERR_BAD_ARG, "d must be in 1..%d", BQ_MAXD);
+    }
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+// C(m x n) -= P(m x k) Q(n x k)^T; tile shape from the amount of parallelism
+int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const double *P, long ldp,
+                long pstride, const double *Q, long qsj, long qsk, long qstride, int m, int n,
+                int k, int lower, int batch)
+{
+    if (m <= 0 || n <= 0 || k <= 0)
+        return BQ_OK;
+    if ((m & 15) || (n & 15) || (k & 7))
+        return fail(c, BQ_ERR_BAD_ARG, "gemm: m,n must be multiples of 16 and k of 8");
+    Bracket br(c, cls);
+    auto tiles = [&](int t) {
+        long a = (long)((m + t - 1) / t) * ((n + t - 1) / t) * batch;
+        return lower ? a / 2 + 1 : a;
+    };
+    const long cu = c->cus;
+    if (tiles(128) >= cu) {
+        dim3 grid((m + 127) / 128, (n + 127) / 128, batch);
+        hipLaunchKernelGGL((gemm_sub_kernel<4, 4>), grid, dim3(256), 0, c->stream, C, ldc, cstride,
+                           P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, lower);
+    } else if (tiles(64) >= cu / 2) {
+        dim3 grid((m + 63) / 64, (n + 63) / 64, batch);
+        hipLaunchKernelGGL((gemm_sub_kernel<2, 2>), grid, dim3(256), 0, c->stream, C, ldc, cstride,
+                           P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, lower);
+    } else {
+        dim3 grid((m + 31) / 32, (n + 31) / 32, batch);
+        hipLaunchKernelGGL((gemm_sub_kernel<1, 1>), grid, dim3(256), 0, c->stream, C, ldc, cstride,
+                           P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, lower);
+    }
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+int launch_potf2(bq_ctx *c, double *A, long lda, long astride, int j0, double *dinv, long dstride,
+                 int *info, int batch)
+{
+    Bracket br(c, BQ_K_POTF2);
+    hipLaunchKernelGGL(potf2_64_kernel, dim3(1, 1, batch), dim3(64), 0, c->stream, A, lda, astride,
+                       j0, dinv, dstride, info);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+template <bool TRANS>
+int launch_trsm(bq_ctx *c, double *X, long ldx, long xstride, int m, const double *L11, long ldl,
+                long lstride, const double *dinv, long dstride, int batch)
+{
+    if (m <= 0)
+        return BQ_OK;
+    Bracket br(c, BQ_K_TRSM);
+    hipLaunchKernelGGL(trsm_rows_kernel<TRANS>, dim3((m + 63) / 64, 1, batch), dim3(64), 0,
+                       c->stream, X, ldx, xstride, m, L11, ldl, lstride, dinv, dstride);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+int auto_nb(const bq_ctx *c, int ntot)
+{
+    if (c->nb_override > 0)
+        return c->nb_override;
+    if (ntot >= 8192)
+        return 256;
+    if (ntot >= 3072)
+        return 128;
+    return 64;
+}
+
+// Eliminate the first ncols columns (multiple of 64) of the ntot x ntot lower
+// matrix (ntot multiple of 64), batched.  dinv: 64 doubles per problem.
+int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
+                          int ncols, double *dinv, int *info)
+{
+    if ((ntot & 63) || (ncols & 63) || ncols > ntot)
+        return fail(c, BQ_ERR_BAD_ARG, "potrf: sizes must be multiples of 64");
+    const int NB = auto_nb(c, ntot);
+    for (int K0 = 0; K0 < ncols; K0 += NB) {
+        const int KB = std::min(NB, ncols - K0);
+        for (int j0 = K0; j0 < K0 + KB; j0 += 64) {
+            double *Ajj = A + j0 + (long)j0 * lda;
+            if (j0 > K0) {
+                // left-looking update of this 64-column slab by the panel so far
+                BQCHK(launch_gemm(c, BQ_K_GEMM, Ajj, lda, astride, A + j0 + (long)K0 * lda, lda,
+                                  astride, A + j0 + (long)K0 * lda, 1, lda, astride, ntot - j0, 64,
+                                  j0 - K0, 0, batch));
+            }
+            BQCHK(launch_potf2(c, A, lda, astride, j0, dinv, 64, info, batch));
+            BQCHK(launch_trsm<true>(c, Ajj + 64, lda, astride, ntot - j0 - 64, Ajj, lda, astride,
+                                    dinv, 64, batch));
+        }
+        const int r0 = K0 + KB;
+        if (r0 < ntot) {
+            const double *P = A + r0 + (long)K0 * lda;
+            BQCHK(launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda, astride,
+                              P, 1, lda, astride, ntot - r0, ntot - r0, KB, 1, batch));
+        }
+    }
+    return BQ_OK;
+}
+
+// X (mrows x npad, ld ldx) <- X L^-T, L resident (npad x npad, ld ldl), dinv[npad]
+int enqueue_forward_rows(bq_ctx *c, double *X, long ldx, int mrows, const double *L, long ldl,
+                         const double *dinv, int npad)
+{
+    for (int jb = 0; jb < npad; jb += 64) {
+        const double *L11 = L + jb + (long)jb * ldl;
+        BQCHK(launch_trsm<true>(c, X + (long)jb * ldx, ldx, 0, mrows, L11, ldl, 0, dinv + jb, 0,
+                                1));
+        const int rest = npad - jb - 64;
+        if (rest > 0)
+            BQCHK(launch_gemm(c, BQ_K_GEMM, X + (long)(jb + 64) * ldx, ldx, 0,
+                              X + (long)jb * ldx, ldx, 0, L11 + 64, 1, ldl, 0, mrows, rest, 64, 0,
+                              1));
+    }
+    return BQ_OK;
+}
+
+// X (mrows x npad) <- X L^-1 (the L^T sweep of dpotrs in row form)
+int enqueue_backward_rows(bq_ctx *c, double *X, long ldx, int mrows, const double *L, long ldl,
+                          const double *dinv, int npad)
+{
+    for (int jb = npad - 64; jb >= 0; jb -= 64) {
+        const double *L11 = L + jb + (long)jb * ldl;
+        BQCHK(launch_trsm<false>(c, X + (long)jb * ldx, ldx, 0, mrows, L11, ldl, 0, dinv + jb, 0,
+                                 1));
+        if (jb > 0) // X[:, 0:jb] -= X[:, jb:jb+64] * L[jb:jb+64, 0:jb]
+            BQCHK(launch_gemm(c, BQ_K_GEMM, X, ldx, 0, X + (long)jb * ldx, ldx, 0, L + jb, ldl, 1,
+                              0, mrows, jb, 64, 0, 1));
+    }
+    return BQ_OK;
+}
+
+int check_dims(bq_ctx *c, int64_t d, int64_t n)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    if (d < 1 || d > BQ_MAXD)
+        return fail(c, BQ_ERR_BAD_ARG, "d must be in 1..%d", BQ_MAXD);
+    if (n < 1 || n > (1 << 20))
+        return fail(c, BQ_ERR_BAD_ARG, "n out of range");
+    return BQ_OK;
+}
+
+int check_w(bq_ctx *c, int64_t d, double h, const double *w, double s)
+{
+    if (!w)
+        return fail(c, BQ_ERR_BAD_ARG, "w is NULL");
+    if (!(std::isfinite(h)) || !(std::isfinite(s)))
+        return fail(c, BQ_ERR_BAD_ARG, "h and s must be finite");
+    for (int k = 0; k < d; ++k)
+        if (!(w[k] > 0.0) || !std::isfinite(w[k]))
+            return fail(c, BQ_ERR_BAD_ARG, "w must be positive and finite");
+    return BQ_OK;
+}
+
+} // namespace
+
+// ===========================================================================
+// contexts
+// ===========================================================================
+extern "C" int bq_device_count(int *count)
+{
+    if (!count)
+        return BQ_ERR_BAD_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        n = 0;
+    *count = n;
+    return BQ_OK;
+}
+
+static int ctx_init(bq_ctx *c, int device)
+{
+    HIPCHK(c, hipSetDevice(device));
+    c->device = device;
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, device));
+    c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIPCHK(c, hipEventCreate(&c->t0));
+    HIPCHK(c, hipEventCreate(&c->t1));
+    return BQ_OK;
+}
+
+extern "C" int bq_ctx_create(int device, bq_ctx **out)
+{
+    if (!out)
+        return BQ_ERR_BAD_ARG;
+    *out = nullptr;
+    bq_ctx *c = new (std::nothrow) bq_ctx();
+    if (!c)
+        return BQ_ERR_NOMEM;
+    int st = ctx_init(c, device);
+    if (st == BQ_OK) {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess)
+            st = fail(c, BQ_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        c->own_stream = true;
+    }
+    if (st != BQ_OK) {
+        fprintf(stderr, "bq_ctx_create: %s\n", c->err);
+        delete c;
+        return st;
+    }
+    *out = c;
+    return BQ_OK;
+}
+
+extern "C" int bq_ctx_create_on_stream(int device, void *hip_stream, bq_ctx **out)
+{
+    if (!out)
+        return BQ_ERR_BAD_ARG;
+    *out = nullptr;
+    bq_ctx *c = new (std::nothrow) bq_ctx();
+    if (!c)
+        return BQ_ERR_NOMEM;
+    int st = ctx_init(c, device);
+    if (st != BQ_OK) {
+        delete c;
+        return st;
+    }
+    c->stream = static_cast<hipStream_t>(hip_stream);
+    c->own_stream = false;
+    *out = c;
+    return BQ_OK;
+}
+
+extern "C" void bq_ctx_destroy(bq_ctx *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &e : c->prof_events) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    if (c->t0)
+        (void)hipEventDestroy(c->t0);
+    if (c->t1)
+        (void)hipEventDestroy(c->t1);
+    if (c->own_stream && c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int bq_ctx_sync(bq_ctx *c)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BQ_OK;
+}
+
+extern "C" const char *bq_last_error(const bq_ctx *c) { return c ? c->err : "null context"; }
+
+extern "C" int bq_device_info(bq_ctx *c, char *name, int *cus, size_t *hbm_bytes, int *clock_khz)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+    if (name) {
+        std::snprintf(name, 64, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (cus)
+        *cus = prop.multiProcessorCount;
+    if (hbm_bytes)
+        *hbm_bytes = prop.totalGlobalMem;
+    if (clock_khz)
+        *clock_khz = prop.clockRate;
+    return BQ_OK;
+}
+
+extern "C" int bq_set_block(bq_ctx *c, int nb)
+{
+    if (!c || nb < 0 || (nb & 63))
+        return c ? fail(c, BQ_ERR_BAD_ARG, "block must be a multiple of 64") : BQ_ERR_BAD_ARG;
+    c->nb_override = nb;
+    return BQ_OK;
+}
+
+// ===========================================================================
+// memory, timers, profiling
+// ===========================================================================
+extern "C" int bq_dev_alloc(bq_ctx *c, size_t bytes, void **dptr)
+{
+    if (!c || !dptr)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(dptr, bytes ? bytes : 8));
+    return BQ_OK;
+}
+
+extern "C" int bq_dev_free(bq_ctx *c, void *dptr)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    if (dptr) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(dptr));
+    }
+    return BQ_OK;
+}
+
+extern "C" int bq_upload(bq_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c || (!dst && bytes) || (!src && bytes))
+        return BQ_ERR_BAD_ARG;
+    if (bytes == 0)
+        return BQ_OK;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BQ_OK;
+}
+
+extern "C" int bq_download(bq_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c || (!dst && bytes) || (!src && bytes))
+        return BQ_ERR_BAD_ARG;
+    if (bytes == 0)
+        return BQ_OK;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BQ_OK;
+}
+
+extern "C" int bq_memset(bq_ctx *c, void *dst, int byte, size_t bytes)
+{
+    if (!c || !dst)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipMemsetAsync(dst, byte, bytes, c->stream));
+    return BQ_OK;
+}
+
+extern "C" int bq_timer_start(bq_ctx *c)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipEventRecord(c->t0, c->stream));
+    return BQ_OK;
+}
+
+extern "C" int bq_timer_stop_ms(bq_ctx *c, float *ms)
+{
+    if (!c || !ms)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipEventRecord(c->t1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->t1));
+    HIPCHK(c, hipEventElapsedTime(ms, c->t0, c->t1));
+    return BQ_OK;
+}
+
+extern "C" int bq_profile_enable(bq_ctx *c, int on)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    BQCHK(prof_collect(c));
+    c->prof = on != 0;
+    return BQ_OK;
+}
+
+extern "C" int bq_profile_reset(bq_ctx *c)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    BQCHK(prof_collect(c));
+    for (int k = 0; k < BQ_K_NCLASS; ++k) {
+        c->prof_ms[k] = 0;
+        c->prof_n[k] = 0;
+    }
+    return BQ_OK;
+}
+
+extern "C" int bq_profile_read(bq_ctx *c, double *ms, int64_t *launches)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    BQCHK(prof_collect(c));
+    for (int k = 0; k < BQ_K_NCLASS; ++k) {
+        if (ms)
+            ms[k] = c->prof_ms[k];
+        if (launches)
+            launches[k] = c->prof_n[k];
+    }
+    return BQ_OK;
+}
+
+// ===========================================================================
+// linalg_c drop-ins (host buffers)
+// ===========================================================================
+namespace {
+
+// upload an n x n host matrix (ld n) into a padded ntot x ntot device matrix
+int upload_padded(bq_ctx *c, const double *H, int n, DevBuf &A, int &ntot, long &lda)
+{
+    ntot = (int)roundup(n, 64);
+    lda = pick_ld(ntot);
+    HIPCHK(c, A.alloc(sizeof(double) * (size_t)lda * ntot));
+    HIPCHK(c, hipMemcpy2DAsync(A.p, sizeof(double) * lda, H, sizeof(double) * n,
+                               sizeof(double) * n, n, hipMemcpyHostToDevice, c->stream));
+    if (ntot > n) {
+        hipLaunchKernelGGL(pad_identity_kernel, dim3((ntot + 255) / 256, ntot), dim3(256), 0,
+                           c->stream, A.d(), lda, n, ntot);
+        HIPCHK(c, hipGetLastError());
+    }
+    return BQ_OK;
+}
+
+} // namespace
+
+extern "C" int bq_cho_factor(bq_ctx *c, const double *C, double *L, int64_t n, int64_t *info_out)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    if (info_out)
+        *info_out = 0;
+    if (!C || !L || n < 0)
+        return fail(c, BQ_ERR_BAD_ARG, "illegal value");
+    if (n == 0)
+        return BQ_OK;
+    if (n > 65536)
+        return fail(c, BQ_ERR_BAD_ARG, "n too large");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf A, ws;
+    int ntot;
+    long lda;
+    BQCHK(upload_padded(c, C, (int)n, A, ntot, lda));
+    HIPCHK(c, ws.alloc(64 * sizeof(double) + 64));
+    double *dinv = ws.d();
+    int *info = reinterpret_cast<int *>(ws.d() + 64);
+    HIPCHK(c, hipMemsetAsync(info, 0, sizeof(int), c->stream));
+    BQCHK(enqueue_potrf_partial(c, A.d(), lda, 0, 1, ntot, ntot, dinv, info));
+    int hinfo = 0;
+    HIPCHK(c, hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (hinfo != 0) {
+        if (info_out)
+            *info_out = hinfo;
+        return fail(c, BQ_ERR_NOT_PD, "matrix is not positive definite");
+    }
+    // copy back only the lower triangle; the strict upper part of L keeps what
+    // the caller had there (C's values after the reference's C -> L copy)
+    std::vector<double> tmp((size_t)n * n);
+    HIPCHK(c, hipMemcpy2D(tmp.data(), sizeof(double) * n, A.p, sizeof(double) * lda,
+                          sizeof(double) * n, n, hipMemcpyDeviceToHost));
+    for (int64_t j = 0; j < n; ++j) {
+        if (C != L)
+            for (int64_t i = 0; i < j; ++i)
+                L[i + j * n] = C[i + j * n];
+        for (int64_t i = j; i < n; ++i)
+            L[i + j * n] = tmp[(size_t)(i + j * n)];
+    }
+    return BQ_OK;
+}
+
+extern "C" int bq_cho_solve(bq_ctx *c, const double *L, const double *B, double *X, int64_t n,
+                            int64_t nrhs)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    if (!L || !B || !X || n < 0 || nrhs < 0)
+        return fail(c, BQ_ERR_BAD_ARG, "illegal value");
+    if (n == 0 || nrhs == 0)
+        return BQ_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf A, ws, Xd;
+    int npad;
+    long ldl;
+    // the strict upper triangle of L is never read by the sweeps
+    BQCHK(upload_padded(c, L, (int)n, A, npad, ldl));
+    HIPCHK(c, ws.alloc(sizeof(double) * npad));
+    hipLaunchKernelGGL(diag_recip_kernel, dim3((npad + 255) / 256), dim3(256), 0, c->stream,
+                       A.d(), ldl, 0, npad, ws.d(), 0);
+    HIPCHK(c, hipGetLastError());
+    // right-hand sides as rows: X_dev is mpad x npad with X_dev[r, j] = B[j, r]
+    const int mpad = (int)roundup(nrhs, 64);
+    std::vector<double> host((size_t)mpad * npad, 0.0);
+    for (int64_t r = 0; r < nrhs; ++r)
+        for (int64_t j = 0; j < n; ++j)
+            host[(size_t)(r + j * mpad)] = B[j + r * n];
+    HIPCHK(c, Xd.alloc(sizeof(double) * host.size()));
+    HIPCHK(c, hipMemcpyAsync(Xd.p, host.data(), sizeof(double) * host.size(),
+                             hipMemcpyHostToDevice, c->stream));
+    BQCHK(enqueue_forward_rows(c, Xd.d(), mpad, mpad, A.d(), ldl, ws.d(), npad));
+    BQCHK(enqueue_backward_rows(c, Xd.d(), mpad, mpad, A.d(), ldl, ws.d(), npad));
+    HIPCHK(c, hipMemcpyAsync(host.data(), Xd.p, sizeof(double) * host.size(),
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int64_t r = 0; r < nrhs; ++r)
+        for (int64_t j = 0; j < n; ++j)
+            X[j + r * n] = host[(size_t)(r + j * mpad)];
+    return BQ_OK;
+}
+
+extern "C" int bq_logdet(bq_ctx *c, const double *L, int64_t n, double *out)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    if (!L || !out || n < 0)
+        return fail(c, BQ_ERR_BAD_ARG, "illegal value");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n == 0) {
+        *out = 0.0;
+        return BQ_OK;
+    }
+    // only the diagonal travels
+    std::vector<double> diag((size_t)n);
+    for (int64_t i = 0; i < n; ++i)
+        diag[(size_t)i] = L[i + i * n];
+    DevBuf dv;
+    HIPCHK(c, dv.alloc(sizeof(double) * (n + 1)));
+    HIPCHK(c, hipMemcpyAsync(dv.p, diag.data(), sizeof(double) * n, hipMemcpyHostToDevice,
+                             c->stream));
+    hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, c->stream, dv.d(), 0L, (int)n,
+                       dv.d() + n);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, dv.d() + n, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BQ_OK;
+}
+
+// ===========================================================================
+// Gram
+// ===========================================================================
+extern "C" int bq_gram_gauss_dev(bq_ctx *c, const double *x_dev, int64_t d, int64_t n, double h,
+                                 const double *w, double s, double *K_dev, int64_t ldk)
+{
+    BQCHK(check_dims(c, d, n));
+    BQCHK(check_w(c, d, h, w, s));
+    if (!x_dev || !K_dev || ldk < n)
+        return fail(c, BQ_ERR_BAD_ARG, "illegal value");
+    // parameters ride in a tiny device buffer so the same kernel serves the
+    // batched callers; one 80-byte upload
+    GaussParams g = make_params((int)d, h, w, s);
+    if (!c->gbuf.p)
+        HIPCHK(c, c->gbuf.alloc(sizeof(GaussParams)));
+    HIPCHK(c, hipMemcpyAsync(c->gbuf.p, &g, sizeof g, hipMemcpyHostToDevice, c->stream));
+    return launch_gram_sym(c, (int)d, x_dev, 0, static_cast<GaussParams *>(c->gbuf.p), 0, K_dev,
+                           ldk, 0, (int)n, 1);
+}
+
+extern "C" int bq_gram_gauss(bq_ctx *c, const double *x, int64_t d, int64_t n, double h,
+                             const double *w, double s, double *K_out)
+{
+    BQCHK(check_dims(c, d, n));
+    BQCHK(check_w(c, d, h, w, s));
+    if (!x || !K_out)
+        return fail(c, BQ_ERR_BAD_ARG, "illegal value");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf xd, Kd, gd;
+    HIPCHK(c, xd.alloc(sizeof(double) * d * n));
+    HIPCHK(c, Kd.alloc(sizeof(double) * (size_t)n * n));
+    HIPCHK(c, gd.alloc(sizeof(GaussParams)));
+    GaussParams g = make_params((int)d, h, w, s);
+    HIPCHK(c, hipMemcpyAsync(xd.p, x, sizeof(double) * d * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(gd.p, &g, sizeof g, hipMemcpyHostToDevice, c->stream));
+    BQCHK(launch_gram_sym(c, (int)d, xd.d(), 0, static_cast<GaussParams *>(gd.p), 0, Kd.d(), n, 0,
+                          (int)n, 1));
+    HIPCHK(c, hipMemcpyAsync(K_out, Kd.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BQ_OK;
+}
+
+extern "C" int bq_gram_gauss_cross(bq_ctx *c, const double *x1, int64_t n1, const double *x2,
+                                   int64_t n2, int64_t d, double h, const double *w, double *K_out)
+{
+    BQCHK(check_dims(c, d, n1 > 0 ? n1 : 1));
+    BQCHK(check_w(c, d, h, w, 0.0));
+    if (n1 < 0 || n2 < 0 || (n1 && !x1) || (n2 && !x2) || (!K_out && n1 * n2))
+        return fail(c, BQ_ERR_BAD_ARG, "illegal value");
+    if (n1 == 0 || n2 == 0)
+        return BQ_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf a, b, Kd;
+    HIPCHK(c, a.alloc(sizeof(double) * d * n1));
+    HIPCHK(c, b.alloc(sizeof(double) * d * n2));
+    HIPCHK(c, Kd.alloc(sizeof(double) * (size_t)n1 * n2));
+    HIPCHK(c, hipMemcpyAsync(a.p, x1, sizeof(double) * d * n1, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b.p, x2, sizeof(double) * d * n2, hipMemcpyHostToDevice, c->stream));
+    GaussParams g = make_params((int)d, h, w, 0.0);
+    BQCHK(launch_gram_cross(c, (int)d, a.d(), (int)n1, b.d(), (int)n2, g, Kd.d(), n1));
+    HIPCHK(c, hipMemcpyAsync(K_out, Kd.p, sizeof(double) * (size_t)n1 * n2, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BQ_OK;
+}
+
+// ===========================================================================
+// device-resident Cholesky
+// ===========================================================================
+extern "C" int bq_potrf_dev(bq_ctx *c, double *A_dev, int64_t n, int64_t lda, int32_t *info_dev)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    if (!A_dev || !info_dev || n <= 0 || (n & 63) || lda < n || (lda & 1))
+        return fail(c, BQ_ERR_BAD_ARG, "potrf_dev: n must be a positive multiple of 64, lda even");
+    if (!c->dinv64.p)
+        HIPCHK(c, c->dinv64.alloc(64 * sizeof(double)));
+    HIPCHK(c, hipMemsetAsync(info_dev, 0, sizeof(int32_t), c->stream));
+    return enqueue_potrf_partial(c, A_dev, lda, 0, 1, (int)n, (int)n, c->dinv64.d(), info_dev);
+}
+
+// ===========================================================================
+// plans: resident batched "fit + posterior + log-ML"
+// ===========================================================================
+struct bq_plan {
+    int nprob = 0, d = 0, n = 0, M = 0;
+    Layout L{};
+    long lda = 0, astride = 0;
+    DevBuf A, pts, y, gp, dinv, info, scal, mean, var;
+    std::vector<GaussParams> hgp;
+    bool has_inputs = false;
+};
+
+namespace {
+
+Layout make_layout(int n, int M, bool has_y)
+{
+    Layout L;
+    L.n = n;
+    L.npad = (int)roundup(n, 64);
+    L.M = M;
+    L.yrow = has_y ? L.npad + M : -1;
+    L.ntot = (int)roundup(L.npad + M + (has_y ? 1 : 0), 64);
+    return L;
+}
+
+} // namespace
+
+extern "C" int bq_plan_create(bq_ctx *c, int64_t nprob, int64_t d, int64_t n, int64_t M,
+                              bq_plan **out)
+{
+    if (!out)
+        return BQ_ERR_BAD_ARG;
+    *out = nullptr;
+    BQCHK(check_dims(c, d, n));
+    if (nprob < 1 || M < 0 || M > (1 << 20) || nprob > 65535)
+        return fail(c, BQ_ERR_BAD_ARG, "illegal batch / M");
+    HIPCHK(c, hipSetDevice(c->device));
+    bq_plan *p = new (std::nothrow) bq_plan();
+    if (!p)
+        return fail(c, BQ_ERR_NOMEM, "out of host memory");
+    p->nprob = (int)nprob;
+    p->d = (int)d;
+    p->n = (int)n;
+    p->M = (int)M;
+    p->L = make_layout((int)n, (int)M, true);
+    p->lda = pick_ld(p->L.ntot);
+    p->astride = p->lda * (long)p->L.ntot;
+    hipError_t e = hipSuccess;
+    auto A = [&](DevBuf &b, size_t bytes) {
+        if (e == hipSuccess)
+            e = b.alloc(bytes);
+    };
+    A(p->A, sizeof(double) * (size_t)p->astride * nprob);
+    A(p->pts, sizeof(double) * (size_t)d * p->L.ntot * nprob);
+    A(p->y, sizeof(double) * (size_t)p->L.npad * nprob);
+    A(p->gp, sizeof(GaussParams) * (size_t)nprob);
+    A(p->dinv, sizeof(double) * 64 * (size_t)nprob);
+    A(p->info, sizeof(int) * (size_t)nprob);
+    A(p->scal, sizeof(double) * 4 * (size_t)nprob);
+    A(p->mean, sizeof(double) * (size_t)std::max<int64_t>(M, 1) * nprob);
+    A(p->var, sizeof(double) * (size_t)std::max<int64_t>(M, 1) * nprob);
+    if (e != hipSuccess) {
+        delete p;
+        return fail(c, e == hipErrorOutOfMemory ? BQ_ERR_NOMEM : BQ_ERR_HIP,
+                    "plan allocation failed: %s", hipGetErrorString(e));
+    }
+    HIPCHK(c, hipMemsetAsync(p->pts.p, 0, p->pts.bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(p->y.p, 0, p->y.bytes, c->stream));
+    *out = p;
+    return BQ_OK;
+}
+
+extern "C" void bq_plan_destroy(bq_ctx *c, bq_plan *p)
+{
+    if (!p)
+        return;
+    if (c) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+    }
+    delete p;
+}
+
+extern "C" int bq_plan_bytes(bq_plan *p, size_t *bytes)
+{
+    if (!p || !bytes)
+        return BQ_ERR_BAD_ARG;
+    *bytes = p->A.bytes + p->pts.bytes + p->y.bytes + p->gp.bytes + p->dinv.bytes +
+             p->info.bytes + p->scal.bytes + p->mean.bytes + p->var.bytes;
+    return BQ_OK;
+}
+
+extern "C" int bq_plan_set_inputs(bq_ctx *c, bq_plan *p, const double *x, const double *y,
+                                  const double *xo, const double *h, const double *w,
+                                  const double *s)
+{
+    if (!c || !p)
+        return BQ_ERR_BAD_ARG;
+    if (!x || !y || (!xo && p->M) || !h || !w || !s)
+        return fail(c, BQ_ERR_BAD_ARG, "illegal value");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int d = p->d, n = p->n, M = p->M, ntot = p->L.ntot, npad = p->L.npad;
+    p->hgp.resize(p->nprob);
+    for (int b = 0; b < p->nprob; ++b) {
+        BQCHK(check_w(c, d, h[b], w + (size_t)b * d, s[b]));
+        p->hgp[b] = make_params(d, h[b], w + (size_t)b * d, s[b]);
+    }
+    HIPCHK(c, hipMemcpyAsync(p->gp.p, p->hgp.data(), sizeof(GaussParams) * p->nprob,
+                             hipMemcpyHostToDevice, c->stream));
+    // points: x at columns [0,n), xo at [npad, npad+M) of each problem's d x ntot block
+    HIPCHK(c, hipMemcpy2DAsync(p->pts.p, sizeof(double) * d * ntot, x, sizeof(double) * d * n,
+                               sizeof(double) * d * n, p->nprob, hipMemcpyHostToDevice,
+                               c->stream));
+    if (M > 0)
+        HIPCHK(c, hipMemcpy2DAsync(p->pts.d() + (size_t)d * npad, sizeof(double) * d * ntot, xo,
+                                   sizeof(double) * d * M, sizeof(double) * d * M, p->nprob,
+                                   hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(p->y.p, sizeof(double) * npad, y, sizeof(double) * n,
+                               sizeof(double) * n, p->nprob, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    p->has_inputs = true;
+    return BQ_OK;
+}
+
+extern "C" int bq_plan_run(bq_ctx *c, bq_plan *p)
+{
+    if (!c || !p)
+        return BQ_ERR_BAD_ARG;
+    if (!p->has_inputs)
+        return fail(c, BQ_ERR_BAD_ARG, "plan has no inputs");
+    HIPCHK(c, hipMemsetAsync(p->info.p, 0, sizeof(int) * p->nprob, c->stream));
+    BQCHK(launch_assemble(c, p->d, p->pts.d(), (long)p->d * p->L.ntot, p->y.d(), p->L.npad,
+                          static_cast<GaussParams *>(p->gp.p), 1, p->A.d(), p->lda, p->astride,
+                          p->L, p->nprob));
+    BQCHK(enqueue_potrf_partial(c, p->A.d(), p->lda, p->astride, p->nprob, p->L.ntot, p->L.npad,
+                                p->dinv.d(), p->info.i()));
+    {
+        Bracket br(c, BQ_K_REDUCE);
+        hipLaunchKernelGGL(finalize_kernel, dim3(1, 1, p->nprob), dim3(256), 0, c->stream,
+                           p->A.d(), p->lda, p->astride, p->L, p->scal.d(), p->mean.d(),
+                           p->var.d(), (long)std::max(p->M, 1));
+        HIPCHK(c, hipGetLastError());
+    }
+    return BQ_OK;
+}
+
+extern "C" int bq_plan_results(bq_ctx *c, bq_plan *p, double *mean, double *var, double *logml,
+                               int32_t *status)
+{
+    if (!c || !p)
+        return BQ_ERR_BAD_ARG;
+    const int nb = p->nprob, M = p->M;
+    std::vector<double> scal((size_t)nb * 4);
+    std::vector<int> info((size_t)nb);
+    HIPCHK(c, hipMemcpyAsync(scal.data(), p->scal.p, sizeof(double) * 4 * nb,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(info.data(), p->info.p, sizeof(int) * nb, hipMemcpyDeviceToHost,
+                             c->stream));
+    if (mean && M)
+        HIPCHK(c, hipMemcpyAsync(mean, p->mean.p, sizeof(double) * (size_t)M * nb,
+                                 hipMemcpyDeviceToHost, c->stream));
+    if (var && M)
+        HIPCHK(c, hipMemcpyAsync(var, p->var.p, sizeof(double) * (size_t)M * nb,
+                                 hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int b = 0; b < nb; ++b) {
+        if (status)
+            status[b] = info[b];
+        if (logml)
+            logml[b] = info[b] ? -std::numeric_limits<double>::infinity() : scal[(size_t)b * 4];
+    }
+    return BQ_OK;
+}
+
+// ===========================================================================
+// one-shot and batched host entry points built on plans
+// ===========================================================================
+extern "C" int bq_batch_fit_predict(bq_ctx *c, int64_t nprob, const double *x, const double *y,
+                                    int64_t d, int64_t n, double h, const double *w, double s,
+                                    const double *xo, int64_t M, double *mean, double *var,
+                                    double *logml, int32_t *status)
+{
+    BQCHK(check_dims(c, d, n));
+    BQCHK(check_w(c, d, h, w, s));
+    if (nprob < 1)
+        return fail(c, BQ_ERR_BAD_ARG, "nprob < 1");
+    // bound the resident working set: chunks of problems
+    const Layout L = make_layout((int)n, (int)M, true);
+    const size_t per = sizeof(double) * (size_t)pick_ld(L.ntot) * L.ntot;
+    size_t freeb = 0, totalb = 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemGetInfo(&freeb, &totalb));
+    int64_t chunk = std::max<int64_t>(1, (int64_t)((freeb / 2) / per));
+    chunk = std::min<int64_t>(chunk, nprob);
+    bq_plan *p = nullptr;
+    BQCHK(bq_plan_create(c, chunk, d, n, M, &p));
+    std::vector<double> hh((size_t)chunk, h), ss((size_t)chunk, s), ww((size_t)chunk * d);
+    for (int64_t b = 0; b < chunk; ++b)
+        for (int64_t k = 0; k < d; ++k)
+            ww[(size_t)(b * d + k)] = w[k];
+    int st = BQ_OK;
+    for (int64_t p0 = 0; p0 < nprob && st == BQ_OK; p0 += chunk) {
+        const int64_t nb = std::min(chunk, nprob - p0);
+        if (nb != chunk) { // last, smaller chunk: a fresh plan of the right size
+            bq_plan_destroy(c, p);
+            p = nullptr;
+            st = bq_plan_create(c, nb, d, n, M, &p);
+            if (st != BQ_OK)
+                break;
+        }
+        st = bq_plan_set_inputs(c, p, x + (size_t)p0 * d * n, y + (size_t)p0 * n,
+                                xo ? xo + (size_t)p0 * d * M : nullptr, hh.data(), ww.data(),
+                                ss.data());
+        if (st == BQ_OK)
+            st = bq_plan_run(c, p);
+        if (st == BQ_OK)
+            st = bq_plan_results(c, p, mean ? mean + (size_t)p0 * M : nullptr,
+                                 var ? var + (size_t)p0 * M : nullptr,
+                                 logml ? logml + p0 : nullptr, status ? status + p0 : nullptr);
+    }
+    bq_plan_destroy(c, p);
+    return st;
+}
+
+extern "C" int bq_fit_predict(bq_ctx *c, const double *x, const double *y, int64_t d, int64_t n,
+                              double h, const double *w, double s, const double *xo, int64_t M,
+                              double *mean, double *var, double *logml)
+{
+    int32_t status = 0;
+    BQCHK(bq_batch_fit_predict(c, 1, x, y, d, n, h, w, s, xo, M, mean, var, logml, &status));
+    if (status != 0)
+        return fail(c, BQ_ERR_NOT_PD, "matrix is not positive definite");
+    return BQ_OK;
+}
+
+extern "C" int bq_gp_logml_grid(bq_ctx *c, const double *x, const double *y, int64_t d, int64_t n,
+                                const double *h, const double *w, double s, int64_t G, double *out,
+                                int64_t chunk)
+{
+    BQCHK(check_dims(c, d, n));
+    if (!x || !y || !h || !w || !out || G < 1)
+        return fail(c, BQ_ERR_BAD_ARG, "illegal value");
+    HIPCHK(c, hipSetDevice(c->device));
+    const Layout L = make_layout((int)n, 0, true);
+    const size_t per = sizeof(double) * (size_t)pick_ld(L.ntot) * L.ntot;
+    if (chunk <= 0) {
+        size_t freeb = 0, totalb = 0;
+        HIPCHK(c, hipMemGetInfo(&freeb, &totalb));
+        chunk = std::max<int64_t>(1, (int64_t)((freeb / 2) / per));
+    }
+    chunk = std::min<int64_t>(chunk, G);
+    bq_plan *p = nullptr;
+    BQCHK(bq_plan_create(c, chunk, d, n, 0, &p));
+    // the data are shared: replicate x, y once for the chunk
+    std::vector<double> xr((size_t)chunk * d * n), yr((size_t)chunk * n), ss((size_t)chunk, s);
+    for (int64_t b = 0; b < chunk; ++b) {
+        std::memcpy(&xr[(size_t)b * d * n], x, sizeof(double) * d * n);
+        std::memcpy(&yr[(size_t)b * n], y, sizeof(double) * n);
+    }
+    int st = BQ_OK;
+    for (int64_t g0 = 0; g0 < G && st == BQ_OK; g0 += chunk) {
+        const int64_t nb = std::min(chunk, G - g0);
+        if (nb != chunk) {
+            bq_plan_destroy(c, p);
+            p = nullptr;
+            st = bq_plan_create(c, nb, d, n, 0, &p);
+            if (st != BQ_OK)
+                break;
+        }
+        st = bq_plan_set_inputs(c, p, xr.data(), yr.data(), nullptr, h + g0, w + (size_t)g0 * d,
+                                ss.data());
+        if (st == BQ_OK)
+            st = bq_plan_run(c, p);
+        if (st == BQ_OK)
+            st = bq_plan_results(c, p, nullptr, nullptr, out + g0, nullptr);
+    }
+    bq_plan_destroy(c, p);
+    return st;
+}
+
+// ===========================================================================
+// GP fit objects
+// ===========================================================================
+struct bq_fit {
+    int d = 0, n = 0, npad = 0;
+    long ldl = 0;
+    Layout L{}; // layout of the fit system (M = 0, y row)
+    double h = 0, s = 0, w[BQ_MAXD] = {0};
+    GaussParams g{};
+    DevBuf A;     // ntot x ntot bordered factor: L in [0,npad)^2, z in row yrow
+    DevBuf pts;   // d x ntot
+    DevBuf y;     // npad
+    DevBuf gp;    // GaussParams
+    DevBuf dinv;  // npad reciprocal diagonal (+64 scratch for the factorisation)
+    DevBuf misc;  // info (int) + scal[4]
+    DevBuf alpha; // npad, valid if have_alpha
+    bool have_alpha = false;
+    double logml = 0, logdet = 0, qf = 0;
+};
+
+namespace {
+
+int fit_factor(bq_ctx *c, bq_fit *f)
+{
+    const int ntot = f->L.ntot;
+    int *info = f->misc.i();
+    double *scal = f->misc.d() + 2;
+    HIPCHK(c, hipMemcpyAsync(f->gp.p, &f->g, sizeof f->g, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(info, 0, sizeof(int), c->stream));
+    BQCHK(launch_assemble(c, f->d, f->pts.d(), 0, f->y.d(), 0, static_cast<GaussParams *>(f->gp.p),
+                          0, f->A.d(), f->ldl, 0, f->L, 1));
+    double *scratch = f->dinv.d() + f->npad;
+    BQCHK(enqueue_potrf_partial(c, f->A.d(), f->ldl, 0, 1, ntot, f->npad, scratch, info));
+    {
+        Bracket br(c, BQ_K_REDUCE);
+        hipLaunchKernelGGL(finalize_kernel, dim3(1, 1, 1), dim3(256), 0, c->stream, f->A.d(),
+                           f->ldl, 0L, f->L, scal, (double *)nullptr, (double *)nullptr, 1L);
+        HIPCHK(c, hipGetLastError());
+        hipLaunchKernelGGL(diag_recip_kernel, dim3((f->npad + 255) / 256), dim3(256), 0, c->stream,
+                           f->A.d(), f->ldl, 0, f->npad, f->dinv.d(), 0);
+        HIPCHK(c, hipGetLastError());
+    }
+    int hinfo = 0;
+    double hs[4];
+    HIPCHK(c, hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hs, scal, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    f->have_alpha = false;
+    if (hinfo != 0)
+        return fail(c, BQ_ERR_NOT_PD, "matrix is not positive definite");
+    f->logml = hs[0];
+    f->logdet = hs[1];
+    f->qf = hs[2];
+    return BQ_OK;
+}
+
+int fit_alpha(bq_ctx *c, bq_fit *f)
+{
+    if (f->have_alpha)
+        return BQ_OK;
+    // row form: X (64 x npad), row 0 = z = A[yrow, 0:npad]; alpha = (X L^-1)[0, :]
+    DevBuf X;
+    HIPCHK(c, X.alloc(sizeof(double) * 64 * (size_t)f->npad));
+    HIPCHK(c, hipMemsetAsync(X.p, 0, X.bytes, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(X.p, sizeof(double) * 64, f->A.d() + f->L.yrow,
+                               sizeof(double) * f->ldl, sizeof(double), f->npad,
+                               hipMemcpyDeviceToDevice, c->stream));
+    BQCHK(enqueue_backward_rows(c, X.d(), 64, 64, f->A.d(), f->ldl, f->dinv.d(), f->npad));
+    HIPCHK(c, hipMemcpy2DAsync(f->alpha.p, sizeof(double), X.p, sizeof(double) * 64,
+                               sizeof(double), f->npad, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    f->have_alpha = true;
+    return BQ_OK;
+}
+
+} // namespace
+
+extern "C" int bq_gp_fit(bq_ctx *c, const double *x, const double *y, int64_t d, int64_t n,
+                         double h, const double *w, double s, bq_fit **out)
+{
+    if (!out)
+        return BQ_ERR_BAD_ARG;
+    *out = nullptr;
+    BQCHK(check_dims(c, d, n));
+    BQCHK(check_w(c, d, h, w, s));
+    if (!x || !y)
+        return fail(c, BQ_ERR_BAD_ARG, "illegal value");
+    HIPCHK(c, hipSetDevice(c->device));
+    bq_fit *f = new (std::nothrow) bq_fit();
+    if (!f)
+        return fail(c, BQ_ERR_NOMEM, "out of host memory");
+    f->d = (int)d;
+    f->n = (int)n;
+    f->L = make_layout((int)n, 0, true);
+    f->npad = f->L.npad;
+    f->ldl = pick_ld(f->L.ntot);
+    f->h = h;
+    f->s = s;
+    for (int k = 0; k < d; ++k)
+        f->w[k] = w[k];
+    f->g = make_params((int)d, h, w, s);
+    hipError_t e = hipSuccess;
+    auto A = [&](DevBuf &b, size_t bytes) {
+        if (e == hipSuccess)
+            e = b.alloc(bytes);
+    };
+    A(f->A, sizeof(double) * (size_t)f->ldl * f->L.ntot);
+    A(f->pts, sizeof(double) * (size_t)d * f->L.ntot);
+    A(f->y, sizeof(double) * (size_t)f->npad);
+    A(f->gp, sizeof(GaussParams));
+    A(f->dinv, sizeof(double) * ((size_t)f->npad + 64));
+    A(f->misc, sizeof(double) * 8);
+    A(f->alpha, sizeof(double) * (size_t)f->npad);
+    if (e != hipSuccess) {
+        delete f;
+        return fail(c, e == hipErrorOutOfMemory ? BQ_ERR_NOMEM : BQ_ERR_HIP,
+                    "fit allocation failed: %s", hipGetErrorString(e));
+    }
+    int st = BQ_OK;
+    auto H = [&](hipError_t err) {
+        if (st == BQ_OK && err != hipSuccess)
+            st = fail(c, BQ_ERR_HIP, "fit upload failed: %s", hipGetErrorString(err));
+    };
+    H(hipMemsetAsync(f->pts.p, 0, f->pts.bytes, c->stream));
+    H(hipMemsetAsync(f->y.p, 0, f->y.bytes, c->stream));
+    H(hipMemcpyAsync(f->pts.p, x, sizeof(double) * d * n, hipMemcpyHostToDevice, c->stream));
+    H(hipMemcpyAsync(f->y.p, y, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    if (st == BQ_OK)
+        st = fit_factor(c, f);
+    if (st != BQ_OK) {
+        (void)hipStreamSynchronize(c->stream);
+        delete f;
+        return st;
+    }
+    *out = f;
+    return BQ_OK;
+}
+
+extern "C" int bq_gp_refit(bq_ctx *c, bq_fit *f, double h, const double *w, double s)
+{
+    if (!c || !f)
+        return BQ_ERR_BAD_ARG;
+    BQCHK(check_w(c, f->d, h, w, s));
+    HIPCHK(c, hipSetDevice(c->device));
+    f->h = h;
+    f->s = s;
+    for (int k = 0; k < f->d; ++k)
+        f->w[k] = w[k];
+    f->g = make_params(f->d, h, w, s);
+    return fit_factor(c, f);
+}
+
+extern "C" void bq_fit_destroy(bq_ctx *c, bq_fit *f)
+{
+    if (!f)
+        return;
+    if (c) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+    }
+    delete f;
+}
+
+extern "C" int bq_gp_logml(bq_ctx *c, bq_fit *f, double *out)
+{
+    if (!c || !f || !out)
+        return BQ_ERR_BAD_ARG;
+    *out = f->logml;
+    return BQ_OK;
+}
+
+extern "C" int bq_gp_get(bq_ctx *c, bq_fit *f, int which, double *out)
+{
+    if (!c || !f || !out)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int n = f->n;
+    switch (which) {
+    case 0: { // L, strict upper zeroed
+        HIPCHK(c, hipMemcpy2DAsync(out, sizeof(double) * n, f->A.p, sizeof(double) * f->ldl,
+                                   sizeof(double) * n, n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int j = 1; j < n; ++j)
+            for (int i = 0; i < j; ++i)
+                out[i + (size_t)j * n] = 0.0;
+        return BQ_OK;
+    }
+    case 1:
+        BQCHK(fit_alpha(c, f));
+        HIPCHK(c, hipMemcpyAsync(out, f->alpha.p, sizeof(double) * n, hipMemcpyDeviceToHost,
+                                 c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return BQ_OK;
+    case 2:
+        HIPCHK(c, hipMemcpy2DAsync(out, sizeof(double), f->A.d() + f->L.yrow,
+                                   sizeof(double) * f->ldl, sizeof(double), n,
+                                   hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return BQ_OK;
+    case 3: {
+        DevBuf K;
+        HIPCHK(c, K.alloc(sizeof(double) * (size_t)n * n));
+        BQCHK(launch_gram_sym(c, f->d, f->pts.d(), 0, static_cast<GaussParams *>(f->gp.p), 0,
+                              K.d(), n, 0, n, 1));
+        HIPCHK(c, hipMemcpyAsync(out, K.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost,
+                                 c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return BQ_OK;
+    }
+    default:
+        return fail(c, BQ_ERR_BAD_ARG, "unknown item %d", which);
+    }
+}
+
+extern "C" int bq_gp_predict(bq_ctx *c, bq_fit *f, const double *xo, int64_t M, double *mean,
+                             double *var, double *cov)
+{
+    if (!c || !f)
+        return BQ_ERR_BAD_ARG;
+    if (M < 0 || (M && !xo))
+        return fail(c, BQ_ERR_BAD_ARG, "illegal value");
+    if (M == 0)
+        return BQ_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int d = f->d, n = f->n, npad = f->npad;
+    const int Mp = (int)roundup(M, 64);
+    DevBuf xod, out;
+    HIPCHK(c, xod.alloc(sizeof(double) * d * M));
+    HIPCHK(c, out.alloc(sizeof(double) * 2 * (size_t)Mp));
+    HIPCHK(c, hipMemcpyAsync(xod.p, xo, sizeof(double) * d * M, hipMemcpyHostToDevice, c->stream));
+    GaussParams g = f->g;
+    if (!var && !cov) {
+        // mean only: fused cross-Gram x alpha
+        BQCHK(fit_alpha(c, f));
+        Bracket br(c, BQ_K_REDUCE);
+        dim3 grid((unsigned)((M + 3) / 4));
+#define PM(D_)                                                                                     \
+    hipLaunchKernelGGL(predict_mean_kernel<D_>, grid, dim3(256), 0, c->stream, xod.d(), (int)M,    \
+                       f->pts.d(), n, f->alpha.d(), g, out.d())
+        switch (d) {
+        case 1: PM(1); break;
+        case 2: PM(2); break;
+        case 3: PM(3); break;
+        case 4: PM(4); break;
+        case 5: PM(5); break;
+        case 6: PM(6); break;
+        case 7: PM(7); break;
+        default: PM(8); break;
+        }
+#undef PM
+        HIPCHK(c, hipGetLastError());
+    } else {
+        // V = K(xo, x) L^-T by a forward sweep with rows = prediction points
+        DevBuf V;
+        HIPCHK(c, V.alloc(sizeof(double) * (size_t)Mp * npad));
+        HIPCHK(c, hipMemsetAsync(V.p, 0, V.bytes, c->stream));
+        BQCHK(launch_gram_cross(c, d, xod.d(), (int)M, f->pts.d(), n, g, V.d(), Mp));
+        BQCHK(enqueue_forward_rows(c, V.d(), Mp, Mp, f->A.d(), f->ldl, f->dinv.d(), npad));
+        // z lives in row yrow of the factor with stride ldl: gather it
+        DevBuf z;
+        HIPCHK(c, z.alloc(sizeof(double) * npad));
+        HIPCHK(c, hipMemcpy2DAsync(z.p, sizeof(double), f->A.d() + f->L.yrow,
+                                   sizeof(double) * f->ldl, sizeof(double), npad,
+                                   hipMemcpyDeviceToDevice, c->stream));
+        {
+            Bracket br(c, BQ_K_REDUCE);
+            hipLaunchKernelGGL(rowdot_kernel, dim3(Mp / 64), dim3(256), 0, c->stream, V.d(),
+                               (long)Mp, (int)M, npad, z.d(), g.c, out.d(), out.d() + Mp);
+            HIPCHK(c, hipGetLastError());
+        }
+        if (cov) {
+            // cov = K(xo,xo) - V V^T  (Mp x Mp on device, M x M out)
+            DevBuf Cd, gd;
+            HIPCHK(c, Cd.alloc(sizeof(double) * (size_t)Mp * Mp));
+            HIPCHK(c, gd.alloc(sizeof(GaussParams)));
+            GaussParams g0 = g;
+            g0.s2 = 0.0;
+            HIPCHK(c, hipMemsetAsync(Cd.p, 0, Cd.bytes, c->stream));
+            HIPCHK(c, hipMemcpyAsync(gd.p, &g0, sizeof g0, hipMemcpyHostToDevice, c->stream));
+            BQCHK(launch_gram_sym(c, d, xod.d(), 0, static_cast<GaussParams *>(gd.p), 0, Cd.d(),
+                                  Mp, 0, (int)M, 1));
+            BQCHK(launch_gemm(c, BQ_K_GEMM, Cd.d(), Mp, 0, V.d(), Mp, 0, V.d(), 1, Mp, 0, Mp, Mp,
+                              npad, 0, 1));
+            HIPCHK(c, hipMemcpy2DAsync(cov, sizeof(double) * M, Cd.p, sizeof(double) * Mp,
+                                       sizeof(double) * M, M, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream)); // V, z, Cd go out of scope
+    }
+    if (mean)
+        HIPCHK(c, hipMemcpyAsync(mean, out.p, sizeof(double) * M, hipMemcpyDeviceToHost,
+                                 c->stream));
+    if (var)
+        HIPCHK(c, hipMemcpyAsync(var, out.d() + Mp, sizeof(double) * M, hipMemcpyDeviceToHost,
+                                 c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BQ_OK;
+}
+
+// ===========================================================================
+// hardware probes
+// ===========================================================================
+extern "C" int bq_probe_mfma_f64(bq_ctx *c, double *tflops)
+{
+    if (!c || !tflops)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf o;
+    HIPCHK(c, o.alloc(64));
+    const int iters = 4096, blocks = c->cus * 8; // 2 waves per SIMD
+    hipLaunchKernelGGL(probe_mfma_kernel, dim3(blocks), dim3(256), 0, c->stream, o.d(), 64);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    BQCHK(bq_timer_start(c));
+    hipLaunchKernelGGL(probe_mfma_kernel, dim3(blocks), dim3(256), 0, c->stream, o.d(), iters);
+    BQCHK(bq_timer_stop_ms(c, &ms));
+    const double flops = (double)blocks * 4 /*waves*/ * iters * 4 /*mfma*/ * (16.0 * 16 * 4 * 2);
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    return BQ_OK;
+}
+
+extern "C" int bq_probe_fma_f64(bq_ctx *c, double *tflops)
+{
+    if (!c || !tflops)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf o;
+    HIPCHK(c, o.alloc(64));
+    const int iters = 1 << 16, blocks = c->cus * 8;
+    hipLaunchKernelGGL(probe_fma_kernel, dim3(blocks), dim3(256), 0, c->stream, o.d(), 64);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    BQCHK(bq_timer_start(c));
+    hipLaunchKernelGGL(probe_fma_kernel, dim3(blocks), dim3(256), 0, c->stream, o.d(), iters);
+    BQCHK(bq_timer_stop_ms(c, &ms));
+    const double flops = (double)blocks * 256 * (double)iters * 8 * 2;
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    return BQ_OK;
+}
+
+extern "C" int bq_probe_hbm(bq_ctx *c, size_t bytes, double *write_gbs, double *copy_gbs)
+{
+    if (!c || bytes < 4096)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf a, b;
+    HIPCHK(c, a.alloc(bytes));
+    HIPCHK(c, b.alloc(bytes));
+    const size_t n2 = bytes / 16;
+    const int blocks = c->cus * 8;
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        BQCHK(bq_timer_start(c));
+        for (int i = 0; i < 5; ++i)
+            hipLaunchKernelGGL(probe_write_kernel, dim3(blocks), dim3(256), 0, c->stream,
+                               static_cast<double2_t *>(a.p), n2);
+        BQCHK(bq_timer_stop_ms(c, &ms));
+    }
+    if (write_gbs)
+        *write_gbs = 5.0 * bytes / (ms * 1e-3) / 1e9;
+    for (int rep = 0; rep < 2; ++rep) {
+        BQCHK(bq_timer_start(c));
+        for (int i = 0; i < 5; ++i)
+            hipLaunchKernelGGL(probe_copy_kernel, dim3(blocks), dim3(256), 0, c->stream,
+                               static_cast<double2_t *>(b.p), static_cast<const double2_t *>(a.p),
+                               n2);
+        BQCHK(bq_timer_stop_ms(c, &ms));
+    }
+    if (copy_gbs)
+        *copy_gbs = 5.0 * 2.0 * bytes / (ms * 1e-3) / 1e9;
+    return BQ_OK;
+}
+
+extern "C" int bq_probe_mfma_layout(bq_ctx *c, double *out256)
+{
+    if (!c || !out256)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf o;
+    HIPCHK(c, o.alloc(256 * sizeof(double)));
+    hipLaunchKernelGGL(probe_layout_kernel, dim3(1), dim3(64), 0, c->stream, o.d());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out256, o.p, 256 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BQ_OK;
+}

@@ -1,0 +1,771 @@
+// kernels.h -- gfx950 (CDNA4) device kernels of libbqhip.so.
+//
+// Everything here is fp64 and column-major.  All kernels take a batch
+// dimension in blockIdx.z (independent problems / hyper-parameter points) with
+// element strides, so one launch covers a whole shard of problems.
+//
+// Kernel inventory (DESIGN.md has the roofline of each):
+//   gram_sym_kernel       full symmetric Gaussian Gram (HBM-write bound)
+//   gram_cross_kernel     rectangular Gram
+//   assemble_kernel       lower triangle of the bordered GP system
+//   potf2_64_kernel       64x64 diagonal Cholesky, one wave, register resident
+//   trsm_rows_kernel      panel solve X <- X L11^-T (or X L11^-1), row per lane
+//   gemm_sub_kernel       C -= P Q^T on v_mfma_f64_16x16x4_f64 (panel + trailing)
+//   finalize_kernel       log-det / log-ML / posterior mean+var read-out
+//   rowdot_kernel, predict_mean_kernel, misc copies
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BQ_MAXD 8
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// Gaussian kernel parameters of one batch element:
+//   k(p,q) = c * exp( sum_k nh[k] (p_k - q_k)^2 ),  c = h^2 / prod(sqrt(2 pi) w_k),
+//   nh[k] = -1 / (2 w_k^2);  s2 = s^2 is added on the diagonal of Kxx.
+struct GaussParams {
+    double c;
+    double s2;
+    double nh[BQ_MAXD];
+};
+
+// Pins a value's computation at this point of the program: without it LLVM
+// sinks the rank-1 updates of the right-looking factorisations down to their
+// first use (a left-looking schedule), keeps every broadcast multiplier alive
+// and spills thousands of registers.
+#define PIN(v) asm volatile("" : "+v"(v))
+
+__device__ __forceinline__ double readlane_f64(double v, int srclane)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, srclane);
+    hi = __builtin_amdgcn_readlane(hi, srclane);
+    return __hiloint2double(hi, lo);
+}
+
+template <int D>
+__device__ __forceinline__ double gauss_q(const double *p, const double *q, const GaussParams &g)
+{
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const double t = p[k] - q[k];
+        acc += (t * t) * g.nh[k];
+    }
+    return acc;
+}
+
+// ---------------------------------------------------------------------------
+// Full symmetric Gram, K[i,j] = k(x_i,x_j) + s2 [i==j].
+// Block = 256 threads = a 128(i) x 64(j) tile: lane pairs two consecutive rows
+// (one 16-byte store), a wave stores 1 KiB of one column per instruction, the
+// four waves take 16 columns each.  x is d x n.
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void gram_sym_kernel(const double *__restrict__ x, long xstride,
+                                                       const GaussParams *__restrict__ gp,
+                                                       int gpstride, double *__restrict__ K,
+                                                       long ldk, long kstride, int n)
+{
+    const int b = blockIdx.z;
+    x += (long)b * xstride;
+    K += (long)b * kstride;
+    const GaussParams g = gp[(long)b * gpstride];
+    const int t = threadIdx.x;
+    const int i = blockIdx.x * 128 + (t & 63) * 2;
+    const int jbase = blockIdx.y * 64 + (t >> 6) * 16;
+    if (i >= n)
+        return;
+    const bool two = (i + 1 < n);
+    double xi0[D], xi1[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        xi0[k] = x[k + (long)i * D];
+        xi1[k] = two ? x[k + (long)(i + 1) * D] : 0.0;
+    }
+    const bool vec = two && ((ldk & 1) == 0);
+#pragma unroll 4
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = jbase + jj;
+        if (j >= n)
+            break;
+        double xj[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            xj[k] = x[k + (long)j * D];
+        double v0 = g.c * exp(gauss_q<D>(xi0, xj, g));
+        double v1 = g.c * exp(gauss_q<D>(xi1, xj, g));
+        if (i == j)
+            v0 += g.s2;
+        if (i + 1 == j)
+            v1 += g.s2;
+        double *dst = K + i + (long)j * ldk;
+        if (vec) {
+            double2_t v = {v0, v1};
+            *reinterpret_cast<double2_t *>(dst) = v;
+        } else {
+            dst[0] = v0;
+            if (two)
+                dst[1] = v1;
+        }
+    }
+}
+
+// Rectangular Gram K[i,j] = k(x1_i, x2_j), n1 x n2, ld = ldk.
+template <int D>
+__global__ __launch_bounds__(256) void gram_cross_kernel(const double *__restrict__ x1, int n1,
+                                                         const double *__restrict__ x2, int n2,
+                                                         GaussParams g, double *__restrict__ K,
+                                                         long ldk)
+{
+    const int t = threadIdx.x;
+    const int i = blockIdx.x * 64 + (t & 63);
+    const int jbase = blockIdx.y * 64 + (t >> 6) * 16;
+    if (i >= n1)
+        return;
+    double xi[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+        xi[k] = x1[k + (long)i * D];
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = jbase + jj;
+        if (j >= n2)
+            break;
+        double xj[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            xj[k] = x2[k + (long)j * D];
+        K[i + (long)j * ldk] = g.c * exp(gauss_q<D>(xi, xj, g));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Bordered GP system, lower triangle only (tiles strictly above the diagonal
+// are skipped).  Index space of size ntot (multiple of 64):
+//   [0, n)              samples x            -> Kxx + s2 I
+//   [n, npad)           identity padding     -> delta_ij
+//   [npad, npad + M)    prediction points xo -> K(xo, x), K(xo, xo)
+//   yrow = npad + M     (if has_y) the row y^T, zero elsewhere, zero diagonal
+//   (yrow, ntot)        identity padding
+// pts is d x ntot with x at [0,n) and xo at [npad, npad+M); other columns are
+// never read.  After eliminating the first npad columns, the Schur complement
+// holds the posterior covariance, -mean in row yrow and -y'K^-1 y at
+// (yrow, yrow); see DESIGN.md.
+// ---------------------------------------------------------------------------
+struct Layout {
+    int n, npad, M, yrow, ntot; // yrow < 0: no y row
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void assemble_kernel(const double *__restrict__ pts,
+                                                       long pstride, const double *__restrict__ y,
+                                                       long ystride,
+                                                       const GaussParams *__restrict__ gp,
+                                                       int gpstride, double *__restrict__ A,
+                                                       long lda, long astride, Layout L)
+{
+    const int b = blockIdx.z;
+    const int t = threadIdx.x;
+    const int ib = blockIdx.x * 128, jb = blockIdx.y * 64;
+    if (jb > ib + 127) // whole tile strictly above the diagonal
+        return;
+    pts += (long)b * pstride;
+    y += (long)b * ystride;
+    A += (long)b * astride;
+    const GaussParams g = gp[(long)b * gpstride];
+    const int i = ib + (t & 63) * 2;
+    const int jbase = jb + (t >> 6) * 16;
+    if (i >= L.ntot)
+        return;
+    bool pi[2];
+    double xi[2][D];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int ii = i + r;
+        pi[r] = (ii < L.n) || (ii >= L.npad && ii < L.npad + L.M);
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            xi[r][k] = pi[r] ? pts[k + (long)ii * D] : 0.0;
+    }
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = jbase + jj;
+        if (j >= L.ntot)
+            break;
+        const bool pj = (j < L.n) || (j >= L.npad && j < L.npad + L.M);
+        double xj[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            xj[k] = pj ? pts[k + (long)j * D] : 0.0;
+        double v[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int ii = i + r;
+            double val;
+            if (pi[r] && pj) {
+                val = g.c * exp(gauss_q<D>(xi[r], xj, g));
+                if (ii == j && ii < L.n)
+                    val += g.s2;
+            } else if (ii == L.yrow) {
+                val = (j < L.n) ? y[j] : 0.0;
+            } else {
+                val = (ii == j) ? 1.0 : 0.0;
+            }
+            v[r] = val;
+        }
+        double2_t vv = {v[0], v[1]};
+        *reinterpret_cast<double2_t *>(A + i + (long)j * lda) = vv; // ntot, lda even
+    }
+}
+
+// ---------------------------------------------------------------------------
+// refined reciprocal square root: v_rsq_f64 seed + two Newton steps, and the
+// square root s = d r with one correction.  Relative error ~1 ulp; the pivot
+// chain is the critical path of the whole factorisation, so it avoids the
+// long div/sqrt library sequences.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void rsqrt_sqrt_f64(double d, double &r, double &s)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    const double hd = 0.5 * d;
+    double t = __builtin_fma(-hd * y, y, 0.5);
+    y = __builtin_fma(y, t, y);
+    t = __builtin_fma(-hd * y, y, 0.5);
+    y = __builtin_fma(y, t, y);
+    double q = d * y;
+    const double e = __builtin_fma(-q, q, d);
+    q = __builtin_fma(0.5 * y, e, q);
+    r = y;
+    s = q;
+}
+
+// ---------------------------------------------------------------------------
+// 64x64 diagonal block: unblocked right-looking Cholesky by ONE wave.  Lane i
+// holds row i in 64 fp64 registers.  Per column: the pivot and the next
+// column's multiplier travel by v_readlane (short dependency chain), the other
+// multipliers l_k are broadcast through LDS (every lane reads the same
+// address), two per ds_read_b128.  Writes the lower triangle back and 1/L_jj
+// to dinv[64].  info[b] receives the 1-based global column of the first
+// non-positive pivot (first failure wins; 0 = ok).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void potf2_64_kernel(double *__restrict__ A, long lda,
+                                                      long astride, int j0,
+                                                      double *__restrict__ dinv, long dstride,
+                                                      int *__restrict__ info)
+{
+    __shared__ __attribute__((aligned(16))) double col[2][64];
+    const int b = blockIdx.z;
+    double *Ab = A + (long)b * astride + j0 + (long)j0 * lda;
+    const int lane = threadIdx.x;
+    double a[64];
+    {
+        const double *pr = Ab + lane;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            a[j] = *pr;
+            pr += lda;
+        }
+    }
+    int bad = 0;
+    double d = readlane_f64(a[0], 0);
+    double r, s;
+    rsqrt_sqrt_f64(d, r, s);
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        if (!(d > 0.0) && bad == 0)
+            bad = j0 + j + 1;
+        const double l = (lane == j) ? s : a[j] * r;
+        a[j] = l;
+        if (lane == j)
+            dinv[(long)b * dstride + j] = r;
+        if (j < 63) {
+            // next pivot first, by readlane: its rsqrt chain is issued ahead of
+            // the LDS-fed updates of this column and overlaps them
+            a[j + 1] -= l * readlane_f64(l, j + 1);
+            d = readlane_f64(a[j + 1], j + 1);
+            rsqrt_sqrt_f64(d, r, s);
+            if (j < 62) {
+                col[j & 1][lane] = l;
+                __syncthreads();
+                const double2_t *c2 = reinterpret_cast<const double2_t *>(col[j & 1]);
+#pragma unroll
+                for (int kk = (j + 2) >> 1; kk < 32; ++kk) {
+                    const double2_t lk = c2[kk];
+                    if (2 * kk >= j + 2) {
+                        a[2 * kk] -= l * lk[0];
+                        PIN(a[2 * kk]);
+                    }
+                    a[2 * kk + 1] -= l * lk[1];
+                    PIN(a[2 * kk + 1]);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // fresh per-lane pointer: without the opaque copy the compiler keeps the 64
+    // load addresses alive across the whole factorisation and spills
+    double *pw = Ab + lane;
+    asm volatile("" : "+v"(pw));
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        if (lane >= j)
+            *pw = a[j];
+        pw += lda;
+    }
+    if (lane == 0 && bad != 0 && info[b] == 0)
+        info[b] = bad;
+}
+
+// ---------------------------------------------------------------------------
+// Panel solve, one row per lane, 64 columns in registers; one wave per block.
+//   TRANS = true : X <- X * L11^-T   (forward substitution; Cholesky panel,
+//                                     forward solves with rows = right-hand sides)
+//   TRANS = false: X <- X * L11^-1   (backward substitution; the L^T sweep)
+// X = rows of the panel (leading dimension ldx), L11 = 64x64 lower block
+// (leading dimension ldl) with reciprocal diagonal dinv[64].  L11 is staged
+// once into LDS (TRANS: as stored; else transposed) and its entries are read
+// back as wave-wide broadcasts, two per ds_read_b128.
+// ---------------------------------------------------------------------------
+template <bool TRANS>
+__global__ __launch_bounds__(64) void trsm_rows_kernel(double *__restrict__ X, long ldx,
+                                                       long xstride, int m,
+                                                       const double *__restrict__ Lm, long ldl,
+                                                       long lstride,
+                                                       const double *__restrict__ dinv,
+                                                       long dstride)
+{
+    // T[p][j]: multiplier of x_p in the update of x_j, rows of 64 doubles
+    __shared__ __attribute__((aligned(16))) double T[64 * 64];
+    __shared__ __attribute__((aligned(16))) double di[64];
+    const int b = blockIdx.z;
+    const int lane = threadIdx.x;
+    const int row = blockIdx.x * 64 + lane;
+    X += (long)b * xstride;
+    const double *L11 = Lm + (long)b * lstride;
+    if (TRANS) {
+        // x_j -= L11[j][p] x_p (j > p): T[p][j] = L11[j + p ldl], coalesced copy
+#pragma unroll 8
+        for (int p = 0; p < 64; ++p)
+            T[p * 64 + lane] = L11[lane + (long)p * ldl];
+    } else {
+        // x_j -= L11[p][j] x_p (j < p): T[p][j] = L11[p + j ldl]; lane = p keeps
+        // the global read coalesced, the LDS write is strided (once per block)
+#pragma unroll 8
+        for (int j = 0; j < 64; ++j)
+            T[lane * 64 + j] = L11[lane + (long)j * ldl];
+    }
+    di[lane] = dinv[(long)b * dstride + lane];
+    const bool ok = row < m;
+    double x[64];
+    {
+        const double *pr = X + (ok ? row : 0);
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            x[j] = *pr;
+            pr += ldx;
+        }
+    }
+    __syncthreads();
+    if (TRANS) {
+#pragma unroll
+        for (int p = 0; p < 64; ++p) {
+            const double xp = x[p] * di[p];
+            x[p] = xp;
+            const double2_t *t2 = reinterpret_cast<const double2_t *>(T + p * 64);
+#pragma unroll
+            for (int kk = (p + 1) >> 1; kk < 32; ++kk) {
+                const double2_t l = t2[kk];
+                if (2 * kk >= p + 1) {
+                    x[2 * kk] -= l[0] * xp;
+                    PIN(x[2 * kk]);
+                }
+                x[2 * kk + 1] -= l[1] * xp;
+                PIN(x[2 * kk + 1]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int p = 63; p >= 0; --p) {
+            const double xp = x[p] * di[p];
+            x[p] = xp;
+            const double2_t *t2 = reinterpret_cast<const double2_t *>(T + p * 64);
+#pragma unroll
+            for (int kk = 0; 2 * kk < p; ++kk) {
+                const double2_t l = t2[kk];
+                x[2 * kk] -= l[0] * xp;
+                PIN(x[2 * kk]);
+                if (2 * kk + 1 < p) {
+                    x[2 * kk + 1] -= l[1] * xp;
+                    PIN(x[2 * kk + 1]);
+                }
+            }
+        }
+    }
+    if (ok) {
+        double *pw = X + row; // opaque copy: see potf2_64_kernel
+        asm volatile("" : "+v"(pw));
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            *pw = x[j];
+            pw += ldx;
+        }
+    }
+}
+
+// reciprocal diagonal of a resident factor: dinv[j] = 1 / L[j0+j, j0+j]
+__global__ void diag_recip_kernel(const double *__restrict__ Lm, long ldl, long lstride, int n,
+                                  double *__restrict__ dinv, long dstride)
+{
+    const int b = blockIdx.z;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n)
+        dinv[(long)b * dstride + j] = 1.0 / Lm[(long)b * lstride + j + (long)j * ldl];
+}
+
+// ---------------------------------------------------------------------------
+// C(m x n) -= P(m x k) * Q(n x k)^T on v_mfma_f64_16x16x4_f64.
+//
+// P element (i,kk) at P[i + kk*ldp].  Q element (j,kk) at Q[j*qsj + kk*qsk]:
+//   (qsj,qsk) = (1, ldq)  -> Q^T product (Cholesky panel / trailing update)
+//   (qsj,qsk) = (ldq, 1)  -> plain product with a k x n matrix (L^T sweep)
+// A workgroup is 4 waves in a 2 x 2 arrangement; each wave owns a
+// (16 TM) x (16 TN) tile built from TM x TN MFMA tiles and streams its A/B
+// fragments straight from global memory (L2-resident panel) into registers,
+// software-pipelined one k-step (4 columns) ahead.  The MFMA is issued as
+// D^T = Q_frag * P_frag^T so that the 16 lanes that share a D register row
+// cover 16 consecutive ROWS of C: the read-modify-write of C then moves whole
+// 128-byte lines (C is column-major).
+//   f64 16x16x4 operand map: lane l supplies A[l&15][l>>4] and B[l>>4][l&15];
+//   D register r of lane l is D[(l>>4) + 4 r][l & 15]   (probed on gfx950 by
+//   bq_probe_mfma_layout; tests/test_gpu_probe.py asserts it).
+// lower != 0: skip wave tiles that lie strictly above the diagonal of C
+// (C square, trailing update); m, n multiples of 16 TM / 16 TN are not
+// required, out-of-range wave tiles exit, but m and n must be multiples of 16
+// and k a multiple of 8.
+// ---------------------------------------------------------------------------
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C, long ldc,
+                                                       long cstride, const double *__restrict__ P,
+                                                       long ldp, long pstride,
+                                                       const double *__restrict__ Q, long qsj,
+                                                       long qsk, long qstride, int m, int n,
+                                                       int k, int lower)
+{
+    const int b = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 2 + (wave & 1)) * (TM * 16);
+    const int col0 = (blockIdx.y * 2 + (wave >> 1)) * (TN * 16);
+    if (row0 >= m || col0 >= n)
+        return;
+    if (lower && col0 >= row0 + TM * 16)
+        return;
+    C += (long)b * cstride;
+    P += (long)b * pstride;
+    Q += (long)b * qstride;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    // clamp fragment rows at the edge (m, n multiples of 16 but maybe not of
+    // the wave tile): out-of-range MFMA tiles are computed on clamped rows and
+    // dropped at the store.
+    const double *pp[TM];
+    const double *qq[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        int r = row0 + tm * 16;
+        if (r >= m)
+            r = row0;
+        pp[tm] = P + r + l15 + (long)l4 * ldp;
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        int c = col0 + tn * 16;
+        if (c >= n)
+            c = col0;
+        qq[tn] = Q + (long)(c + l15) * qsj + (long)l4 * qsk;
+    }
+
+    double4_t acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    double pa[TM], qa[TN], pb[TM], qb[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+        pa[tm] = pp[tm][0];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+        qa[tn] = qq[tn][0];
+    const long pstep = 4 * ldp, qstep = 4 * qsk;
+    const int ksteps = k >> 2; // even (k is a multiple of 8): the body below has no branch
+    for (int ks = 0; ks < ksteps; ks += 2) {
+        // fragments of step ks+1 are requested before the MFMAs of step ks issue,
+        // those of step ks+2 before the MFMAs of step ks+1
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+            pb[tm] = pp[tm][(long)(ks + 1) * pstep];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+            qb[tn] = qq[tn][(long)(ks + 1) * qstep];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] =
+                    __builtin_amdgcn_mfma_f64_16x16x4f64(qa[tn], pa[tm], acc[tm][tn], 0, 0, 0);
+        const long o2 = (ks + 2 < ksteps) ? (long)(ks + 2) : (long)ks; // clamped, value unused
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+            pa[tm] = pp[tm][o2 * pstep];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+            qa[tn] = qq[tn][o2 * qstep];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] =
+                    __builtin_amdgcn_mfma_f64_16x16x4f64(qb[tn], pb[tm], acc[tm][tn], 0, 0, 0);
+    }
+
+    // D^T tile: D[jj][ii], jj = l4 + 4 r (column of C), ii = l15 (row of C)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int r = row0 + tm * 16;
+        if (r >= m)
+            continue;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int c = col0 + tn * 16;
+            if (c >= n)
+                continue;
+            if (lower && c >= r + 16)
+                continue;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                double *dst = C + (r + l15) + (long)(c + l4 + 4 * rr) * ldc;
+                *dst -= acc[tm][tn][rr];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Read-out after the bordered elimination (one block per problem):
+//   logdet = 2 sum_{i<n} log L_ii,  qf = -S[yrow,yrow] = y' Kxx^-1 y,
+//   logml  = -qf/2 - logdet/2 - n/2 log 2 pi,
+//   mean_i = -S[yrow, i],  var_i = S[i,i]   (S = Schur complement at npad)
+// scal[b*4 + {0,1,2}] = logml, logdet, qf.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict__ A, long lda,
+                                                       long astride, Layout L,
+                                                       double *__restrict__ scal,
+                                                       double *__restrict__ mean,
+                                                       double *__restrict__ var, long mstride)
+{
+    const int b = blockIdx.z;
+    A += (long)b * astride;
+    const int t = threadIdx.x;
+    double s = 0.0;
+    for (int i = t; i < L.n; i += 256)
+        s += log(A[i + (long)i * lda]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        s += __shfl_down(s, off, 64);
+    __shared__ double part[4];
+    if ((t & 63) == 0)
+        part[t >> 6] = s;
+    __syncthreads();
+    if (t == 0) {
+        const double logdet = 2.0 * (part[0] + part[1] + part[2] + part[3]);
+        double qf = 0.0, logml = 0.0;
+        if (L.yrow >= 0) {
+            qf = -A[L.yrow + (long)L.yrow * lda];
+            logml = -0.5 * qf - 0.5 * logdet - 0.5 * (double)L.n * 1.8378770664093453; // log 2pi
+        }
+        scal[b * 4 + 0] = logml;
+        scal[b * 4 + 1] = logdet;
+        scal[b * 4 + 2] = qf;
+    }
+    for (int i = t; i < L.M; i += 256) {
+        const long c = L.npad + i;
+        if (var)
+            var[(long)b * mstride + i] = A[c + c * lda];
+        if (mean && L.yrow >= 0)
+            mean[(long)b * mstride + i] = -A[L.yrow + c * lda];
+    }
+}
+
+// per-row reductions of a solved border V (m x n, ld = ldv), z (n):
+//   mean_i = sum_j V[i,j] z[j],   var_i = k0 - sum_j V[i,j]^2
+__global__ __launch_bounds__(256) void rowdot_kernel(const double *__restrict__ V, long ldv, int m,
+                                                     int n, const double *__restrict__ z,
+                                                     double k0, double *__restrict__ mean,
+                                                     double *__restrict__ var)
+{
+    // block = 64 rows x 4 column slices
+    const int t = threadIdx.x;
+    const int row = blockIdx.x * 64 + (t & 63);
+    const int sl = t >> 6;
+    double sm = 0.0, sv = 0.0;
+    if (row < m)
+        for (int j = sl; j < n; j += 4) {
+            const double v = V[row + (long)j * ldv];
+            sm += v * (z ? z[j] : 0.0);
+            sv += v * v;
+        }
+    __shared__ double pm[4][64], pv[4][64];
+    pm[sl][t & 63] = sm;
+    pv[sl][t & 63] = sv;
+    __syncthreads();
+    if (sl == 0 && row < m) {
+        const int r = t & 63;
+        if (mean)
+            mean[row] = (pm[0][r] + pm[1][r]) + (pm[2][r] + pm[3][r]);
+        if (var)
+            var[row] = k0 - ((pv[0][r] + pv[1][r]) + (pv[2][r] + pv[3][r]));
+    }
+}
+
+// mean_i = sum_j k(xo_i, x_j) alpha_j : fused cross-Gram x GEMV, one wave per
+// 64 outputs?  No: one block of 256 threads per output point slice would
+// starve; use one wave per output point, lanes stride over j.
+template <int D>
+__global__ __launch_bounds__(256) void predict_mean_kernel(const double *__restrict__ xo, int M,
+                                                           const double *__restrict__ x, int n,
+                                                           const double *__restrict__ alpha,
+                                                           GaussParams g, double *__restrict__ mean)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= M)
+        return;
+    double p[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+        p[k] = xo[k + (long)i * D];
+    double s = 0.0;
+    for (int j = lane; j < n; j += 64) {
+        double q[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            q[k] = x[k + (long)j * D];
+        s += exp(gauss_q<D>(p, q, g)) * alpha[j];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        s += __shfl_down(s, off, 64);
+    if (lane == 0)
+        mean[i] = g.c * s;
+}
+
+// dst(rows x cols, ld ldd) <- src(rows x cols, ld lds); optional transpose
+__global__ void copy2d_kernel(double *__restrict__ dst, long ldd, const double *__restrict__ src,
+                              long lds, int rows, int cols, int transpose_src)
+{
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
+    if (i >= rows)
+        return;
+    for (int j = j0; j < j0 + 4 && j < cols; ++j)
+        dst[i + (long)j * ldd] = transpose_src ? src[j + (long)i * lds] : src[i + (long)j * lds];
+}
+
+// A <- identity on the padding square [n, ntot) and zero in the padding
+// rows/cols of the lower triangle (used by the linalg drop-ins)
+__global__ void pad_identity_kernel(double *__restrict__ A, long lda, int n, int ntot)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= ntot || j >= ntot)
+        return;
+    if (i >= n || j >= n)
+        A[i + (long)j * lda] = (i == j) ? 1.0 : 0.0;
+}
+
+// 2 sum log diag, one block
+__global__ __launch_bounds__(256) void logdet_kernel(const double *__restrict__ A, long lda, int n,
+                                                     double *__restrict__ out)
+{
+    const int t = threadIdx.x;
+    double s = 0.0;
+    for (int i = t; i < n; i += 256)
+        s += log(A[i + (long)i * lda]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        s += __shfl_down(s, off, 64);
+    __shared__ double part[4];
+    if ((t & 63) == 0)
+        part[t >> 6] = s;
+    __syncthreads();
+    if (t == 0)
+        out[0] = 2.0 * (part[0] + part[1] + part[2] + part[3]);
+}
+
+// ---------------------------------------------------------------------------
+// hardware probes
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void probe_mfma_kernel(double *out, int iters)
+{
+    double4_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    const double a = 1.0 + threadIdx.x * 1e-9, bb = 1.0 - threadIdx.x * 1e-9;
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c3, 0, 0, 0);
+    }
+    c0 += c1 + c2 + c3;
+    if (c0[0] == 123.456)
+        out[0] = c0[1];
+}
+
+__global__ __launch_bounds__(256) void probe_fma_kernel(double *out, int iters)
+{
+    double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5,
+           a6 = a0 + 6, a7 = a0 + 7;
+    const double m = 0.999999, c = 1e-9;
+    for (int i = 0; i < iters; ++i) {
+        a0 = a0 * m + c; a1 = a1 * m + c; a2 = a2 * m + c; a3 = a3 * m + c;
+        a4 = a4 * m + c; a5 = a5 * m + c; a6 = a6 * m + c; a7 = a7 * m + c;
+    }
+    const double s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    if (s == 123.456)
+        out[0] = s;
+}
+
+__global__ __launch_bounds__(256) void probe_write_kernel(double2_t *dst, size_t n2)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    const double2_t v = {1.0, 2.0};
+    for (; i < n2; i += stride)
+        dst[i] = v;
+}
+
+__global__ __launch_bounds__(256) void probe_copy_kernel(double2_t *dst, const double2_t *src,
+                                                         size_t n2)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n2; i += stride)
+        dst[i] = src[i];
+}
+
+// D = A B with A[i][k] = i (row tag), B[k][j] = [k==0] * 1 ... we want each D
+// element to carry row*16+col: use A[i][k] = (k==0) ? i*16 : (k==1 ? 1 : 0),
+// B[k][j] = (k==0) ? 1 : (k==1 ? j : 0)  ->  D[i][j] = 16 i + j.
+__global__ void probe_layout_kernel(double *out)
+{
+    const int l = threadIdx.x;
+    const int i = l & 15, k = l >> 4;
+    const double a = (k == 0) ? 16.0 * i : (k == 1 ? 1.0 : 0.0);
+    const double bb = (k == 0) ? 1.0 : (k == 1 ? (double)(l & 15) : 0.0);
+    double4_t c = {0, 0, 0, 0};
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c, 0, 0, 0);
+    for (int r = 0; r < 4; ++r)
+        out[l * 4 + r] = c[r];
+}

@@ -1,0 +1,425 @@
+"""Engine: one device context of libbqhip.so behind numpy-in / numpy-out calls.
+
+This is the whole seam between the Python host code (``gp.py``, ``linalg.py``,
+``bq.py``) and the HIP kernels.  Status codes are mapped to the exceptions the
+reference raises at the same places (linalg_c.pyx:49-53,88-91): not positive
+definite -> numpy.linalg.LinAlgError, bad argument -> ValueError, HIP failure ->
+RuntimeError.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+_dp = L._dp
+
+
+def _pts(x):
+    """Points as d x n, column-major (gauss_c.pyx:116-117)."""
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim == 1:
+        x = x[None, :]
+    if x.ndim != 2:
+        raise ValueError("points must be a vector or a d x n matrix")
+    return np.asfortranarray(x)
+
+
+def _wvec(w, d):
+    w = np.atleast_1d(np.asarray(w, dtype=np.float64)).ravel().copy()
+    if w.shape[0] != d:
+        raise ValueError("w has invalid shape")
+    return w
+
+
+class Engine(object):
+    """A device context.  Not thread-safe; use one per thread / per GPU."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = L.load_library()
+        self._ctx = C.c_void_p()
+        n = C.c_int(0)
+        self._lib.bq_device_count(C.byref(n))
+        if n.value <= 0:
+            raise RuntimeError("no HIP device visible: the MI355X engine cannot run "
+                               "(there is no CPU fallback)")
+        if device >= n.value:
+            raise ValueError("device %d out of range (%d visible)" % (device, n.value))
+        if stream is None:
+            st = self._lib.bq_ctx_create(int(device), C.byref(self._ctx))
+        else:
+            st = self._lib.bq_ctx_create_on_stream(int(device), C.c_void_p(stream),
+                                                   C.byref(self._ctx))
+        if st != L.BQ_OK:
+            raise RuntimeError("bq_ctx_create failed with status %d" % st)
+        self.device = int(device)
+
+    # -- plumbing ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.bq_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st == L.BQ_OK:
+            return
+        msg = self._lib.bq_last_error(self._ctx)
+        msg = msg.decode() if msg else "status %d" % st
+        if st == L.BQ_ERR_NOT_PD:
+            raise np.linalg.LinAlgError(msg)
+        if st == L.BQ_ERR_BAD_ARG:
+            raise ValueError(msg)
+        if st == L.BQ_ERR_NOMEM:
+            raise MemoryError(msg)
+        raise RuntimeError(msg)
+
+    def sync(self):
+        self._check(self._lib.bq_ctx_sync(self._ctx))
+
+    def info(self):
+        name = C.create_string_buffer(64)
+        cus, clk, mem = C.c_int(), C.c_int(), C.c_size_t()
+        self._check(self._lib.bq_device_info(self._ctx, name, C.byref(cus), C.byref(mem),
+                                             C.byref(clk)))
+        return {"name": name.value.decode(), "cus": cus.value, "hbm_bytes": mem.value,
+                "clock_khz": clk.value}
+
+    def set_block(self, nb):
+        self._check(self._lib.bq_set_block(self._ctx, int(nb)))
+
+    # -- raw device memory -------------------------------------------------
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self._check(self._lib.bq_dev_alloc(self._ctx, int(nbytes), C.byref(p)))
+        return p
+
+    def free(self, p):
+        self._check(self._lib.bq_dev_free(self._ctx, p))
+
+    def upload(self, dptr, arr):
+        arr = np.ascontiguousarray(arr) if not arr.flags.f_contiguous else arr
+        self._check(self._lib.bq_upload(self._ctx, dptr, arr.ctypes.data_as(C.c_void_p),
+                                        arr.nbytes))
+
+    def download(self, arr, dptr):
+        self._check(self._lib.bq_download(self._ctx, arr.ctypes.data_as(C.c_void_p), dptr,
+                                          arr.nbytes))
+
+    def timer_start(self):
+        self._check(self._lib.bq_timer_start(self._ctx))
+
+    def timer_stop_ms(self):
+        ms = C.c_float()
+        self._check(self._lib.bq_timer_stop_ms(self._ctx, C.byref(ms)))
+        return float(ms.value)
+
+    def profile(self, on):
+        self._check(self._lib.bq_profile_enable(self._ctx, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self._lib.bq_profile_reset(self._ctx))
+
+    def profile_read(self):
+        ms = np.zeros(len(L.K_CLASSES))
+        cnt = np.zeros(len(L.K_CLASSES), dtype=np.int64)
+        self._check(self._lib.bq_profile_read(self._ctx, L.dptr(ms),
+                                              cnt.ctypes.data_as(L._i64p)))
+        return {k: {"ms": float(ms[i]), "launches": int(cnt[i])}
+                for i, k in enumerate(L.K_CLASSES)}
+
+    # -- linalg_c drop-ins (host arrays) ------------------------------------
+    def cho_factor(self, Cm, Lm):
+        """linalg_c.pyx:55-93 semantics; Cm, Lm are F-contiguous n x n."""
+        n = Cm.shape[0]
+        info = C.c_int64(0)
+        self._check(self._lib.bq_cho_factor(self._ctx, L.dptr(Cm), L.dptr(Lm), n,
+                                            C.byref(info)))
+
+    def cho_solve(self, Lm, B, X, nrhs):
+        self._check(self._lib.bq_cho_solve(self._ctx, L.dptr(Lm), L.dptr(B), L.dptr(X),
+                                           Lm.shape[0], int(nrhs)))
+
+    def logdet(self, Lm):
+        out = C.c_double()
+        self._check(self._lib.bq_logdet(self._ctx, L.dptr(Lm), Lm.shape[0],
+                                        C.cast(C.byref(out), _dp)))
+        return float(out.value)
+
+    # -- Gram -----------------------------------------------------------------
+    def gram(self, x, h, w, s=0.0):
+        x = _pts(x)
+        d, n = x.shape
+        w = _wvec(w, d)
+        K = np.empty((n, n), order="F")
+        self._check(self._lib.bq_gram_gauss(self._ctx, L.dptr(x), d, n, float(h), L.dptr(w),
+                                            float(s), L.dptr(K)))
+        return K
+
+    def gram_cross(self, x1, x2, h, w):
+        x1, x2 = _pts(x1), _pts(x2)
+        d = x1.shape[0]
+        if x2.shape[0] != d:
+            raise ValueError("dimension mismatch")
+        w = _wvec(w, d)
+        K = np.empty((x1.shape[1], x2.shape[1]), order="F")
+        self._check(self._lib.bq_gram_gauss_cross(self._ctx, L.dptr(x1), x1.shape[1], L.dptr(x2),
+                                                  x2.shape[1], d, float(h), L.dptr(w), L.dptr(K)))
+        return K
+
+    # -- GP fits --------------------------------------------------------------
+    def gp_fit(self, x, y, h, w, s=0.0):
+        return Fit(self, x, y, h, w, s)
+
+    def fit_predict(self, x, y, h, w, s, xo):
+        """One bordered-Cholesky pass: (mean, var, logml)."""
+        x, xo = _pts(x), _pts(xo)
+        d, n = x.shape
+        M = xo.shape[1]
+        if xo.shape[0] != d:
+            raise ValueError("dimension mismatch")
+        w = _wvec(w, d)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if y.shape != (n,):
+            raise ValueError("y has invalid shape")
+        mean, var = np.empty(M), np.empty(M)
+        logml = C.c_double()
+        self._check(self._lib.bq_fit_predict(self._ctx, L.dptr(x), L.dptr(y), d, n, float(h),
+                                             L.dptr(w), float(s), L.dptr(xo), M, L.dptr(mean),
+                                             L.dptr(var), C.cast(C.byref(logml), _dp)))
+        return mean, var, float(logml.value)
+
+    def logml_grid(self, x, y, h, w, s=0.0, chunk=0):
+        """log-ML at G hyper-parameter points: h (G,), w (G,) or (G, d)."""
+        x = _pts(x)
+        d, n = x.shape
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        h = np.ascontiguousarray(h, dtype=np.float64).ravel()
+        G = h.shape[0]
+        w = np.ascontiguousarray(np.asarray(w, dtype=np.float64).reshape(G, -1))
+        if w.shape[1] == 1 and d > 1:
+            w = np.ascontiguousarray(np.repeat(w, d, axis=1))
+        if w.shape != (G, d):
+            raise ValueError("w has invalid shape")
+        out = np.empty(G)
+        self._check(self._lib.bq_gp_logml_grid(self._ctx, L.dptr(x), L.dptr(y), d, n, L.dptr(h),
+                                               L.dptr(w), float(s), G, L.dptr(out), int(chunk)))
+        return out
+
+    def batch_fit_predict(self, x, y, h, w, s, xo):
+        """nprob independent problems.  x: (P, n) or (P, d, n); y: (P, n);
+        xo: (P, M) or (P, d, M).  Returns mean (P, M), var (P, M), logml (P,),
+        status (P,)."""
+        x = np.asarray(x, dtype=np.float64)
+        xo = np.asarray(xo, dtype=np.float64)
+        if x.ndim == 2:
+            x = x[:, None, :]
+        if xo.ndim == 2:
+            xo = xo[:, None, :]
+        P, d, n = x.shape
+        M = xo.shape[2]
+        # each problem's points are d x n column-major = (n, d) C-order
+        xb = np.ascontiguousarray(np.transpose(x, (0, 2, 1)))
+        xob = np.ascontiguousarray(np.transpose(xo, (0, 2, 1)))
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if y.shape != (P, n) or xo.shape[0] != P or xo.shape[1] != d:
+            raise ValueError("shape mismatch")
+        w = _wvec(w, d)
+        mean, var = np.empty((P, M)), np.empty((P, M))
+        logml = np.empty(P)
+        status = np.zeros(P, dtype=np.int32)
+        self._check(self._lib.bq_batch_fit_predict(
+            self._ctx, P, L.dptr(xb), L.dptr(y), d, n, float(h), L.dptr(w), float(s),
+            L.dptr(xob), M, L.dptr(mean), L.dptr(var), L.dptr(logml),
+            status.ctypes.data_as(L._i32p)))
+        return mean, var, logml, status
+
+    def plan(self, nprob, d, n, M):
+        return Plan(self, nprob, d, n, M)
+
+    # -- probes ----------------------------------------------------------------
+    def probe_mfma_f64(self):
+        v = C.c_double()
+        self._check(self._lib.bq_probe_mfma_f64(self._ctx, C.cast(C.byref(v), _dp)))
+        return float(v.value)
+
+    def probe_fma_f64(self):
+        v = C.c_double()
+        self._check(self._lib.bq_probe_fma_f64(self._ctx, C.cast(C.byref(v), _dp)))
+        return float(v.value)
+
+    def probe_hbm(self, nbytes=1 << 30):
+        a, b = C.c_double(), C.c_double()
+        self._check(self._lib.bq_probe_hbm(self._ctx, int(nbytes), C.cast(C.byref(a), _dp),
+                                           C.cast(C.byref(b), _dp)))
+        return float(a.value), float(b.value)
+
+    def probe_mfma_layout(self):
+        out = np.empty(256)
+        self._check(self._lib.bq_probe_mfma_layout(self._ctx, L.dptr(out)))
+        return out.reshape(64, 4)
+
+
+class Fit(object):
+    """Device-resident GP fit (bq_fit): L, z = L^-1 y, log-ML; alpha on demand."""
+
+    def __init__(self, eng, x, y, h, w, s):
+        self._eng = eng
+        self._h = C.c_void_p()
+        x = _pts(x)
+        self.d, self.n = x.shape
+        w = _wvec(w, self.d)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if y.shape != (self.n,):
+            raise ValueError("y has invalid shape")
+        eng._check(eng._lib.bq_gp_fit(eng._ctx, L.dptr(x), L.dptr(y), self.d, self.n, float(h),
+                                      L.dptr(w), float(s), C.byref(self._h)))
+
+    def close(self):
+        if self._h is not None and self._h.value and self._eng._ctx.value:
+            self._eng._lib.bq_fit_destroy(self._eng._ctx, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def refit(self, h, w, s):
+        w = _wvec(w, self.d)
+        e = self._eng
+        e._check(e._lib.bq_gp_refit(e._ctx, self._h, float(h), L.dptr(w), float(s)))
+
+    @property
+    def logml(self):
+        v = C.c_double()
+        e = self._eng
+        e._check(e._lib.bq_gp_logml(e._ctx, self._h, C.cast(C.byref(v), _dp)))
+        return float(v.value)
+
+    def _get(self, which, shape):
+        out = np.empty(shape, order="F")
+        e = self._eng
+        e._check(e._lib.bq_gp_get(e._ctx, self._h, which, L.dptr(out)))
+        return out
+
+    def L(self):
+        return self._get(0, (self.n, self.n))
+
+    def alpha(self):
+        return self._get(1, (self.n,))
+
+    def z(self):
+        return self._get(2, (self.n,))
+
+    def K(self):
+        return self._get(3, (self.n, self.n))
+
+    def predict(self, xo, want_mean=True, want_var=True, want_cov=False):
+        xo = _pts(xo)
+        if xo.shape[0] != self.d:
+            raise ValueError("dimension mismatch")
+        M = xo.shape[1]
+        mean = np.empty(M) if want_mean else None
+        var = np.empty(M) if want_var else None
+        cov = np.empty((M, M), order="F") if want_cov else None
+        e = self._eng
+        e._check(e._lib.bq_gp_predict(e._ctx, self._h, L.dptr(xo), M, L.dptr(mean), L.dptr(var),
+                                      L.dptr(cov)))
+        return mean, var, cov
+
+
+class Plan(object):
+    """Resident batched fit+posterior pipeline (bq_plan); what bench.py times."""
+
+    def __init__(self, eng, nprob, d, n, M):
+        self._eng = eng
+        self._h = C.c_void_p()
+        self.nprob, self.d, self.n, self.M = int(nprob), int(d), int(n), int(M)
+        eng._check(eng._lib.bq_plan_create(eng._ctx, self.nprob, self.d, self.n, self.M,
+                                           C.byref(self._h)))
+
+    def close(self):
+        if self._h is not None and self._h.value and self._eng._ctx.value:
+            self._eng._lib.bq_plan_destroy(self._eng._ctx, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def nbytes(self):
+        v = C.c_size_t()
+        self._eng._check(self._eng._lib.bq_plan_bytes(self._h, C.byref(v)))
+        return int(v.value)
+
+    def set_inputs(self, x, y, xo, h, w, s):
+        """x: (P, d, n) or (P, n); y: (P, n); xo: (P, d, M) or (P, M);
+        h, s: (P,) or scalars; w: (P, d), (P,) or (d,)."""
+        P, d, n, M = self.nprob, self.d, self.n, self.M
+        x = np.asarray(x, dtype=np.float64).reshape(P, d, n)
+        xb = np.ascontiguousarray(np.transpose(x, (0, 2, 1)))
+        y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(P, n))
+        if M:
+            xo = np.asarray(xo, dtype=np.float64).reshape(P, d, M)
+            xob = np.ascontiguousarray(np.transpose(xo, (0, 2, 1)))
+        else:
+            xob = None
+        h = np.ascontiguousarray(np.broadcast_to(np.asarray(h, dtype=np.float64), (P,)))
+        s = np.ascontiguousarray(np.broadcast_to(np.asarray(s, dtype=np.float64), (P,)))
+        w = np.asarray(w, dtype=np.float64)
+        if w.ndim <= 1 and w.size == d:
+            w = np.broadcast_to(w.reshape(1, d), (P, d))
+        elif w.size == P and d == 1:
+            w = w.reshape(P, 1)
+        elif w.size == P and d > 1:
+            w = np.repeat(w.reshape(P, 1), d, axis=1)
+        w = np.ascontiguousarray(w.reshape(P, d))
+        e = self._eng
+        e._check(e._lib.bq_plan_set_inputs(e._ctx, self._h, L.dptr(xb), L.dptr(y), L.dptr(xob),
+                                           L.dptr(h), L.dptr(w), L.dptr(s)))
+
+    def run(self):
+        e = self._eng
+        e._check(e._lib.bq_plan_run(e._ctx, self._h))
+
+    def results(self):
+        P, M = self.nprob, self.M
+        mean, var = np.empty((P, M)), np.empty((P, M))
+        logml = np.empty(P)
+        status = np.zeros(P, dtype=np.int32)
+        e = self._eng
+        e._check(e._lib.bq_plan_results(e._ctx, self._h, L.dptr(mean) if M else None,
+                                        L.dptr(var) if M else None, L.dptr(logml),
+                                        status.ctypes.data_as(L._i32p)))
+        return mean, var, logml, status
+
+
+_engines = {}
+
+
+def get_engine(device=None):
+    """Process-wide engine for a device (default: LOCAL_RANK or 0)."""
+    import os
+    if device is None:
+        device = int(os.environ.get("BQ_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        n = C.c_int(0)
+        L.load_library().bq_device_count(C.byref(n))
+        if n.value > 0:
+            device %= n.value
+    if device not in _engines:
+        _engines[device] = Engine(device)
+    return _engines[device]
+
+
+def set_engine(eng, device=0):
+    """Install an engine object (tests install a CPU test double here)."""
+    _engines[device] = eng

@@ -1,0 +1,387 @@
+#!/usr/bin/env python3
+"""bench.py -- BQ fit+posterior throughput on MI355X, with roofline and CPU baseline.
+
+Contract (one JSON line on stdout from rank 0):
+    python bench.py --gpus N --steps K --warmup W
+A "step" is one pass of the hot path over one batch of synthetic problems that
+are already resident in HBM: assemble the bordered Gaussian-kernel system,
+blocked fp64 Cholesky (MFMA trailing update), posterior mean/variance at the
+candidate points and the log marginal likelihood.  The default workload is
+BASELINE.json configs[1] (C2: d=1, N=1024, M=256); per-GPU work is fixed as N
+grows (weak scaling, no collective on the data path -- ranks only meet at the
+timing barrier).
+
+Extra objects on the same line:
+    roofline      the dominant kernel class of the timed workload
+    rooflines     the two north-star lines: N=16384 Cholesky trailing update
+                  (fp64 MFMA) and N=4096 / N=16384 Gram build (HBM)
+    cpu_baseline  the CPU oracle (a port, OpenMP) on a bounded sample of the
+                  same workload, rank 0, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# peaks: HBM from /opt/skills/guides/MI355X_MICROARCH.md (8.0 TB/s spec); the guide
+# has no fp64 row, so the fp64 matrix peak is AMD's public MI355X figure (78.6
+# TFLOP/s, equal to the fp64 vector peak) and the on-box probe is reported beside it.
+PEAK_HBM_GBS = 8000.0
+PEAK_FP64_TFLOPS = 78.6
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c5"])
+    ap.add_argument("--batch", type=int, default=0, help="problems per GPU per step (0 = default)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the C3/C4 roofline runs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nb", type=int, default=0, help="outer Cholesky block override")
+    return ap.parse_args()
+
+
+class Dist(object):
+    """Barrier + max over ranks.  torch.distributed (gloo, CPU tensors) when
+    launched by torch.distributed.run with WORLD_SIZE > 1; trivial otherwise.
+    The GPU work itself never goes through torch."""
+
+    def __init__(self, gpus):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.td = None
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            import torch
+            import torch.distributed as td
+            td.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
+            self.td, self.torch = td, torch
+        if gpus != self.world and self.rank == 0 and self.world > 1:
+            print("warning: --gpus %d but WORLD_SIZE %d" % (gpus, self.world), file=sys.stderr)
+
+    def barrier(self):
+        if self.td is not None:
+            self.td.barrier()
+
+    def max(self, v):
+        if self.td is None:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64)
+        self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
+        return float(t[0])
+
+    def sum(self, v):
+        if self.td is None:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64)
+        self.td.all_reduce(t, op=self.td.ReduceOp.SUM)
+        return float(t[0])
+
+    def close(self):
+        if self.td is not None:
+            self.td.destroy_process_group()
+
+
+def make_workload(name, batch, rank):
+    from bayesian_quadrature_amd import workloads as wl
+    if name == "c2":
+        c = wl.c2()
+        B = batch or 1
+        x = np.repeat(c["x"][None], B, axis=0)
+        y = np.repeat(c["y"][None], B, axis=0)
+        xo = np.repeat(c["xo"][None], B, axis=0)
+        desc = "C2: d=1 N=1024 M=256 Gaussian integrand, w=dx, s=1e-3"
+        return dict(x=x, y=y, xo=xo, h=c["h"], w=c["w"], s=c["s"], d=1, n=1024, M=256, B=B,
+                    desc=desc)
+    B = batch or 64
+    probs = [rank * B + i for i in range(B)]  # each rank owns its own block of problems
+    c = wl.c5(probs)
+    desc = "C5 shard: %d x (d=1 N=2048 M=256), w=dx, s=1e-2" % B
+    return dict(x=c["x"], y=c["y"], xo=c["xo"], h=c["h"], w=c["w"], s=c["s"], d=1, n=2048, M=256,
+                B=B, desc=desc)
+
+
+def class_work(n, M, nb_outer):
+    """Algorithmic flops (bytes for gram) per step of each kernel class for the
+    bordered system of one problem (DESIGN.md section 'per-unit figures')."""
+    npad = -(-n // 64) * 64
+    ntot = -(-(npad + M + 1) // 64) * 64
+    w = {"gram": 8.0 * ntot * (ntot + 1) / 2, "potf2": 0.0, "trsm": 0.0, "gemm_panel": 0.0,
+         "syrk_trailing": 0.0, "reduce": 8.0 * (n + 2 * M)}
+    K0 = 0
+    while K0 < npad:
+        KB = min(nb_outer, npad - K0)
+        j0 = K0
+        while j0 < K0 + KB:
+            if j0 > K0:
+                w["gemm_panel"] += 2.0 * (ntot - j0) * 64 * (j0 - K0)
+            w["potf2"] += 64.0 ** 3 / 3
+            w["trsm"] += (ntot - j0 - 64) * 64.0 * 64
+            j0 += 64
+        m = ntot - K0 - KB
+        w["syrk_trailing"] += float(m) * m * KB
+        K0 += KB
+    return w, ntot
+
+
+def auto_nb(ntot, override):
+    if override:
+        return override
+    return 256 if ntot >= 8192 else (128 if ntot >= 3072 else 64)
+
+
+def run_main(eng, wk, steps, warmup, dist):
+    plan = eng.plan(wk["B"], wk["d"], wk["n"], wk["M"])
+    plan.set_inputs(wk["x"], wk["y"], wk["xo"], wk["h"], wk["w"], wk["s"])
+    for _ in range(warmup):
+        plan.run()
+    eng.sync()
+    dist.barrier()
+    eng.timer_start()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.run()
+    eng.sync()
+    t1 = time.perf_counter()
+    ev_ms = eng.timer_stop_ms()
+    dist.barrier()
+    wall = dist.max(t1 - t0)
+    mean, var, logml, status = plan.results()
+    # the same K steps with the result read-back (sync + D2H) inside every step
+    t2 = time.perf_counter()
+    for _ in range(max(1, steps // 4)):
+        plan.run()
+        plan.results()
+    t3 = time.perf_counter()
+    rb_ms = (t3 - t2) / max(1, steps // 4) * 1e3
+    # instrumented pass: HIP events around every launch, per kernel class
+    eng.profile(True)
+    eng.profile_reset()
+    ninstr = 3
+    for _ in range(ninstr):
+        plan.run()
+    prof = eng.profile_read()
+    eng.profile(False)
+    for k in prof:
+        prof[k]["ms"] /= ninstr
+        prof[k]["launches"] //= ninstr
+    nbytes = plan.nbytes()
+    plan.close()
+    return dict(wall=wall, ev_ms=ev_ms, rb_ms=rb_ms, prof=prof, mean=mean, var=var, logml=logml,
+                status=status, plan_bytes=nbytes)
+
+
+def parity_spotcheck(wk, res):
+    """The bench is not the parity gate (tests/ is) but it refuses to print a
+    number for wrong results: problem 0 against the CPU oracle."""
+    from oracle import load
+    o = load()
+    o.set_threads(o.max_threads())
+    x, y, xo = wk["x"][0], wk["y"][0], wk["xo"][0]
+    L, a, lm = o.gp_fit(x, y, wk["h"], wk["w"], wk["s"])
+    m, v = o.gp_predict(x, wk["h"], wk["w"], L, a, xo)
+    k0 = o.kernel_scale(1, wk["h"], wk["w"])
+    return {"mean_rel": float(np.max(np.abs(res["mean"][0] - m)) / np.max(np.abs(m))),
+            "var_rel_prior": float(np.max(np.abs(res["var"][0] - v)) / k0),
+            "logml_rel": float(abs(res["logml"][0] - lm) / abs(lm)),
+            "tolerance": 1e-10}
+
+
+def cpu_baseline(wk, budget_s=12.0):
+    from oracle import load
+    o = load()
+    cores = o.max_threads()
+    o.set_threads(cores)
+    x, y, xo = wk["x"][0], wk["y"][0], wk["xo"][0]
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        L, a, lm = o.gp_fit(x, y, wk["h"], wk["w"], wk["s"])
+        o.gp_predict(x, wk["h"], wk["w"], L, a, xo)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or reps >= 200:
+            break
+    return {"value": reps / el, "unit": "problems/s", "cores": cores, "kind": "port",
+            "ms_per_problem": el / reps * 1e3,
+            "sample": "%d x (gram + blocked potrf + potrs + predict mean/var + logML) of the "
+                      "N=%d, M=%d problem, oracle/bq_oracle.c with OpenMP on %d threads, %.1f s"
+                      % (reps, wk["n"], wk["M"], cores, el)}
+
+
+def extras(eng, nb_override):
+    """C4 (N=16384 Cholesky, MFMA roofline) and C3 (N=4096 d=2 Gram, HBM roofline)."""
+    from bayesian_quadrature_amd import workloads as wl
+    from bayesian_quadrature_amd import _lib as L_
+    out = {}
+    lib, ctx = eng._lib, eng._ctx
+    # ---- Gram, N=4096 d=2 and N=16384 d=1 --------------------------------------
+    for tag, n, d in (("gram_n4096_d2", 4096, 2), ("gram_n16384_d1", 16384, 1)):
+        if d == 2:
+            c = wl.c3()
+            pts, h, w, s = np.asfortranarray(c["x"]), float(c["h"][200]), c["w"][200], c["s"]
+        else:
+            c = wl.c4(n)
+            pts, h, w, s = np.asfortranarray(c["x"][None, :]), c["h"], c["w"], c["s"]
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        xd = eng.alloc(8 * d * n)
+        Kd = eng.alloc(8 * n * n)
+        eng.upload(xd, pts)
+        reps = 20 if n <= 4096 else 6
+        for _ in range(3):
+            eng._check(lib.bq_gram_gauss_dev(ctx, xd, d, n, h, L_.dptr(w), s, Kd, n))
+        eng.sync()
+        eng.timer_start()
+        for _ in range(reps):
+            eng._check(lib.bq_gram_gauss_dev(ctx, xd, d, n, h, L_.dptr(w), s, Kd, n))
+        ms = eng.timer_stop_ms() / reps
+        alg = 8.0 * n * n + 8.0 * d * n
+        out[tag] = {"kernel": "gram_sym_kernel", "bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9,
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                    "traffic": None, "ms_per_launch": ms, "algorithmic_bytes": alg,
+                    "note": "includes a 80-byte parameter upload per launch"}
+        if n == 16384:
+            # ---- C4: potrf on the matrix just built ------------------------------
+            info = eng.alloc(64)
+            nb = auto_nb(n, nb_override)
+            times = []
+            for rep in range(3):
+                eng._check(lib.bq_gram_gauss_dev(ctx, xd, d, n, h, L_.dptr(w), s, Kd, n))
+                eng.sync()
+                eng.timer_start()
+                eng._check(lib.bq_potrf_dev(ctx, Kd, n, n, info))
+                times.append(eng.timer_stop_ms())
+            hinfo = np.zeros(1, dtype=np.int32)
+            eng.download(hinfo, info)
+            # instrumented pass for the trailing-update share
+            eng._check(lib.bq_gram_gauss_dev(ctx, xd, d, n, h, L_.dptr(w), s, Kd, n))
+            eng.profile(True)
+            eng.profile_reset()
+            eng._check(lib.bq_potrf_dev(ctx, Kd, n, n, info))
+            prof = eng.profile_read()
+            eng.profile(False)
+            best = min(times[1:])
+            tfl = wl.trailing_flops(n, nb)
+            sy = prof["syrk_trailing"]
+            out["potrf_n16384"] = {
+                "ms": best, "gflops": wl.potrf_flops(n) / (best * 1e-3) / 1e9, "nb": nb,
+                "info": int(hinfo[0]), "all_ms": times, "class_ms": {k: v["ms"] for k, v in prof.items()},
+                "class_launches": {k: v["launches"] for k, v in prof.items()}}
+            out["trailing_update_n16384"] = {
+                "kernel": "gemm_sub_kernel<4,4> (trailing SYRK)", "bound": "mfma",
+                "achieved": tfl / (sy["ms"] * 1e-3) / 1e12, "peak": PEAK_FP64_TFLOPS,
+                "unit": "TFLOP/s", "frac": tfl / (sy["ms"] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
+                "traffic": None, "algorithmic_flops": tfl, "launches": sy["launches"],
+                "ms_total": sy["ms"], "ms_per_launch": sy["ms"] / max(1, sy["launches"])}
+            eng.free(info)
+        eng.free(xd)
+        eng.free(Kd)
+    return out
+
+
+def main():
+    a = parse()
+    dist = Dist(a.gpus)
+    # the engine must exist before torch could initialise a second HIP runtime
+    from bayesian_quadrature_amd import Engine
+    import ctypes as C
+    from bayesian_quadrature_amd import _lib as L_
+    ndev = C.c_int(0)
+    L_.load_library().bq_device_count(C.byref(ndev))
+    if ndev.value <= 0:
+        print("bench.py needs a HIP device (no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    eng = Engine(dist.local_rank % ndev.value)
+    if a.nb:
+        eng.set_block(a.nb)
+    wk = make_workload(a.workload, a.batch, dist.rank)
+    res = run_main(eng, wk, a.steps, a.warmup, dist)
+    nfail = dist.sum(float((res["status"] != 0).sum()))
+    units = a.steps * wk["B"] * dist.world  # problems processed by the whole job
+    value = units / res["wall"]
+    line = None
+    if dist.rank == 0:
+        info = eng.info()
+        work, ntot = class_work(wk["n"], wk["M"], auto_nb(
+            -(-(-(-wk["n"] // 64) * 64 + wk["M"] + 1) // 64) * 64, a.nb))
+        prof = res["prof"]
+        dom = max(prof, key=lambda k: prof[k]["ms"])
+        dom_ms = prof[dom]["ms"]
+        per_launch_ms = dom_ms / max(1, prof[dom]["launches"])
+        if dom in ("gram", "reduce"):
+            ach = work[dom] * wk["B"] / (dom_ms * 1e-3) / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None}
+        else:
+            ach = work[dom] * wk["B"] / (dom_ms * 1e-3) / 1e12
+            roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / PEAK_FP64_TFLOPS, "traffic": None}
+        roof.update({"launches_per_step": prof[dom]["launches"], "ms_per_launch": per_launch_ms,
+                     "ms_per_step_in_class": dom_ms,
+                     "algorithmic_work_per_step": work[dom] * wk["B"],
+                     "class_ms_per_step": {k: v["ms"] for k, v in prof.items()},
+                     "class_launches_per_step": {k: v["launches"] for k, v in prof.items()},
+                     "note": "dominant kernel class of the timed workload, HIP events on the "
+                             "engine stream in an instrumented pass; potf2/trsm are fp64 VALU "
+                             "kernels (fp64 vector peak == fp64 MFMA peak on MI355X)"})
+        line = {
+            "metric": "bq_fit_posterior_throughput",
+            "value": value,
+            "unit": "problems/s",
+            "n_gpus": dist.world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": res["wall"] / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": wk["desc"], "problems_per_gpu_per_step": wk["B"],
+                       "bordered_system": ntot, "sharding": "independent problems per rank, "
+                       "no data-path collective"},
+            "ms_per_problem": res["wall"] / a.steps / wk["B"] * 1e3,
+            "ms_per_step_hip_events": res["ev_ms"] / a.steps,
+            "ms_per_step_with_readback": res["rb_ms"],
+            "failed_problems": int(nfail),
+            "device": info,
+            "plan_bytes": res["plan_bytes"],
+            "roofline": roof,
+        }
+        line["parity"] = parity_spotcheck(wk, res)
+        if dist.world == 1:
+            try:
+                line["probes"] = {"mfma_f64_tflops": eng.probe_mfma_f64(),
+                                  "fma_f64_tflops": eng.probe_fma_f64()}
+                wgb, cgb = eng.probe_hbm(1 << 30)
+                line["probes"].update({"hbm_write_gbs": wgb, "hbm_copy_gbs": cgb})
+            except Exception as e:  # probes are informational
+                line["probes"] = {"error": str(e)}
+            if not a.no_extras:
+                line["rooflines"] = extras(eng, a.nb)
+            if not a.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(wk)
+                line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        p = line["parity"]
+        if not (p["mean_rel"] < 1e-10 and p["var_rel_prior"] < 1e-10 and p["logml_rel"] < 1e-10) \
+                or nfail:
+            line["value"] = None
+            line["invalid"] = "parity check failed"
+    dist.barrier()
+    if dist.rank == 0:
+        print(json.dumps(line))
+    eng.close()
+    dist.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,195 @@
+/*
+ * bqhip.h -- C ABI of libbqhip.so, the MI355X (gfx950) Bayesian-quadrature
+ * GP engine.  This is the drop-in boundary: plain pointers and sizes, no
+ * torch / numpy types.  The Python host package binds it with ctypes
+ * (bayesian-quadrature_amd/_lib.py); INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Reference interfaces replaced (jhamrick/bayesian-quadrature v0.2.0):
+ *   bq_cho_factor      <- linalg_c.pyx:55-93   cho_factor(C, L)
+ *   bq_cho_solve       <- linalg_c.pyx:96-179  cho_solve_vec / cho_solve_mat
+ *   bq_logdet          <- linalg_c.pyx:182-210 logdet(L)
+ *   bq_gram_gauss      <- gp.GP.Kxx / gp.GaussianKernel.__call__ (third-party
+ *                         `gp` package, requirements.txt:2; used bq.py:147-162,465)
+ *   bq_gp_fit          <- gp.GP.Lxx, .inv_Kxx_y, .log_lh   (bq.py:282,334-335,546)
+ *   bq_gp_predict      <- gp.GP.mean(xo), diag(gp.GP.cov(xo)) (bq.py:200,227-228,942-943)
+ *   bq_gp_logml_grid   <- the hyper-parameter loop body  (bq.py:536-550)
+ *   bq_batch_fit_predict <- a Python loop over independent BQ problems
+ *
+ * Conventions
+ *   - all floating point data is fp64; matrices are COLUMN-MAJOR (the
+ *     reference's float64_t[::1, :]), points are d x n (gauss_c.pyx:116-117)
+ *   - "host" pointers are caller-owned host memory; "_dev" entry points take
+ *     device pointers obtained from bq_dev_alloc (or any HIP allocation on the
+ *     context's device) and only enqueue work on the context's stream
+ *   - every function returns a status code; bq_last_error() gives the text
+ *   - a context is bound to one device and one stream and is not thread-safe;
+ *     use one context per thread / per GPU
+ */
+#ifndef BQHIP_H
+#define BQHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes; the Python layer maps them like linalg_c.pyx:49-53,88-91 */
+#define BQ_OK 0
+#define BQ_ERR_NOT_PD 1  /* dpotrf info > 0  -> numpy.linalg.LinAlgError */
+#define BQ_ERR_BAD_ARG 2 /* shape / illegal value -> ValueError */
+#define BQ_ERR_HIP 3     /* HIP runtime failure -> RuntimeError */
+#define BQ_ERR_NOMEM 4   /* allocation failure -> MemoryError */
+
+#define BQ_MAX_DIM 8 /* largest input dimension d */
+
+typedef struct bq_ctx bq_ctx;
+typedef struct bq_fit bq_fit;
+
+/* ---- contexts ------------------------------------------------------ */
+int bq_device_count(int *count);
+int bq_ctx_create(int device, bq_ctx **out);
+/* adopt an existing hipStream_t (e.g. a torch stream); not destroyed by us */
+int bq_ctx_create_on_stream(int device, void *hip_stream, bq_ctx **out);
+void bq_ctx_destroy(bq_ctx *ctx);
+int bq_ctx_sync(bq_ctx *ctx);
+const char *bq_last_error(const bq_ctx *ctx);
+/* name: at least 64 bytes.  cus = compute units, hbm_bytes = total memory */
+int bq_device_info(bq_ctx *ctx, char *name, int *cus, size_t *hbm_bytes, int *clock_khz);
+/* outer Cholesky block (multiple of 64; 0 = automatic from the size) */
+int bq_set_block(bq_ctx *ctx, int nb);
+
+/* ---- device memory -------------------------------------------------- */
+int bq_dev_alloc(bq_ctx *ctx, size_t bytes, void **dptr);
+int bq_dev_free(bq_ctx *ctx, void *dptr);
+int bq_upload(bq_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);   /* synchronous */
+int bq_download(bq_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes); /* synchronous */
+int bq_memset(bq_ctx *ctx, void *dst_dev, int byte, size_t bytes);
+
+/* ---- stream timers (HIP events on the context's stream) ------------- */
+int bq_timer_start(bq_ctx *ctx);
+int bq_timer_stop_ms(bq_ctx *ctx, float *ms); /* records, synchronises, returns elapsed */
+
+/* per-kernel-class device time of everything enqueued since the last reset,
+ * measured with HIP events around each launch (slows the pipeline: use in a
+ * separate, instrumented pass).  Classes: */
+#define BQ_K_GRAM 0     /* gram_gauss / assemble kernels */
+#define BQ_K_POTF2 1    /* 64x64 diagonal factor */
+#define BQ_K_TRSM 2     /* panel solve */
+#define BQ_K_GEMM 3     /* in-panel (left-looking) MFMA update */
+#define BQ_K_SYRK 4     /* trailing MFMA update */
+#define BQ_K_REDUCE 5   /* finalize / reductions / predict */
+#define BQ_K_NCLASS 6
+int bq_profile_enable(bq_ctx *ctx, int on);
+int bq_profile_reset(bq_ctx *ctx);
+/* ms[BQ_K_NCLASS], launches[BQ_K_NCLASS]; synchronises */
+int bq_profile_read(bq_ctx *ctx, double *ms, int64_t *launches);
+
+/* ---- linalg_c drop-ins: host buffers in and out --------------------- */
+/* L <- lower Cholesky factor of C (n x n, ld = n).  C == L allowed (in place).
+ * The strict upper triangle of L is left as it was in C ("upper values could
+ * be anything", linalg_c.pyx:58-59).  BQ_ERR_NOT_PD when dpotrf would fail;
+ * *info (may be NULL) receives the 1-based failing column. */
+int bq_cho_factor(bq_ctx *ctx, const double *C, double *L, int64_t n, int64_t *info);
+/* X <- (L L^T)^-1 B, B and X are n x nrhs, ld = n.  B == X allowed. */
+int bq_cho_solve(bq_ctx *ctx, const double *L, const double *B, double *X, int64_t n,
+                 int64_t nrhs);
+/* *out <- 2 sum_i log L[i,i] */
+int bq_logdet(bq_ctx *ctx, const double *L, int64_t n, double *out);
+
+/* ---- Gaussian-kernel Gram ------------------------------------------- */
+/* K[i,j] = h^2 N(x_i | x_j, diag(w^2)) + s^2 [i==j]; full symmetric n x n
+ * matrix, host in / host out.  x is d x n, w has d entries. */
+int bq_gram_gauss(bq_ctx *ctx, const double *x, int64_t d, int64_t n, double h, const double *w,
+                  double s, double *K_out);
+/* same on device-resident data; only enqueues.  x_dev: d x n, K_dev: n x n
+ * with leading dimension ldk >= n. */
+int bq_gram_gauss_dev(bq_ctx *ctx, const double *x_dev, int64_t d, int64_t n, double h,
+                      const double *w, double s, double *K_dev, int64_t ldk);
+/* cross Gram K[i,j] = k(x1_i, x2_j), n1 x n2, host in / out (gp.GP.Kxxo, .K) */
+int bq_gram_gauss_cross(bq_ctx *ctx, const double *x1, int64_t n1, const double *x2, int64_t n2,
+                        int64_t d, double h, const double *w, double *K_out);
+
+/* ---- device-resident Cholesky (the MFMA roofline path) -------------- */
+/* In-place lower Cholesky of the n x n device matrix (ld = lda).  n must be a
+ * multiple of 64 (callers pad with an identity block).  Only enqueues; the
+ * failing column (0 = success) is written to info_dev[0] (device int32). */
+int bq_potrf_dev(bq_ctx *ctx, double *A_dev, int64_t n, int64_t lda, int32_t *info_dev);
+
+/* ---- GP fit objects (device resident) ------------------------------- */
+/* Fit a GP: Gram, Cholesky, z = L^-1 y, log marginal likelihood.  x is d x n
+ * (host), y has n entries (host).  The factor stays on the device. */
+int bq_gp_fit(bq_ctx *ctx, const double *x, const double *y, int64_t d, int64_t n, double h,
+              const double *w, double s, bq_fit **out);
+/* same data, new hyper-parameters (the hyper-parameter loop, bq.py:933-965) */
+int bq_gp_refit(bq_ctx *ctx, bq_fit *fit, double h, const double *w, double s);
+void bq_fit_destroy(bq_ctx *ctx, bq_fit *fit);
+int bq_gp_logml(bq_ctx *ctx, bq_fit *fit, double *out);
+/* which: 0 = L (n x n, strict upper zeroed), 1 = alpha = Kxx^-1 y (n),
+ * 2 = z = L^-1 y (n), 3 = Kxx (n x n, recomputed) */
+int bq_gp_get(bq_ctx *ctx, bq_fit *fit, int which, double *out_host);
+/* posterior at M points xo (d x M, host): mean[M], var[M] (marginal, prior
+ * scale minus explained part; either may be NULL), cov (M x M full posterior
+ * covariance, may be NULL). */
+int bq_gp_predict(bq_ctx *ctx, bq_fit *fit, const double *xo, int64_t M, double *mean,
+                  double *var, double *cov);
+
+/* One pass "fit + posterior + log-ML" of ONE problem without keeping a fit
+ * object: the bordered-Cholesky pipeline.  Host in / host out. */
+int bq_fit_predict(bq_ctx *ctx, const double *x, const double *y, int64_t d, int64_t n,
+                   double h, const double *w, double s, const double *xo, int64_t M,
+                   double *mean, double *var, double *logml);
+
+/* log marginal likelihood on a grid of G hyper-parameter points sharing the
+ * data (x, y): h[G], w[G*d] (point g uses w[g*d .. g*d+d-1]), one s.
+ * out[G]; a point whose Gram is not positive definite yields -inf
+ * (bq.py:542-548).  chunk = problems factored per batched launch (0 = auto). */
+int bq_gp_logml_grid(bq_ctx *ctx, const double *x, const double *y, int64_t d, int64_t n,
+                     const double *h, const double *w, double s, int64_t G, double *out,
+                     int64_t chunk);
+
+/* nprob independent problems of equal size: x[p] is d x n, y[p] has n entries,
+ * xo[p] is d x M; all concatenated problem after problem.  Hyper-parameters
+ * are shared.  mean/var: nprob x M, logml: nprob, status: nprob (0 ok, >0 the
+ * failing column).  This is the unit that shards across GPUs: each rank calls
+ * it on its own slice with its own context; there is no collective. */
+int bq_batch_fit_predict(bq_ctx *ctx, int64_t nprob, const double *x, const double *y,
+                         int64_t d, int64_t n, double h, const double *w, double s,
+                         const double *xo, int64_t M, double *mean, double *var, double *logml,
+                         int32_t *status);
+
+/* ---- resident batch pipeline (what bench.py times) ------------------ */
+/* A plan owns device copies of the inputs and all workspaces, so that a run
+ * starts with everything resident in HBM and only enqueues kernels. */
+typedef struct bq_plan bq_plan;
+int bq_plan_create(bq_ctx *ctx, int64_t nprob, int64_t d, int64_t n, int64_t M, bq_plan **out);
+void bq_plan_destroy(bq_ctx *ctx, bq_plan *plan);
+/* upload inputs (host) of all nprob problems; hyper-parameters per problem:
+ * h[nprob], w[nprob*d], s[nprob] */
+int bq_plan_set_inputs(bq_ctx *ctx, bq_plan *plan, const double *x, const double *y,
+                       const double *xo, const double *h, const double *w, const double *s);
+/* enqueue one full pass (assemble -> bordered Cholesky -> finalize) */
+int bq_plan_run(bq_ctx *ctx, bq_plan *plan);
+/* synchronise and copy results out (any pointer may be NULL) */
+int bq_plan_results(bq_ctx *ctx, bq_plan *plan, double *mean, double *var, double *logml,
+                    int32_t *status);
+/* bytes of device memory the plan holds */
+int bq_plan_bytes(bq_plan *plan, size_t *bytes);
+
+/* ---- hardware probes (tools/probe.py, bench.py peak denominators) --- */
+/* sustained v_mfma_f64_16x16x4_f64 rate in TFLOP/s over all CUs */
+int bq_probe_mfma_f64(bq_ctx *ctx, double *tflops);
+/* sustained v_fma_f64 rate in TFLOP/s */
+int bq_probe_fma_f64(bq_ctx *ctx, double *tflops);
+/* streaming fp64 write / copy bandwidth in GB/s over `bytes` */
+int bq_probe_hbm(bq_ctx *ctx, size_t bytes, double *write_gbs, double *copy_gbs);
+/* dump of the f64 MFMA D-register layout: out[64*4] receives, for lane l and
+ * register r, the value row*16+col of the D element it holds */
+int bq_probe_mfma_layout(bq_ctx *ctx, double *out256);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BQHIP_H */

@@ -1,0 +1,329 @@
+"""GPU parity: every hot-path entry point of the C ABI against the CPU oracle on
+the same seeded inputs (SURVEY.md section 8d bars), plus size-independent
+properties at the full BASELINE sizes.  All calls go through libbqhip.so."""
+import numpy as np
+import pytest
+
+from conftest import rand_spd
+from bayesian_quadrature_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10  # north_star: posterior mean/variance and log-ML within 1e-10 relative fp64
+
+
+def relmax(a, b, scale=None):
+    a, b = np.asarray(a), np.asarray(b)
+    s = np.max(np.abs(b)) if scale is None else scale
+    return np.max(np.abs(a - b)) / s
+
+
+# ---- hardware facts the kernels rely on ----------------------------------------
+def test_mfma_f64_layout(engine):
+    """D register r of lane l holds D[(l>>4) + 4r][l&15] (kernels.h gemm_sub_kernel)."""
+    lay = engine.probe_mfma_layout()
+    for l in range(64):
+        for r in range(4):
+            row, col = (l >> 4) + 4 * r, l & 15
+            assert lay[l, r] == 16 * row + col, (l, r, lay[l, r])
+
+
+# ---- Gram ------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 9, 63, 64, 129, 1000])
+def test_gram_1d(engine, oracle, n):
+    rs = np.random.RandomState(n)
+    x = np.sort(rs.uniform(-5, 5, n))
+    h, w, s = 1.7, 0.31, 0.05
+    K = engine.gram(x, h, w, s)
+    Ko = oracle.gram(x, h, w, s)
+    assert relmax(K, Ko) < 1e-14
+    assert (K == K.T).all()
+
+
+@pytest.mark.parametrize("d", [2, 3, 8])
+def test_gram_nd(engine, oracle, d):
+    rs = np.random.RandomState(d)
+    pts = rs.uniform(-2, 2, size=(d, 301))
+    w = rs.uniform(0.3, 1.0, d)
+    assert relmax(engine.gram(pts, 0.9, w, 0.1), oracle.gram(pts, 0.9, w, 0.1)) < 1e-14
+
+
+def test_gram_cross(engine, oracle):
+    rs = np.random.RandomState(0)
+    x1, x2 = rs.uniform(-5, 5, 77), rs.uniform(-5, 5, 130)
+    assert relmax(engine.gram_cross(x1, x2, 1.2, 0.4), oracle.gram_cross(x1, x2, 1.2, 0.4)) < 1e-14
+
+
+def test_gram_bad_args(engine):
+    with pytest.raises(ValueError):
+        engine.gram(np.zeros(4), 1.0, -1.0)
+    with pytest.raises(ValueError):
+        engine.gram(np.zeros((9, 4)), 1.0, np.ones(9))
+
+
+# ---- linalg_c drop-ins (reference tests/test_linalg_c.py) --------------------------
+@pytest.mark.parametrize("n", list(range(1, 11)) + [33, 64, 65, 128, 200, 513])
+def test_cho_factor(engine, oracle, n):
+    from bayesian_quadrature_amd import la
+    rs = np.random.RandomState(100 + n)
+    A = rand_spd(rs, n)
+    L = np.empty_like(A, order="F")
+    la.cho_factor(A, L)
+    Lo = oracle.cho_factor(A)
+    assert relmax(np.tril(L), Lo) < 1e-13
+    # upper triangle is C's (linalg_c.pyx:58-59 "could be anything"; here: untouched copy)
+    assert (np.triu(L, 1) == np.triu(A, 1)).all()
+    # in place
+    A2 = A.copy(order="F")
+    la.cho_factor(A2, A2)
+    assert (np.tril(A2) == np.tril(L)).all()
+
+
+def test_cho_factor_errors(engine):
+    from bayesian_quadrature_amd import la
+    A = np.asfortranarray(np.array([[1.0, 2.0], [2.0, 1.0]]))
+    with pytest.raises(np.linalg.LinAlgError):
+        la.cho_factor(A, np.empty_like(A, order="F"))
+    with pytest.raises(ValueError):
+        la.cho_factor(np.asfortranarray(np.ones((2, 3))), np.asfortranarray(np.ones((2, 3))))
+    with pytest.raises(ValueError):
+        la.cho_factor(np.ascontiguousarray(np.eye(3) + 1), np.empty((3, 3), order="F"))
+    big = rand_spd(np.random.RandomState(0), 300)
+    big[250, 250] = -5.0  # fails deep inside the blocked sweep
+    with pytest.raises(np.linalg.LinAlgError):
+        la.cho_factor(big, np.empty_like(big, order="F"))
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 10, 64, 100, 300])
+def test_cho_solve(engine, oracle, n):
+    from bayesian_quadrature_amd import la
+    rs = np.random.RandomState(n)
+    A = rand_spd(rs, n)
+    L = oracle.cho_factor(A)
+    b = rs.rand(n)
+    x = np.empty(n)
+    la.cho_solve_vec(L, b, x)
+    assert relmax(x, oracle.cho_solve(L, b)) < 1e-12
+    la.cho_solve_vec(L, b, b)  # aliased
+    assert (b == x).all()
+    B = np.asfortranarray(rs.rand(n, n))
+    X = np.empty_like(B, order="F")
+    la.cho_solve_mat(L, B, X)
+    assert relmax(X, oracle.cho_solve(L, B)) < 1e-12
+    assert np.allclose(A.dot(X), B)
+
+
+@pytest.mark.parametrize("n", [1, 3, 10, 77, 640])
+def test_logdet(engine, oracle, n):
+    from bayesian_quadrature_amd import la
+    rs = np.random.RandomState(n)
+    L = oracle.cho_factor(rand_spd(rs, n))
+    assert abs(la.logdet(L) - oracle.logdet(L)) <= 1e-13 * max(1.0, abs(oracle.logdet(L)))
+
+
+# ---- GP fit / predict ----------------------------------------------------------------
+def _problem(n, seed, w_scale=1.0):
+    rs = np.random.RandomState(seed)
+    x = np.sort(rs.uniform(-5, 5, n))
+    y = wl.norm_logpdf(x) + 0.01 * rs.randn(n)
+    dx = 10.0 / max(n - 1, 1)
+    return x, y, 1.3, w_scale * dx, 1e-2
+
+
+@pytest.mark.parametrize("n", [1, 9, 32, 64, 100, 257, 1024])
+def test_gp_fit(engine, oracle, n):
+    x, y, h, w, s = _problem(n, n)
+    fit = engine.gp_fit(x, y, h, w, s)
+    Lo, ao, lmo = oracle.gp_fit(x, y, h, w, s)
+    assert relmax(fit.L(), Lo) < 1e-12
+    assert relmax(fit.alpha(), ao) < RTOL
+    assert relmax(fit.z(), oracle.trsm_lower(Lo, y)) < RTOL
+    assert abs(fit.logml - lmo) <= RTOL * abs(lmo)
+    assert relmax(fit.K(), oracle.gram(x, h, w, s)) < 1e-14
+    fit.close()
+
+
+@pytest.mark.parametrize("n,M", [(9, 5), (100, 1), (100, 64), (300, 257), (1024, 256)])
+def test_gp_predict(engine, oracle, n, M):
+    x, y, h, w, s = _problem(n, 7 * n + M)
+    xo = np.linspace(-5.2, 5.2, M) + 0.013
+    fit = engine.gp_fit(x, y, h, w, s)
+    Lo, ao, _ = oracle.gp_fit(x, y, h, w, s)
+    mo, vo = oracle.gp_predict(x, h, w, Lo, ao, xo)
+    k0 = oracle.kernel_scale(1, h, [w])
+    m, v, c = fit.predict(xo, want_cov=True)
+    assert relmax(m, mo) < RTOL
+    assert relmax(v, vo, scale=k0) < RTOL       # variance relative to the prior scale
+    assert relmax(np.diag(c), vo, scale=k0) < RTOL
+    assert np.allclose(c, c.T, rtol=0, atol=1e-12 * k0)
+    m2 = fit.predict(xo, want_var=False)[0]    # fused mean-only path through alpha
+    assert relmax(m2, mo) < RTOL
+    fit.close()
+
+
+def test_gp_refit_and_not_pd(engine, oracle):
+    x, y, h, w, s = _problem(200, 3)
+    fit = engine.gp_fit(x, y, h, w, s)
+    fit.refit(0.7, 2 * w, 0.1)
+    _, _, lmo = oracle.gp_fit(x, y, 0.7, 2 * w, 0.1)
+    assert abs(fit.logml - lmo) <= RTOL * abs(lmo)
+    with pytest.raises(np.linalg.LinAlgError):
+        fit.refit(1.0, 50 * w, 0.0)  # numerically singular Gaussian Gram
+    fit.close()
+
+
+def test_gp_2d(engine, oracle):
+    rs = np.random.RandomState(11)
+    pts = rs.uniform(-3, 3, size=(2, 400))
+    y = wl.norm_logpdf(pts[0]) + wl.norm_logpdf(pts[1])
+    w = np.array([0.35, 0.5])
+    fit = engine.gp_fit(pts, y, 1.0, w, 0.1)
+    Lo, ao, lmo = oracle.gp_fit(pts, y, 1.0, w, 0.1)
+    assert abs(fit.logml - lmo) <= RTOL * abs(lmo)
+    xo = rs.uniform(-3, 3, size=(2, 50))
+    mo, vo = oracle.gp_predict(pts, 1.0, w, Lo, ao, xo)
+    m, v, _ = fit.predict(xo)
+    assert relmax(m, mo) < RTOL
+    assert relmax(v, vo, scale=oracle.kernel_scale(2, 1.0, w)) < RTOL
+    fit.close()
+
+
+# ---- the bordered one-pass pipeline (what bench.py times) ---------------------------
+def test_fit_predict_c2(engine, oracle):
+    c = wl.c2()
+    mean, var, logml = engine.fit_predict(c["x"], c["y"], c["h"], c["w"], c["s"], c["xo"])
+    Lo, ao, lmo = oracle.gp_fit(c["x"], c["y"], c["h"], c["w"], c["s"])
+    mo, vo = oracle.gp_predict(c["x"], c["h"], c["w"], Lo, ao, c["xo"])
+    k0 = oracle.kernel_scale(1, c["h"], c["w"])
+    assert relmax(mean, mo) < RTOL
+    assert relmax(var, vo, scale=k0) < RTOL
+    assert abs(logml - lmo) <= RTOL * abs(lmo)
+
+
+@pytest.mark.parametrize("n,M", [(1, 1), (5, 3), (64, 64), (65, 7), (191, 130)])
+def test_fit_predict_ragged(engine, oracle, n, M):
+    x, y, h, w, s = _problem(n, n + M)
+    xo = np.linspace(-5, 5, M) + 0.01
+    mean, var, logml = engine.fit_predict(x, y, h, w, s, xo)
+    Lo, ao, lmo = oracle.gp_fit(x, y, h, w, s)
+    mo, vo = oracle.gp_predict(x, h, w, Lo, ao, xo)
+    assert relmax(mean, mo, scale=max(1e-300, np.abs(mo).max())) < RTOL
+    assert relmax(var, vo, scale=oracle.kernel_scale(1, h, [w])) < RTOL
+    assert abs(logml - lmo) <= RTOL * abs(lmo)
+
+
+def test_logml_grid(engine, oracle):
+    c = wl.c3(side=16, gh=3, gw=3)
+    out = engine.logml_grid(c["x"], c["y"], c["h"], c["w"], c["s"], chunk=4)
+    for g in range(9):
+        _, _, lmo = oracle.gp_fit(c["x"], c["y"], c["h"][g], c["w"][g], c["s"])
+        assert abs(out[g] - lmo) <= RTOL * abs(lmo)
+    # a hopeless point yields -inf, the others survive (bq.py:542-548)
+    x = np.linspace(-5, 5, 128)
+    y = wl.norm_logpdf(x)
+    h = np.array([1.0, 1.0, 1.0])
+    w = np.array([0.08, 4.0, 0.1])
+    out = engine.logml_grid(x, y, h, w, 0.0)
+    assert np.isfinite(out[0]) and np.isfinite(out[2]) and out[1] == -np.inf
+
+
+def test_batch_fit_predict(engine, oracle):
+    probs = [3, 4, 5, 6, 7]
+    c = wl.c5(probs, n=200, m=33)
+    mean, var, logml, status = engine.batch_fit_predict(c["x"], c["y"], c["h"], c["w"] * 10,
+                                                        c["s"], c["xo"])
+    assert (status == 0).all()
+    for i in range(len(probs)):
+        Lo, ao, lmo = oracle.gp_fit(c["x"][i], c["y"][i], c["h"], c["w"] * 10, c["s"])
+        mo, vo = oracle.gp_predict(c["x"][i], c["h"], c["w"] * 10, Lo, ao, c["xo"][i])
+        assert relmax(mean[i], mo) < RTOL
+        assert relmax(var[i], vo, scale=oracle.kernel_scale(1, c["h"], c["w"] * 10)) < RTOL
+        assert abs(logml[i] - lmo) <= RTOL * abs(lmo)
+
+
+def test_plan_rerun_is_deterministic(engine):
+    c = wl.c5([0, 1, 2], n=300, m=40)
+    plan = engine.plan(3, 1, 300, 40)
+    plan.set_inputs(c["x"], c["y"], c["xo"], c["h"], c["w"] * 10, c["s"])
+    plan.run()
+    a = plan.results()
+    plan.run()
+    b = plan.results()
+    for u, v in zip(a, b):
+        assert (u == v).all()
+    plan.close()
+
+
+# ---- golden fixtures ----------------------------------------------------------------
+def test_golden_c1(engine):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "c1_n32.npz"))
+    mean, var, logml = engine.fit_predict(g["x"], g["y"], float(g["h"]), g["w"], float(g["s"]),
+                                          g["xo"])
+    assert relmax(mean, g["mean"]) < RTOL
+    assert relmax(var, g["var"], scale=float(g["k0"])) < RTOL
+    assert abs(logml - float(g["logml"])) <= RTOL * abs(float(g["logml"]))
+    fit = engine.gp_fit(g["x"], g["y"], float(g["h"]), g["w"], float(g["s"]))
+    assert relmax(fit.L(), g["L"]) < 1e-12
+    assert relmax(fit.alpha(), g["alpha"]) < RTOL
+    fit.close()
+
+
+# ---- full BASELINE sizes through size-independent properties --------------------------
+def _resid(K, L, rs, nvec=4):
+    """|| L (L^T v) - K v || / || K v || on random vectors: O(n^2) per vector."""
+    worst = 0.0
+    for _ in range(nvec):
+        v = rs.randn(K.shape[0])
+        Kv = K.dot(v)
+        worst = max(worst, np.linalg.norm(L.dot(L.T.dot(v)) - Kv) / np.linalg.norm(Kv))
+    return worst
+
+
+def test_c3_size_factorisation_property(engine):
+    c = wl.c3()  # N = 4096, d = 2
+    g = 200      # a mid-grid hyper-parameter point
+    fit = engine.gp_fit(c["x"], c["y"], c["h"][g], c["w"][g], c["s"])
+    K, L = fit.K(), fit.L()
+    assert (K == K.T).all()
+    assert _resid(K, L, np.random.RandomState(0)) < 1e-14 * 4096
+    # log-ML identity from the factor: -1/2 |z|^2 - sum log L_ii - n/2 log 2pi
+    z = fit.z()
+    ref = -0.5 * z.dot(z) - np.log(np.diag(L)).sum() - 0.5 * 4096 * np.log(2 * np.pi)
+    assert abs(fit.logml - ref) <= 1e-12 * abs(ref)
+    # alpha solves K alpha = y
+    assert np.linalg.norm(K.dot(fit.alpha()) - c["y"]) / np.linalg.norm(c["y"]) < 1e-9
+    fit.close()
+
+
+def test_c4_size_cholesky_property(engine):
+    """N = 16384 (the MFMA roofline size) on device-resident data."""
+    import ctypes as C
+    c = wl.c4()
+    n = 16384
+    x = np.ascontiguousarray(c["x"])
+    xd = engine.alloc(8 * n)
+    Kd = engine.alloc(8 * n * n)
+    info = engine.alloc(64)
+    engine.upload(xd, x)
+    lib, ctx = engine._lib, engine._ctx
+    w = np.ascontiguousarray(c["w"])
+    from bayesian_quadrature_amd import _lib as L_
+    engine._check(lib.bq_gram_gauss_dev(ctx, xd, 1, n, c["h"], L_.dptr(w), c["s"], Kd, n))
+    K = np.empty((n, n), order="F")
+    engine.download(K, Kd)
+    engine._check(lib.bq_potrf_dev(ctx, Kd, n, n, info))
+    Lf = np.empty((n, n), order="F")
+    engine.download(Lf, Kd)
+    hinfo = np.zeros(1, dtype=np.int32)
+    engine.download(hinfo, info)
+    engine.free(xd), engine.free(Kd), engine.free(info)
+    assert hinfo[0] == 0
+    Lf = np.tril(Lf)
+    assert _resid(K, Lf, np.random.RandomState(1), nvec=2) < 1e-14 * n
+    # spot-check Gram entries against the closed form
+    rs = np.random.RandomState(2)
+    i, j = rs.randint(0, n, 1000), rs.randint(0, n, 1000)
+    ref = c["h"] ** 2 / (np.sqrt(2 * np.pi) * w[0]) * np.exp(-(x[i] - x[j]) ** 2 / (2 * w[0] ** 2)) \
+        + (i == j) * c["s"] ** 2
+    assert np.allclose(K[i, j], ref, rtol=1e-13, atol=0)
