@@ -80,7 +80,9 @@ struct bq_ctx {
     std::vector<ProfEvent> prof_events;
     double prof_ms[BQ_K_NCLASS] = {0};
     int64_t prof_n[BQ_K_NCLASS] = {0};
-    DevBuf gbuf;   // GaussParams of the single-problem entry points
+    DevBuf gbuf;   // GaussParams of the single-problem entry points (cached)
+    GaussParams gbuf_host{};
+    bool gbuf_valid = false;
     DevBuf dinv64; // potf2 reciprocal-diagonal scratch
 };
 
@@ -802,11 +804,19 @@ extern "C" int bq_gram_gauss_dev(bq_ctx *c, const double *x_dev, int64_t d, int6
     if (!x_dev || !K_dev || ldk < n)
         return fail(c, BQ_ERR_BAD_ARG, "illegal value");
     // parameters ride in a tiny device buffer so the same kernel serves the
-    // batched callers; one 80-byte upload
+    // batched callers; uploaded only when they change
     GaussParams g = make_params((int)d, h, w, s);
-    if (!c->gbuf.p)
+    if (!c->gbuf.p) {
         HIPCHK(c, c->gbuf.alloc(sizeof(GaussParams)));
-    HIPCHK(c, hipMemcpyAsync(c->gbuf.p, &g, sizeof g, hipMemcpyHostToDevice, c->stream));
+        c->gbuf_valid = false;
+    }
+    if (!c->gbuf_valid || std::memcmp(&c->gbuf_host, &g, sizeof g) != 0) {
+        // synchronous on purpose: the staging copy of `g` must not outlive this frame
+        HIPCHK(c, hipMemcpyAsync(c->gbuf.p, &g, sizeof g, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->gbuf_host = g;
+        c->gbuf_valid = true;
+    }
     return launch_gram_sym(c, (int)d, x_dev, 0, static_cast<GaussParams *>(c->gbuf.p), 0, K_dev,
                            ldk, 0, (int)n, 1);
 }

@@ -270,6 +270,7 @@ __global__ __launch_bounds__(64) void potf2_64_kernel(double *__restrict__ A, lo
     int bad = 0;
     double d = readlane_f64(a[0], 0);
     double r, s;
+    double myr = 0.0; // lane j keeps 1 / L_jj
     rsqrt_sqrt_f64(d, r, s);
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
@@ -277,32 +278,37 @@ __global__ __launch_bounds__(64) void potf2_64_kernel(double *__restrict__ A, lo
             bad = j0 + j + 1;
         const double l = (lane == j) ? s : a[j] * r;
         a[j] = l;
-        if (lane == j)
-            dinv[(long)b * dstride + j] = r;
+        myr = (lane == j) ? r : myr;
         if (j < 63) {
-            // next pivot first, by readlane: its rsqrt chain is issued ahead of
-            // the LDS-fed updates of this column and overlaps them
-            a[j + 1] -= l * readlane_f64(l, j + 1);
-            d = readlane_f64(a[j + 1], j + 1);
-            rsqrt_sqrt_f64(d, r, s);
+            double2_t lk[32];
             if (j < 62) {
+                // broadcast reads of the column are issued first; the next
+                // pivot's readlane + rsqrt chain below runs under their latency
                 col[j & 1][lane] = l;
                 __syncthreads();
                 const double2_t *c2 = reinterpret_cast<const double2_t *>(col[j & 1]);
 #pragma unroll
+                for (int kk = (j + 2) >> 1; kk < 32; ++kk)
+                    lk[kk] = c2[kk];
+            }
+            a[j + 1] -= l * readlane_f64(l, j + 1);
+            d = readlane_f64(a[j + 1], j + 1);
+            rsqrt_sqrt_f64(d, r, s);
+            if (j < 62) {
+#pragma unroll
                 for (int kk = (j + 2) >> 1; kk < 32; ++kk) {
-                    const double2_t lk = c2[kk];
-                    if (2 * kk >= j + 2) {
-                        a[2 * kk] -= l * lk[0];
-                        PIN(a[2 * kk]);
-                    }
-                    a[2 * kk + 1] -= l * lk[1];
-                    PIN(a[2 * kk + 1]);
+                    if (2 * kk >= j + 2)
+                        a[2 * kk] -= l * lk[kk][0];
+                    a[2 * kk + 1] -= l * lk[kk][1];
                 }
+#pragma unroll
+                for (int k = j + 2; k < 64; ++k)
+                    PIN(a[k]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    dinv[(long)b * dstride + lane] = myr;
     // fresh per-lane pointer: without the opaque copy the compiler keeps the 64
     // load addresses alive across the whole factorisation and spills
     double *pw = Ab + lane;
@@ -367,39 +373,68 @@ __global__ __launch_bounds__(64) void trsm_rows_kernel(double *__restrict__ X, l
         }
     }
     __syncthreads();
+    // Row p of T is fetched one column step ahead of its use (T is static), so
+    // the LDS latency hides behind the previous step's FMAs.
+    double2_t cur[32], nxt[32];
     if (TRANS) {
+        {
+            const double2_t *t2 = reinterpret_cast<const double2_t *>(T);
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk)
+                cur[kk] = t2[kk];
+        }
 #pragma unroll
         for (int p = 0; p < 64; ++p) {
+            if (p < 63) {
+                const double2_t *t2 = reinterpret_cast<const double2_t *>(T + (p + 1) * 64);
+#pragma unroll
+                for (int kk = (p + 2) >> 1; kk < 32; ++kk)
+                    nxt[kk] = t2[kk];
+            }
             const double xp = x[p] * di[p];
             x[p] = xp;
-            const double2_t *t2 = reinterpret_cast<const double2_t *>(T + p * 64);
 #pragma unroll
             for (int kk = (p + 1) >> 1; kk < 32; ++kk) {
-                const double2_t l = t2[kk];
-                if (2 * kk >= p + 1) {
-                    x[2 * kk] -= l[0] * xp;
-                    PIN(x[2 * kk]);
-                }
-                x[2 * kk + 1] -= l[1] * xp;
-                PIN(x[2 * kk + 1]);
+                if (2 * kk >= p + 1)
+                    x[2 * kk] -= cur[kk][0] * xp;
+                x[2 * kk + 1] -= cur[kk][1] * xp;
             }
+#pragma unroll
+            for (int j = p + 1; j < 64; ++j)
+                PIN(x[j]);
+#pragma unroll
+            for (int kk = (p + 2) >> 1; kk < 32; ++kk)
+                cur[kk] = nxt[kk];
         }
     } else {
+        {
+            const double2_t *t2 = reinterpret_cast<const double2_t *>(T + 63 * 64);
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk)
+                cur[kk] = t2[kk];
+        }
 #pragma unroll
         for (int p = 63; p >= 0; --p) {
+            if (p > 0) {
+                const double2_t *t2 = reinterpret_cast<const double2_t *>(T + (p - 1) * 64);
+#pragma unroll
+                for (int kk = 0; 2 * kk < p - 1; ++kk)
+                    nxt[kk] = t2[kk];
+            }
             const double xp = x[p] * di[p];
             x[p] = xp;
-            const double2_t *t2 = reinterpret_cast<const double2_t *>(T + p * 64);
 #pragma unroll
             for (int kk = 0; 2 * kk < p; ++kk) {
-                const double2_t l = t2[kk];
-                x[2 * kk] -= l[0] * xp;
-                PIN(x[2 * kk]);
-                if (2 * kk + 1 < p) {
-                    x[2 * kk + 1] -= l[1] * xp;
-                    PIN(x[2 * kk + 1]);
-                }
+                x[2 * kk] -= cur[kk][0] * xp;
+                if (2 * kk + 1 < p)
+                    x[2 * kk + 1] -= cur[kk][1] * xp;
             }
+#pragma unroll
+            for (int j = 0; j < p; ++j)
+                PIN(x[j]);
+#pragma unroll
+            for (int kk = 0; 2 * kk < p - 1; ++kk)
+                cur[kk] = nxt[kk];
         }
     }
     if (ok) {

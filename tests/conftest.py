@@ -28,7 +28,7 @@ def _have_gpu():
 def oracle():
     from oracle import load
     o = load()
-    o.set_threads(min(8, o.max_threads()))
+    o.set_threads(max(1, min(8, o.max_threads(), len(os.sched_getaffinity(0)))))
     return o
 
 
