@@ -1,0 +1,391 @@
+"""``BQ``: Bayesian quadrature of Z = int l(x) N(x | mu, sigma^2) dx with two stacked
+GPs (one over log l, one over exp(log l)), after Osborne et al. 2012.
+
+Drop-in for ``bayesian_quadrature.BQ`` (reference bq.py:19-1026): same constructor,
+options, method names, return values and exceptions.  Python 3; the GP fits, posterior
+evaluations, log marginal likelihoods and Cholesky solves run on the MI355X through the
+C ABI (``gp.py`` / ``linalg.py``).  Only the exact (Gaussian-kernel) branch exists: the
+trapezoid ``approx`` branch and the periodic kernel are outside the accelerated path
+ and raise ``NotImplementedError``; plotting helpers
+are likewise not part of this package.
+"""
+import logging
+from copy import copy, deepcopy
+
+import numpy as np
+
+from . import bq_c
+from . import linalg as la
+from . import util
+from .gp import GP, GaussianKernel, PeriodicKernel
+
+logger = logging.getLogger("bayesian_quadrature")
+DTYPE = np.dtype("float64")
+MIN = float(np.log(np.exp2(np.float64(np.finfo(np.float64).minexp + 4))))
+MAX = float(np.log(np.exp2(np.float64(np.finfo(np.float64).maxexp - 4))))
+
+_STATE_ALWAYS = ("x_s", "l_s", "tl_s", "options", "initialized")
+
+
+def _row(x):
+    """1-D points as the d x n Fortran array the integral helpers expect (bq.py:281)."""
+    return np.array(np.asarray(x, dtype=DTYPE)[None], order="F")
+
+
+class BQ(object):
+    """Estimate Z = int l(x) N(x | x_mean, x_var) dx from samples (x, l)."""
+
+    # ------------------------------------------------------------------ setup
+    def __init__(self, x, l, **options):
+        self.x_s = np.array(x, dtype=DTYPE)
+        self.l_s = np.array(l, dtype=DTYPE)
+        if (self.l_s <= 0).any():
+            raise ValueError("l_s contains zero or negative values")
+        if self.x_s.ndim > 1:
+            raise ValueError("invalid number of dimensions for x")
+        if self.l_s.ndim > 1:
+            raise ValueError("invalid number of dimensions for l")
+        if self.x_s.shape != self.l_s.shape:
+            raise ValueError("shape mismatch for x and l")
+        self.tl_s = np.log(self.l_s)
+        self.ns = self.x_s.shape[0]
+        self.load_options(**options)
+        self.initialized = False
+        self._clear_fit_state()
+
+    def _clear_fit_state(self):
+        self.gp_log_l = None   # GP over log(l)
+        self.gp_l = None       # GP over exp(log(l))
+        self.x_c = self.l_c = self.nc = None      # candidate points
+        self.x_sc = self.l_sc = self.nsc = None   # samples followed by candidates
+        self._approx_x = None
+        self._approx_px = None
+
+    def load_options(self, kernel, n_candidate, candidate_thresh, x_mean, x_var, optim_method):
+        """All six options are required (bq.py:94).  ``kernel`` is the kernel class,
+        ``x_mean`` / ``x_var`` the Gaussian prior over x."""
+        self.options = {
+            "kernel": kernel,
+            "n_candidate": int(n_candidate),
+            "candidate_thresh": float(candidate_thresh),
+            "x_mean": np.array([x_mean], dtype=DTYPE, order="F"),
+            "x_cov": np.array([[x_var]], dtype=DTYPE, order="F"),
+            "use_approx": not (kernel is GaussianKernel),
+            "wrapped": kernel is PeriodicKernel,
+            "optim_method": optim_method,
+        }
+
+    def _require_exact(self):
+        if self.options["use_approx"]:
+            raise NotImplementedError(
+                "only the Gaussian-kernel (exact) branch is implemented on the MI355X engine")
+
+    def init(self, params_tl, params_l):
+        """Create both GPs.  ``params_*`` = (h, w, s): kernel parameters then noise."""
+        self._require_exact()
+        kernel = self.options["kernel"]
+        self.gp_log_l = GP(kernel(*params_tl[:-1]), self.x_s, self.tl_s, s=params_tl[-1])
+        self.gp_log_l.jitter = np.zeros(self.ns, dtype=DTYPE)
+        self._choose_candidates()
+        self.gp_l = GP(kernel(*params_l[:-1]), self.x_sc, self.l_sc, s=params_l[-1])
+        self.gp_l.jitter = np.zeros(self.nsc, dtype=DTYPE)
+        self._approx_x = self._make_approx_x()
+        self._approx_px = self._make_approx_px()
+        self.initialized = True
+
+    # ------------------------------------------------------- posterior over l
+    def l_mean(self, x):
+        """Mean of the final approximation: the posterior mean of the second GP."""
+        return self.gp_l.mean(x)
+
+    def l_var(self, x):
+        """Marginal variance: var of the log-GP times the squared mean of the
+        second GP, negatives clamped to zero (bq.py:227-231).  Only the diagonal of
+        the covariance is computed."""
+        v_log_l = self.gp_log_l.var(x)
+        m_l = self.gp_l.mean(x)
+        l_var = v_log_l * m_l ** 2
+        l_var[l_var < 0] = 0
+        return l_var
+
+    # ---------------------------------------------------------------- moments
+    def Z_mean(self):
+        self._require_exact()
+        return self._exact_Z_mean()
+
+    def _exact_Z_mean(self):
+        h, w = self.gp_l.K.params
+        return bq_c.Z_mean(_row(self.x_sc), self.gp_l.inv_Kxx_y, h, np.array([w]),
+                           self.options["x_mean"], self.options["x_cov"])
+
+    def Z_var(self):
+        self._require_exact()
+        return self._exact_Z_var()
+
+    def _exact_Z_var(self):
+        h_l, w_l = self.gp_l.K.params
+        h_tl, w_tl = self.gp_log_l.K.params
+        return bq_c.Z_var(_row(self.x_s), _row(self.x_sc), self.gp_l.inv_Kxx_y,
+                          np.array(self.gp_log_l.Lxx, order="F"), h_l, np.array([w_l]),
+                          h_tl, np.array([w_tl]), self.options["x_mean"], self.options["x_cov"])
+
+    # ------------------------------------------------- expected moments given x_a
+    def expected_Z_var(self, x_a):
+        """E[V(Z) | new observation at x_a] for every entry of x_a."""
+        second_moment = self.Z_mean() ** 2 + self.Z_var()
+        return second_moment - self.expected_squared_mean(x_a)
+
+    def expected_squared_mean(self, x_a):
+        x_a = np.asarray(x_a, dtype=DTYPE)
+        return np.array([self._esm_and_em(x_a[[i]])[0] for i in range(x_a.shape[0])])
+
+    def expected_mean(self, x_a):
+        x_a = np.asarray(x_a, dtype=DTYPE)
+        return np.array([self._esm_and_em(x_a[[i]])[1] for i in range(x_a.shape[0])])
+
+    def expected_squared_mean_and_mean(self, x_a):
+        x_a = np.asarray(x_a, dtype=DTYPE)
+        out = np.empty((x_a.shape[0], 2))
+        for i in range(x_a.shape[0]):
+            out[i] = self._esm_and_em(x_a[[i]])
+        return out
+
+    def _current_mean_pair(self):
+        em = self.Z_mean()
+        return em ** 2, em
+
+    def _esm_and_em(self, x_a):
+        """(E[m(Z)^2], E[m(Z)]) after a hypothetical observation at the single
+        point x_a (bq.py:447-527)."""
+        self._require_exact()
+        if x_a is None or np.isnan(x_a) or np.isinf(x_a):
+            raise ValueError("invalid value for x_a: %s" % x_a)
+        # a point we (almost) already have cannot move the mean
+        if np.isclose(x_a, self.x_s, atol=1e-4).any():
+            return self._current_mean_pair()
+
+        x_sca = np.concatenate([self.x_sc, x_a])
+        K_l = self.gp_l.Kxoxo(x_sca)
+        jitter = np.zeros(self.nsc + 1)
+        # candidates near x_a are the ones most likely to change: loosen them,
+        # and always loosen the new point itself
+        close = np.abs(self.x_c - x_a) < self.options["candidate_thresh"]
+        if close.any():
+            bq_c.improve_covariance_conditioning(K_l, jitter, np.nonzero(close)[0] + self.ns)
+        bq_c.improve_covariance_conditioning(K_l, jitter, np.array([self.nsc]))
+
+        L = np.empty(K_l.shape, order="F")
+        try:
+            la.cho_factor(np.array(K_l, order="F"), L)
+        except np.linalg.LinAlgError:
+            # singular: x_a duplicates information we have, the mean will not move
+            return self._current_mean_pair()
+
+        tm_a, tC_a = self.gp_log_l.mean_var(x_a)
+        esm, em = bq_c.expected_squared_mean_and_mean(
+            self.l_sc, L, tm_a, tC_a, _row(x_sca), self.gp_l.K.h, np.array([self.gp_l.K.w]),
+            self.options["x_mean"], np.array(self.options["x_cov"], order="F"))
+
+        if np.isnan(esm) or esm < 0:
+            raise RuntimeError("invalid expected squared mean for x_a=%s: %s" % (x_a, esm))
+        if np.isnan(em):
+            raise RuntimeError("invalid expected mean for x_a=%s: %s" % (x_a, em))
+        if np.isinf(esm):
+            logger.warning("expected squared mean for x_a=%s is infinity!", x_a)
+        if np.isinf(em):
+            logger.warning("expected mean for x_a=%s is infinity!", x_a)
+        return esm, em
+
+    # ------------------------------------------------------- hyper-parameters
+    def _make_llh_params(self, params):
+        """Closure x -> log_lh(GP1) + log_lh(GP2) for parameter vector
+        [params of GP1..., params of GP2...]; any failure is -inf (bq.py:536-550)."""
+        nparam = len(params)
+
+        def f(x):
+            if x is None or np.isnan(x).any():
+                return -np.inf
+            try:
+                self._set_gp_log_l_params(dict(zip(params, x[:nparam])))
+                self._set_gp_l_params(dict(zip(params, x[nparam:])))
+                return self.gp_log_l.log_lh + self.gp_l.log_lh
+            except (ValueError, np.linalg.LinAlgError):
+                return -np.inf
+
+        return f
+
+    def _current_params(self, params):
+        return np.array([self.gp_log_l.get_param(p) for p in params] +
+                        [self.gp_l.get_param(p) for p in params])
+
+    def fit_hypers(self, params):
+        f = self._make_llh_params(params)
+        p0 = util.find_good_parameters(f, self._current_params(params),
+                                       self.options["optim_method"])
+        if p0 is None:
+            raise RuntimeError("couldn't find good parameters")
+        f(p0)  # leave the GPs at the optimum (the optimiser's last call may be elsewhere)
+
+    def sample_hypers(self, params, n=1, nburn=10):
+        """Slice-sample new hyper-parameters for both GPs; returns the samples for
+        GP1 and GP2 (bq.py:565-598).  The GPs are left at the last evaluated point."""
+        nparam = len(params)
+        window = 2 * nparam
+        p0 = self._current_params(params)
+        f = self._make_llh_params(params)
+        if f(p0) < MIN:
+            pn = util.find_good_parameters(f, p0, self.options["optim_method"])
+            if pn is None:
+                raise RuntimeError("couldn't find good starting parameters")
+            p0 = pn
+        hypers = util.slice_sample(f, nburn + n, window, p0, nburn=nburn, freq=1)
+        return hypers[:, :nparam], hypers[:, nparam:]
+
+    # --------------------------------------------------------- active sampling
+    def marginalize(self, funs, n, params):
+        """Evaluate each function of ``funs`` under ``n`` sampled hyper-parameter
+        settings; the object's state is restored afterwards (bq.py:604-657)."""
+        state = deepcopy(self.__getstate__())
+        values = []
+        for fun in funs:
+            shape = getattr(fun(), "shape", ())
+            values.append(np.empty((n,) + tuple(shape)))
+        hypers_tl, hypers_l = self.sample_hypers(params, n=n, nburn=1)
+        for i in range(n):
+            params_tl = dict(zip(params, hypers_tl[i]))
+            params_l = dict(zip(params, hypers_l[i]))
+            self._set_gp_log_l_params(params_tl)
+            self._set_gp_l_params(params_l)
+            for j, fun in enumerate(funs):
+                try:
+                    values[j][i] = fun()
+                except Exception:
+                    logger.error("error with parameters %s and %s", params_tl, params_l)
+                    raise
+        self.__setstate__(state)
+        return values
+
+    def choose_next(self, x_a, n, params, plot=False):
+        """The entry of x_a with the smallest marginal loss -E[m(Z)^2]."""
+        if plot:
+            raise NotImplementedError("plotting is not part of the MI355X engine")
+        loss = self.marginalize([lambda: -self.expected_squared_mean(x_a)], n, params)[0]
+        loss = loss.mean(axis=0)
+        ties = np.nonzero(np.isclose(loss, np.min(loss)))[0]
+        return x_a[np.random.choice(ties)]
+
+    def add_observation(self, x_a, l_a):
+        """Add (x_a, l_a); an x_a within ``candidate_thresh`` of a sample is averaged
+        into it instead.  Re-initialises both GPs with their current parameters."""
+        diffs = np.abs(x_a - self.x_s)
+        if diffs.min() < self.options["candidate_thresh"]:
+            c = diffs.argmin()
+            self.x_s[c] = (self.x_s[c] + x_a) / 2.0
+            self.l_s[c] = (self.l_s[c] + l_a) / 2.0
+            self.tl_s[c] = np.log(float(self.l_s[c]))
+        else:
+            self.x_s = np.append(self.x_s, float(x_a))
+            self.l_s = np.append(self.l_s, float(l_a))
+            self.tl_s = np.append(self.tl_s, np.log(float(l_a)))
+            self.ns += 1
+        self.init(self.gp_log_l.params, self.gp_l.params)
+
+    # ------------------------------------------------------- pickling, copying
+    def __getstate__(self):
+        state = {k: getattr(self, k) for k in _STATE_ALWAYS}
+        if self.initialized:
+            state["gp_log_l"] = self.gp_log_l
+            state["gp_log_l_jitter"] = self.gp_log_l.jitter
+            state["gp_l"] = self.gp_l
+            state["gp_l_jitter"] = self.gp_l.jitter
+            state["_approx_x"] = self._approx_x
+            state["_approx_px"] = self._approx_px
+        return state
+
+    def __setstate__(self, state):
+        for k in _STATE_ALWAYS:
+            setattr(self, k, state[k])
+        self.ns = self.x_s.shape[0]
+        if not self.initialized:
+            self._clear_fit_state()
+            return
+        self.gp_log_l = state["gp_log_l"]
+        self.gp_log_l.jitter = state["gp_log_l_jitter"]
+        self.gp_l = state["gp_l"]
+        self.gp_l.jitter = state["gp_l_jitter"]
+        self.x_sc = self.gp_l._x
+        self.l_sc = self.gp_l._y
+        self.nsc = self.x_sc.shape[0]
+        self.x_c = self.x_sc[self.ns:]
+        self.l_c = self.l_sc[self.ns:]
+        self.nc = self.nsc - self.ns
+        self._approx_x = state["_approx_x"]
+        self._approx_px = state["_approx_px"]
+
+    def __copy__(self):
+        new = type(self).__new__(type(self))
+        new.__setstate__(self.__getstate__())
+        return new
+
+    def __deepcopy__(self, memo):
+        new = type(self).__new__(type(self))
+        new.__setstate__(deepcopy(self.__getstate__(), memo))
+        return new
+
+    def copy(self, deep=True):
+        return deepcopy(self) if deep else copy(self)
+
+    # ---------------------------------------------------------------- helpers
+    def _set_gp_log_l_params(self, params):
+        """New hyper-parameters for GP1: refit, re-evaluate the candidates
+        (l_c = exp(mean), with the overflow guard of bq.py:945-947) and hand the
+        new targets to GP2 (bq.py:933-957)."""
+        for p, v in params.items():
+            self.gp_log_l.set_param(p, v)
+        self.gp_log_l.jitter.fill(0)
+        m, V = self.gp_log_l.mean_var(self.x_c) if self.nc else (np.empty(0), np.empty(0))
+        V = V.copy()
+        V[V < 0] = 0
+        if ((m + 2 * np.sqrt(V)) > MAX).any():
+            raise np.linalg.LinAlgError("GP mean is too large")
+        self.l_c = np.exp(m)
+        self.l_sc = np.array(np.concatenate([self.l_s, self.l_c]))
+        self.gp_l.x = self.x_sc
+        self.gp_l.y = self.l_sc
+        self.gp_l.jitter.fill(0)
+
+    def _set_gp_l_params(self, params):
+        for p, v in params.items():
+            self.gp_l.set_param(p, v)
+        self.gp_l.jitter.fill(0)
+
+    def _choose_candidates(self):
+        """Uniform draws over the sample range widened by w, filtered for spacing
+        (bq.py:967-991); their values are exp(mean of GP1)."""
+        if self.options["wrapped"]:
+            raise NotImplementedError("periodic kernels are out of scope")
+        w = self.gp_log_l.K.w
+        xc = np.random.uniform(self.x_s.min() - w, self.x_s.max() + w,
+                               self.options["n_candidate"])
+        bq_c.filter_candidates(xc, self.x_s, self.options["candidate_thresh"])
+        self.x_c = np.sort(xc[~np.isnan(xc)])
+        self.nc = self.x_c.shape[0]
+        self.l_c = np.exp(self.gp_log_l.mean(self.x_c)) if self.nc else np.empty(0, dtype=DTYPE)
+        self.x_sc = np.array(np.concatenate([self.x_s, self.x_c]))
+        self.l_sc = np.array(np.concatenate([self.l_s, self.l_c]))
+        self.nsc = self.ns + self.nc
+
+    def _make_approx_x(self, xmin=None, xmax=None, n=1000):
+        w = self.gp_log_l.K.w
+        if xmin is None:
+            xmin = self.x_sc.min() - w
+        if xmax is None:
+            xmax = self.x_sc.max() + w
+        return np.linspace(xmin, xmax, n)
+
+    def _make_approx_px(self, x=None):
+        if x is None:
+            x = self._approx_x
+        p = np.empty(x.size, order="F")
+        bq_c.p_x_gaussian(p, _row(x), self.options["x_mean"], self.options["x_cov"])
+        return p

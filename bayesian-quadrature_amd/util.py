@@ -1,0 +1,79 @@
+"""Host-side drivers of the hyper-parameter loop (callers of the hot path).
+
+Mirror of the parts of the reference's ``util.py`` / ``util_c.pyx`` that ``BQ``
+uses: ``find_good_parameters`` (util.py:151-169) and ``slice_sample``
+(util.py:45-75 over util_c.pyx:25-148).  The slice sampler is a sequential MCMC
+driver around a Python log-pdf; it stays on the host.  Unlike the reference it
+draws from numpy's generator only (the reference mixes in libc ``rand()``,
+util_c.pyx:21-33), so runs are reproducible under ``np.random.seed``.
+"""
+import logging
+
+import numpy as np
+import scipy.optimize as optim
+
+logger = logging.getLogger("bayesian_quadrature.util")
+
+MIN = float(np.log(np.exp2(np.float64(np.finfo(np.float64).minexp + 4))))
+
+
+def find_good_parameters(logpdf, x0, method, ntry=10):
+    """Up to ``ntry`` restarts of scipy.optimize.minimize on -logpdf; returns the
+    first optimum whose log-pdf exceeds MIN, else None."""
+    for i in range(ntry):
+        logger.debug("Attempt #%d with %s", i + 1, method)
+        res = optim.minimize(fun=lambda x: -logpdf(x), x0=x0, method=method)
+        p = logpdf(res["x"])
+        if p > MIN:
+            return res["x"]
+        if logpdf(x0) < p:
+            x0 = res["x"]
+    return None
+
+
+def _slice_sample(samples, logpdf, xval, w, verbose=False):
+    """Univariate slice sampling along random directions; fills samples[1:]."""
+    n, d = samples.shape
+    i = 0
+    while i < n - 1:
+        xpr = logpdf(samples[i])
+        if xpr == -np.inf:
+            raise RuntimeError("zero probability encountered")
+        yval = np.random.uniform(0, np.exp(xpr))
+        logyval = np.log(yval) if yval > 0 else -np.inf
+        direction = np.random.rand(d) - 0.5
+        direction /= np.linalg.norm(direction)
+        left, right = -w, w
+        # step the window out until both ends leave the slice (at most 100 steps)
+        for _ in range(101):
+            if logpdf(samples[i] + left * direction) < logyval:
+                break
+            left -= w
+        for _ in range(101):
+            if logpdf(samples[i] + right * direction) < logyval:
+                break
+            right += w
+        # shrink until a point inside the slice is drawn
+        while True:
+            if (right - left) < 1e-9:
+                break  # window collapsed: redraw the slice height at the same point
+            loc = np.random.uniform(left, right)
+            samples[i + 1] = samples[i] + loc * direction
+            if logpdf(samples[i + 1]) > logyval:
+                i += 1
+                break
+            if loc < 0:
+                left = loc
+            else:
+                right = loc
+
+
+def slice_sample(logpdf, niter, w, xval, nburn=1, freq=1):
+    """Draw ``niter`` states starting at ``xval``; drops the first ``nburn`` and
+    keeps every ``freq``-th of the rest."""
+    xval = np.asarray(xval, dtype=np.float64)
+    samples = np.empty((niter, xval.size))
+    samples[0] = xval
+    verbose = (logger.level != 0) and (logger.level < 10)
+    _slice_sample(samples, logpdf, xval, float(w), verbose)
+    return samples[nburn:][::freq]

@@ -1,0 +1,102 @@
+"""CPU test double of ``bayesian_quadrature_amd.engine.Engine`` backed by the oracle.
+
+TEST INFRASTRUCTURE ONLY.  It exists so that the CPU-only suite (``-m "not gpu"``)
+can exercise the *host logic* of the product -- the ``BQ`` class, the ``gp`` memoisation
+protocol, the ``linalg`` argument checking, pickling, the sharding helpers -- on a
+machine without a GPU.  It is installed with ``engine.set_engine`` from tests only; the
+product has no way to select it and never imports this file.  GPU parity is established
+by ``test_gpu_parity.py`` / the ``gpu`` parameter of ``test_bq_object.py``, which run the
+same assertions against the real HIP engine.
+"""
+import numpy as np
+
+
+class FitDouble(object):
+    def __init__(self, o, x, y, h, w, s):
+        self.o = o
+        self.x = np.asarray(x, dtype=np.float64)
+        self.y = np.ascontiguousarray(y, dtype=np.float64)
+        self.n = self.y.shape[0]
+        self.refit(h, w, s)
+
+    def refit(self, h, w, s):
+        self.h, self.w, self.s = float(h), np.atleast_1d(np.asarray(w, dtype=np.float64)), float(s)
+        self._L, self._alpha, self.logml = self.o.gp_fit(self.x, self.y, self.h, self.w, self.s)
+
+    def close(self):
+        pass
+
+    def L(self):
+        return self._L.copy(order="F")
+
+    def alpha(self):
+        return self._alpha.copy()
+
+    def z(self):
+        return self.o.trsm_lower(self._L, self.y)
+
+    def K(self):
+        return self.o.gram(self.x, self.h, self.w, self.s)
+
+    def predict(self, xo, want_mean=True, want_var=True, want_cov=False):
+        xo = np.atleast_1d(np.asarray(xo, dtype=np.float64))
+        mean, var = self.o.gp_predict(self.x, self.h, self.w, self._L, self._alpha, xo)
+        cov = None
+        if want_cov:
+            Ks = self.o.gram_cross(self.x, xo, self.h, self.w)      # n x M
+            V = self.o.trsm_lower(self._L, Ks)
+            cov = np.asfortranarray(self.o.gram_cross(xo, xo, self.h, self.w) - V.T.dot(V))
+        return (mean if want_mean else None), (var if want_var else None), cov
+
+
+class EngineDouble(object):
+    device = 0
+
+    def __init__(self, oracle):
+        self.o = oracle
+
+    def cho_factor(self, Cm, Lm):
+        L = self.o.cho_factor(Cm)           # raises LinAlgError like the device engine
+        upper = np.triu(Cm, 1)
+        Lm[:, :] = L + upper
+
+    def cho_solve(self, Lm, B, X, nrhs):
+        X[...] = self.o.cho_solve(np.tril(Lm), B)
+
+    def logdet(self, Lm):
+        return self.o.logdet(Lm)
+
+    def gram(self, x, h, w, s=0.0):
+        w = np.atleast_1d(np.asarray(w, dtype=np.float64))
+        if (w <= 0).any():
+            raise ValueError("w must be positive and finite")
+        return self.o.gram(x, h, w, s)
+
+    def gram_cross(self, x1, x2, h, w):
+        return self.o.gram_cross(x1, x2, h, w)
+
+    def gp_fit(self, x, y, h, w, s=0.0):
+        return FitDouble(self.o, x, y, h, w, s)
+
+    def batch_fit_predict(self, x, y, h, w, s, xo):
+        P = len(x)
+        M = np.asarray(xo).shape[-1]
+        mean, var = np.empty((P, M)), np.empty((P, M))
+        logml, status = np.empty(P), np.zeros(P, dtype=np.int32)
+        for p in range(P):
+            try:
+                f = FitDouble(self.o, x[p], y[p], h, w, s)
+                mean[p], var[p], _ = f.predict(xo[p])
+                logml[p] = f.logml
+            except np.linalg.LinAlgError:
+                status[p], logml[p] = 1, -np.inf
+        return mean, var, logml, status
+
+    def logml_grid(self, x, y, h, w, s=0.0, chunk=0):
+        out = np.empty(len(h))
+        for g in range(len(h)):
+            try:
+                out[g] = self.o.gp_fit(x, y, h[g], np.atleast_1d(w[g]), s)[2]
+            except np.linalg.LinAlgError:
+                out[g] = -np.inf
+        return out

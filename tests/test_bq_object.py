@@ -1,0 +1,305 @@
+"""Behavioural contract of ``BQ``, restated from the reference's
+tests/test_bq_object.py (same fixture: tests/util.py:12-59 of the reference) and its
+visual-tests notebook.  Runs twice: on the CPU against the oracle-backed engine double
+(host logic only) and, marked ``gpu``, against the real HIP engine."""
+import copy
+import pickle
+
+import numpy as np
+import pytest
+import scipy.stats
+
+from fixture_chain import known_answers
+
+OPTIONS = {
+    "n_candidate": 10, "x_mean": 0.0, "x_var": 10.0, "candidate_thresh": 0.5,
+    "optim_method": "L-BFGS-B",
+}
+
+
+@pytest.fixture(params=["double", pytest.param("gpu", marks=pytest.mark.gpu)])
+def pkg(request, oracle):
+    import bayesian_quadrature_amd as pkg
+    from bayesian_quadrature_amd import engine as eng_mod
+    saved = dict(eng_mod._engines)
+    eng_mod._engines.clear()
+    if request.param == "double":
+        from engine_double import EngineDouble
+        eng_mod.set_engine(EngineDouble(oracle), 0)
+    else:
+        from conftest import _have_gpu
+        if not _have_gpu():
+            pytest.skip("no HIP device")
+    yield pkg
+    eng_mod._engines.clear()
+    eng_mod._engines.update(saved)
+
+
+def f_x(x):
+    return scipy.stats.norm.pdf(x, 0, 1)
+
+
+def make_bq(pkg, n=9, x=None, nc=None, init=True):
+    if x is None:
+        x = np.linspace(-5, 5, n)
+    opt = dict(OPTIONS, kernel=pkg.GaussianKernel)
+    if nc is not None:
+        opt["n_candidate"] = nc
+    bq = pkg.BQ(x, f_x(x), **opt)
+    if init:
+        bq.init(params_tl=(15, 2, 0), params_l=(0.2, 1.3, 0))
+    return bq
+
+
+def npseed():
+    np.random.seed(8728)
+
+
+def test_init(pkg):
+    npseed()
+    x = np.linspace(-5, 5, 9)
+    y = f_x(x)
+    bq = pkg.BQ(x, y, kernel=pkg.GaussianKernel, **OPTIONS)
+    assert (x == bq.x_s).all() and (y == bq.l_s).all() and (np.log(y) == bq.tl_s).all()
+    assert bq.ns == 9 and not bq.initialized
+    for name in ("gp_log_l", "gp_l", "x_c", "l_c", "nc", "x_sc", "l_sc", "nsc", "_approx_x",
+                 "_approx_px"):
+        assert getattr(bq, name) is None
+    bq.init(params_tl=(15, 2, 0), params_l=(0.2, 1.3, 0))
+    assert bq.initialized
+    for name in ("gp_log_l", "gp_l", "x_c", "l_c", "nc", "x_sc", "l_sc", "nsc", "_approx_x",
+                 "_approx_px"):
+        assert getattr(bq, name) is not None
+    assert hasattr(bq.gp_log_l, "jitter") and hasattr(bq.gp_l, "jitter")
+    assert bq._approx_x.shape == (1000,) and bq._approx_px.shape == (1000,)
+
+
+def test_bad_init(pkg):
+    x = np.linspace(-5, 5, 9)
+    y = f_x(x)
+    kw = dict(OPTIONS, kernel=pkg.GaussianKernel)
+    for bx, by in ((x[:, None], y), (x, y[:, None]), (x[:-1], y), (x, y[:-1]), (x, -y)):
+        with pytest.raises(ValueError):
+            pkg.BQ(bx, by, **kw)
+    with pytest.raises(TypeError):
+        pkg.BQ(x, y, kernel=pkg.GaussianKernel)  # all six options are required
+
+
+def test_choose_candidates(pkg):
+    npseed()
+    bq = make_bq(pkg, nc=1000)
+    assert bq.x_c.ndim == 1 and bq.x_sc.size >= bq.x_s.size
+    diff = np.abs(bq.x_sc[:, None] - bq.x_c[None])
+    assert ((diff > bq.options["candidate_thresh"]) | (diff == 0)).all()
+
+
+def test_fixture_matches_reference(pkg):
+    """seed 8728 -> nc = 2 and the notebook's printed E[Z], V(Z)."""
+    npseed()
+    bq = make_bq(pkg)
+    assert bq.nc == 2 and bq.nsc == 11
+    exp = known_answers()["expected"]
+    assert abs(bq.Z_mean() - exp["Z_mean"]["value"]) < 1e-12
+    assert abs(bq.Z_var() - exp["Z_var"]["value"]) / exp["Z_var"]["value"] < 1e-7
+
+
+def test_l_mean(pkg):
+    npseed()
+    bq = make_bq(pkg)
+    assert np.allclose(bq.l_mean(bq.x_s), bq.l_s, atol=1e-4)
+
+
+def test_l_var(pkg):
+    npseed()
+    bq = make_bq(pkg)
+    xo = np.linspace(-10, 10, 100)
+    v = bq.l_var(xo)
+    assert v.shape == (100,) and (v >= 0).all()
+    # the reference formula: diag(cov of GP1) * mean(GP2)^2, negatives clamped
+    ref = np.diag(bq.gp_log_l.cov(xo)) * bq.gp_l.mean(xo) ** 2
+    ref[ref < 0] = 0
+    assert np.allclose(v, ref, rtol=1e-8, atol=1e-14)
+
+
+def test_Z_mean_and_var_vs_quadrature(pkg):
+    npseed()
+    bq = make_bq(pkg)
+    xo = np.linspace(-10, 10, 500)
+    p = scipy.stats.norm.pdf(xo, 0, np.sqrt(10.0))
+    assert np.allclose(np.trapezoid(bq.l_mean(xo) * p, xo), bq.Z_mean(), atol=1e-5)
+    m = bq.l_mean(xo) * p
+    C = bq.gp_log_l.cov(xo)
+    approx_var = np.trapezoid(np.trapezoid(C * m[:, None], xo, axis=0) * m, xo)
+    assert np.allclose(approx_var, bq.Z_var(), atol=1e-4)
+
+
+def test_Z_repeatable(pkg):
+    npseed()
+    bq = make_bq(pkg)
+    means = np.array([bq.Z_mean() for _ in range(20)])
+    assert (means[0] == means).all()
+    assert np.allclose([bq.Z_var() for _ in range(20)], bq.Z_var())
+
+
+def test_expected_Z_var_close(pkg):
+    npseed()
+    bq = make_bq(pkg)
+    assert np.allclose(bq.expected_Z_var(bq.x_s), bq.Z_var(), atol=1e-4)
+
+
+def test_expected_squared_mean(pkg):
+    npseed()
+    bq = make_bq(pkg)
+    x_a = np.random.uniform(-10, 10, 10)
+    esm = bq.expected_squared_mean(x_a)
+    assert (esm >= 0).all()
+    both = bq.expected_squared_mean_and_mean(x_a)
+    assert both.shape == (10, 2) and np.allclose(both[:, 0], esm)
+    assert np.allclose(both[:, 1], bq.expected_mean(x_a))
+    for bad in (np.nan, np.inf, -np.inf):
+        with pytest.raises(ValueError):
+            bq.expected_squared_mean(np.array([bad]))
+
+
+def test_expected_squared_mean_single_point(pkg):
+    npseed()
+    for x in np.linspace(-5, 5, 5)[:, None]:
+        bq = make_bq(pkg, x=x, nc=0)
+        m2 = bq.Z_mean() ** 2
+        for shift in (0.0, 1e-10, 1e-8):
+            assert np.allclose(m2, bq.expected_squared_mean(x - shift), atol=1e-4)
+
+
+def test_l(pkg):
+    npseed()
+    bq = make_bq(pkg)
+    assert (np.log(bq.l_s) == bq.tl_s).all()
+    assert (bq.l_s == bq.l_sc[:bq.ns]).all()
+    assert (bq.l_sc[bq.ns:] == np.exp(bq.gp_log_l.mean(bq.x_c))).all()
+
+
+def test_add_observation(pkg):
+    npseed()
+    bq = make_bq(pkg)
+    x, l, tl = bq.x_s.copy(), bq.l_s.copy(), bq.tl_s.copy()
+    x_a = 20
+    l_a = f_x(x_a)
+    bq.add_observation(x_a, l_a)
+    assert (bq.x_s == np.append(x, x_a)).all() and (bq.l_s == np.append(l, l_a)).all()
+    assert (bq.tl_s == np.append(tl, np.log(l_a))).all()
+    assert (bq.x_s == bq.x_sc[:bq.ns]).all() and (bq.l_s == bq.l_sc[:bq.ns]).all()
+    old_x, old_l = bq.x_s.copy(), bq.l_s.copy()
+    bq.add_observation(x[0], l[0])  # within candidate_thresh of a sample: averaged in
+    assert (old_x == bq.x_s).all() and (old_l == bq.l_s).all()
+
+
+def test_getstate_keys(pkg):
+    npseed()
+    bq = make_bq(pkg, init=False)
+    assert sorted(bq.__getstate__()) == sorted(["x_s", "l_s", "tl_s", "options", "initialized"])
+    bq.init(params_tl=(15, 2, 0), params_l=(0.2, 1.3, 0))
+    state = bq.__getstate__()
+    assert sorted(state) == sorted(
+        ["x_s", "l_s", "tl_s", "options", "initialized", "gp_log_l", "gp_log_l_jitter", "gp_l",
+         "gp_l_jitter", "_approx_x", "_approx_px"])
+    assert state["gp_log_l"] is bq.gp_log_l and state["gp_l"] is bq.gp_l
+
+
+def _states_equal(pkg, s1, s2, same_objects):
+    assert sorted(s1) == sorted(s2)
+    for key in s1:
+        if isinstance(s1[key], np.ndarray):
+            assert (s1[key] == s2[key]).all()
+        elif isinstance(s1[key], pkg.GP):
+            assert (s1[key].params == s2[key].params).all()
+        elif key != "options":
+            assert s1[key] == s2[key]
+        if not isinstance(s1[key], bool):
+            assert (s1[key] is s2[key]) == same_objects
+
+
+def test_copy_and_deepcopy(pkg):
+    npseed()
+    for init in (False, True):
+        bq1 = make_bq(pkg, init=init)
+        _states_equal(pkg, bq1.__getstate__(), bq1.copy(deep=False).__getstate__(), True)
+        bq2 = bq1.copy(deep=True)
+        assert bq1 is not bq2
+        _states_equal(pkg, bq1.__getstate__(), bq2.__getstate__(), False)
+        _states_equal(pkg, bq1.__getstate__(), copy.deepcopy(bq1).__getstate__(), False)
+    bq3 = pickle.loads(pickle.dumps(bq1))
+    assert bq3.Z_mean() == bq1.Z_mean()
+    assert (bq3.x_c == bq1.x_c).all() and bq3.nc == bq1.nc
+
+
+def test_set_params(pkg):
+    npseed()
+    bq = make_bq(pkg)
+    params_tl, params_l = bq.gp_log_l.params, bq.gp_l.params
+    x_sc, l_sc = bq.x_sc.copy(), bq.l_sc.copy()
+    bq._set_gp_log_l_params(dict(h=10, w=3.0, s=0.01))
+    assert (bq.gp_log_l.params != params_tl).all() and (bq.gp_l.params == params_l).all()
+    assert (bq.gp_log_l.jitter == 0).all() and (bq.gp_l.jitter == 0).all()
+    assert (bq.x_sc == x_sc).all() and not (bq.l_sc == l_sc).all()
+    assert (bq.gp_l.y == bq.l_sc).all()
+    params_tl = bq.gp_log_l.params
+    bq._set_gp_l_params(dict(h=0.3, w=1.4, s=0.01))
+    assert (bq.gp_log_l.params == params_tl).all() and (bq.gp_l.params != params_l).all()
+
+
+def test_llh_closure_failures_are_minus_inf(pkg):
+    npseed()
+    bq = make_bq(pkg)
+    f = bq._make_llh_params(["h", "w"])
+    assert np.isfinite(f(np.array([15.0, 2.0, 0.2, 1.3])))
+    assert f(None) == -np.inf
+    assert f(np.array([np.nan, 2.0, 0.2, 1.3])) == -np.inf
+    assert f(np.array([15.0, -2.0, 0.2, 1.3])) == -np.inf       # ValueError from set_param
+    assert f(np.array([15.0, 200.0, 0.2, 1.3])) == -np.inf      # singular Gram -> LinAlgError
+
+
+def test_fit_hypers(pkg):
+    npseed()
+    bq = make_bq(pkg)
+    llh = bq.gp_log_l.log_lh + bq.gp_l.log_lh
+    bq.fit_hypers(["h", "w"])
+    assert bq.gp_log_l.log_lh + bq.gp_l.log_lh >= llh
+
+
+def test_sample_hypers(pkg):
+    npseed()
+    bq = make_bq(pkg)
+    params = ["h", "w"]
+    before_tl = {p: bq.gp_log_l.get_param(p) for p in params}
+    before_l = {p: bq.gp_l.get_param(p) for p in params}
+    tl, l = bq.sample_hypers(params)
+    assert tl.shape == (1, 2) and l.shape == (1, 2)
+    assert np.isfinite(bq.gp_log_l.log_lh) and np.isfinite(bq.gp_l.log_lh)
+    for p in params:
+        assert bq.gp_log_l.get_param(p) != before_tl[p]
+        assert bq.gp_l.get_param(p) != before_l[p]
+    bq = make_bq(pkg, init=False)
+    bq.init(params_tl=(15, 2, 0), params_l=(0.00000002, 1.3, 0))
+    with pytest.raises(RuntimeError):
+        bq.sample_hypers(["w"])
+
+
+def test_marginalize_and_choose_next(pkg):
+    npseed()
+    bq = make_bq(pkg)
+    Z0 = bq.Z_mean()
+    values = bq.marginalize([bq.Z_mean, bq.Z_var], 6, ["h", "w"])
+    assert len(values) == 2 and values[0].shape == (6,) and values[1].shape == (6,)
+    assert bq.Z_mean() == Z0                    # state restored
+    x_a = np.random.uniform(-10, 10, 4)
+    loss = bq.marginalize([lambda: bq.expected_squared_mean(x_a)], 3, ["h", "w"])
+    assert loss[0].shape == (3, 4)
+    assert bq.choose_next(x_a, 3, ["h", "w"]) in x_a
+
+
+def test_out_of_scope_branches_raise(pkg):
+    x = np.linspace(-3, 3, 5)
+    bq = pkg.BQ(x, f_x(x), kernel=pkg.PeriodicKernel, **OPTIONS)
+    assert bq.options["use_approx"] and bq.options["wrapped"]
+    with pytest.raises(NotImplementedError):
+        bq.init(params_tl=(5, 6.0, 1, 0), params_l=(0.2, 1.5, 1, 0))

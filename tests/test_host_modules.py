@@ -1,0 +1,201 @@
+"""Host-side mirrors (linalg / gauss / bq_c / gp protocol) against the oracle, on the
+CPU through the engine double; the ``gpu`` parameter repeats them on the real engine."""
+import numpy as np
+import pytest
+
+from conftest import rand_spd
+
+
+@pytest.fixture(params=["double", pytest.param("gpu", marks=pytest.mark.gpu)])
+def pkg(request, oracle):
+    import bayesian_quadrature_amd as pkg
+    from bayesian_quadrature_amd import engine as eng_mod
+    saved = dict(eng_mod._engines)
+    eng_mod._engines.clear()
+    if request.param == "double":
+        from engine_double import EngineDouble
+        eng_mod.set_engine(EngineDouble(oracle), 0)
+    else:
+        from conftest import _have_gpu
+        if not _have_gpu():
+            pytest.skip("no HIP device")
+    yield pkg
+    eng_mod._engines.clear()
+    eng_mod._engines.update(saved)
+
+
+# ---- linalg: the reference's tests/test_linalg_c.py --------------------------------
+@pytest.mark.parametrize("n", [1, 2, 5, 10])
+def test_linalg_roundtrip(pkg, n):
+    la = pkg.la
+    rs = np.random.RandomState(n)
+    A = rand_spd(rs, n)
+    L = np.empty_like(A, order="F")
+    assert la.cho_factor(A, L) == 0
+    assert np.allclose(np.tril(L), np.linalg.cholesky(A))
+    A2 = A.copy(order="F")
+    la.cho_factor(A2, A2)
+    assert np.allclose(np.tril(A2), np.tril(L))
+    b, x = rs.rand(n), np.empty(n)
+    la.cho_solve_vec(L, b, x)
+    assert np.allclose(A.dot(x), b)
+    la.cho_solve_vec(L, b, b)
+    assert np.allclose(b, x)
+    B = np.asfortranarray(rs.rand(n, n))
+    X = np.empty_like(B, order="F")
+    la.cho_solve_mat(L, B, X)
+    assert np.allclose(A.dot(X), B)
+    assert np.allclose(la.logdet(L), np.linalg.slogdet(A)[1])
+    y = rs.rand(n)
+    assert np.allclose(la.dot11(x, y), x.dot(y))
+    out = np.empty(n)
+    la.dot12(x, B, out)
+    assert np.allclose(out, x.dot(B))
+    la.dot21(B, y, out)
+    assert np.allclose(out, B.dot(y))
+    XY = np.empty((n, n), order="F")
+    la.dot22(B, X, XY)
+    assert np.allclose(XY, B.dot(X))
+    assert np.allclose(la.vecdiff(x, y), np.linalg.norm(x - y))
+
+
+def test_linalg_argument_errors(pkg):
+    la = pkg.la
+    A = np.asfortranarray(np.eye(3))
+    with pytest.raises(ValueError):
+        la.cho_factor(np.ascontiguousarray(np.eye(3) * 2 + 1), A)     # C order
+    with pytest.raises(ValueError):
+        la.cho_factor(np.asfortranarray(np.ones((3, 2))), A)           # not square
+    with pytest.raises(ValueError):
+        la.cho_factor(A, np.empty((4, 4), order="F"))
+    with pytest.raises(ValueError):
+        la.cho_solve_vec(A, np.zeros(4), np.zeros(4))
+    with pytest.raises(ValueError):
+        la.cho_solve_mat(A, np.asfortranarray(np.zeros((3, 2))), np.asfortranarray(np.zeros((3, 2))))
+    with pytest.raises(ValueError):
+        la.dot11(np.zeros(3), np.zeros(4))
+    with pytest.raises(np.linalg.LinAlgError):
+        la.cho_factor(np.asfortranarray(np.array([[1.0, 2.0], [2.0, 1.0]])),
+                      np.empty((2, 2), order="F"))
+
+
+# ---- gauss / bq_c against the oracle restatement --------------------------------------
+MU, COV = np.array([0.3]), np.array([[10.0]], order="F")
+
+
+def test_gauss_closed_forms_1d(pkg, oracle):
+    ga = pkg.gauss
+    x = np.array(np.linspace(-4, 5, 11)[None], order="F")
+    x2 = np.array(np.linspace(-3, 3, 7)[None], order="F")
+    w1, w2 = np.array([1.3]), np.array([2.0])
+    out = np.empty(11)
+    ga.int_K(out, x, 0.2, w1, MU, COV)
+    assert np.allclose(out, oracle.int_K(x, 0.2, w1, MU, COV), rtol=1e-13)
+    out2 = np.empty((11, 7), order="F")
+    ga.int_K1_K2(out2, x, x2, 0.2, w1, 15.0, w2, MU, COV)
+    assert np.allclose(out2, oracle.int_K1_K2(x, x2, 0.2, w1, 15.0, w2, MU, COV), rtol=1e-12)
+    out3 = np.empty((11, 11), order="F")
+    ga.int_int_K1_K2_K1(out3, x, 0.2, w1, 15.0, w2, MU, COV)
+    assert np.allclose(out3, oracle.int_int_K1_K2_K1(x, 0.2, w1, 15.0, w2, MU, COV), rtol=1e-12)
+    ga.int_int_K1_K2(out, x, 0.2, w1, 15.0, w2, MU, COV)
+    assert np.allclose(out, oracle.int_int_K1_K2(x, 0.2, w1, 15.0, w2, MU, COV), rtol=1e-13)
+    assert np.allclose(ga.int_int_K(1, 0.2, w1, MU, COV), oracle.int_int_K(1, 0.2, w1, MU, COV),
+                       rtol=1e-14)
+    assert abs(ga.int_int_K(1, 0.2, np.array([1.3]), np.array([0.0]), COV)
+               - 0.00342641751296) < 1e-14                    # notebook cell 29
+    assert ga.int_exp_norm(2, 400, 1) == np.inf
+    assert np.allclose(ga.int_exp_norm(1.5, -0.3, 0.4), oracle.int_exp_norm(1.5, -0.3, 0.4))
+    L = np.array([[1.7]])
+    assert np.allclose(ga.mvn_logpdf(np.array([0.2]), np.array([-1.0]), L, np.log(1.7 ** 2)),
+                       oracle.mvn_logpdf([0.2], [-1.0], L, np.log(1.7 ** 2)))
+
+
+def test_gauss_closed_forms_2d(pkg, oracle):
+    ga = pkg.gauss
+    rs = np.random.RandomState(4)
+    x = np.asfortranarray(rs.uniform(-2, 2, (2, 9)))
+    x2 = np.asfortranarray(rs.uniform(-2, 2, (2, 5)))
+    w1, w2 = np.array([0.8, 1.1]), np.array([1.5, 0.6])
+    mu = np.array([0.1, -0.2])
+    cov = np.asfortranarray(np.array([[3.0, 0.4], [0.4, 2.0]]))
+    out = np.empty(9)
+    ga.int_K(out, x, 0.7, w1, mu, cov)
+    assert np.allclose(out, oracle.int_K(x, 0.7, w1, mu, cov), rtol=1e-12)
+    o2 = np.empty((9, 5), order="F")
+    ga.int_K1_K2(o2, x, x2, 0.7, w1, 1.2, w2, mu, cov)
+    assert np.allclose(o2, oracle.int_K1_K2(x, x2, 0.7, w1, 1.2, w2, mu, cov), rtol=1e-11)
+    o3 = np.empty((9, 9), order="F")
+    ga.int_int_K1_K2_K1(o3, x, 0.7, w1, 1.2, w2, mu, cov)
+    assert np.allclose(o3, oracle.int_int_K1_K2_K1(x, 0.7, w1, 1.2, w2, mu, cov), rtol=1e-11)
+    ga.int_int_K1_K2(out, x, 0.7, w1, 1.2, w2, mu, cov)
+    assert np.allclose(out, oracle.int_int_K1_K2(x, 0.7, w1, 1.2, w2, mu, cov), rtol=1e-12)
+    with pytest.raises(ValueError):
+        ga.int_K(np.empty(3), x, 0.7, w1, mu, cov)
+
+
+def test_bq_c_helpers(pkg, oracle):
+    bq_c = pkg.bq_c
+    rs = np.random.RandomState(9)
+    # filter_candidates: same NaN pattern and merged values as the oracle
+    for _ in range(5):
+        xc = rs.uniform(-7, 7, 12)
+        xs = np.linspace(-5, 5, 9)
+        a, b = xc.copy(), xc.copy()
+        bq_c.filter_candidates(a, xs, 0.5)
+        oracle.filter_candidates(b, xs, 0.5)
+        assert (np.isnan(a) == np.isnan(b)).all()
+        assert np.allclose(a[~np.isnan(a)], b[~np.isnan(b)], rtol=0, atol=0)
+    # jitter add / remove are inverse and in place (reference tests/test_bq_c.py:16-36)
+    M = rs.rand(6, 6)
+    M = M + M.T
+    M0 = M.copy()
+    jit = np.zeros(6)
+    idx = np.array([1, 4])
+    bq_c.improve_covariance_conditioning(M, jit, idx)
+    assert np.allclose(np.diag(M)[idx] - np.diag(M0)[idx], max(np.finfo(float).eps, M0.max()) * 1e-4)
+    assert (jit[idx] > 0).all() and (np.delete(jit, idx) == 0).all()
+    bq_c.remove_jitter(M, jit, idx)
+    assert np.allclose(M, M0) and (jit == 0).all()
+    p = np.empty(20)
+    x = np.array(np.linspace(-3, 3, 20)[None], order="F")
+    bq_c.p_x_gaussian(p, x, MU, COV)
+    assert np.allclose(p, oracle.p_x_gaussian(x, MU, COV), rtol=1e-13)
+
+
+def test_esm_vs_oracle(pkg, oracle):
+    rs = np.random.RandomState(2)
+    x_sca = np.array(np.sort(rs.uniform(-4, 4, 8))[None], order="F")
+    K = oracle.gram(x_sca, 0.4, [1.1], 0.0) + 1e-6 * np.eye(8)
+    L = oracle.cho_factor(K)
+    l_sc = rs.rand(7)
+    got = pkg.bq_c.expected_squared_mean_and_mean(l_sc, L, 0.3, 0.05, x_sca, 0.4, np.array([1.1]),
+                                                  MU, COV)
+    ref = oracle.esm_and_em(l_sc, L, 0.3, 0.05, x_sca, 0.4, [1.1], MU, COV)
+    assert np.allclose(got, ref, rtol=1e-10)
+
+
+# ---- gp protocol ("behavioural semantics") ---------------------------
+def test_gp_memoisation_protocol(pkg):
+    x = np.linspace(-3, 3, 12)
+    y = np.sin(x)
+    g = pkg.GP(pkg.GaussianKernel(1.0, 0.8), x, y, s=0.1)
+    K1 = g.Kxx
+    assert g.Kxx is K1                                   # reference tests/test_bq_c.py:43-49
+    L1, a1, lh1 = g.Lxx, g.inv_Kxx_y, g.log_lh
+    assert g.Lxx is L1 and g.inv_Kxx_y is a1
+    assert np.allclose(L1.dot(L1.T), K1) and np.allclose(K1.dot(a1), y)
+    assert (g.params == np.array([1.0, 0.8, 0.1])).all()
+    g.set_param("w", 0.9)                                # invalidates
+    assert g.Kxx is not K1 and g.log_lh != lh1
+    assert g.get_param("w") == 0.9 and g.K.w == 0.9
+    g.y = np.cos(x)                                      # invalidates
+    assert not np.allclose(g.inv_Kxx_y, a1)
+    with pytest.raises(ValueError):
+        g.set_param("w", -1.0)
+    with pytest.raises(ValueError):
+        g.set_param("h", np.nan)
+    assert g.mean(np.empty(0)).shape == (0,) and g.cov(np.empty(0)).shape == (0, 0)
+    xo = np.linspace(-3, 3, 5)
+    assert np.allclose(np.diag(g.cov(xo)), g.var(xo), atol=1e-12)
+    assert g.Kxoxo(xo).shape == (5, 5) and g.Kxxo(xo).shape == (12, 5)
+    assert g._x is g.x and g._y is g.y
