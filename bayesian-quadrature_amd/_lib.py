@@ -33,6 +33,7 @@ SIGNATURES = {
     "bq_device_info": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_size_t),
                                  C.POINTER(C.c_int)]),
     "bq_set_block": (C.c_int, [_vp, C.c_int]),
+    "bq_set_lookahead": (C.c_int, [_vp, C.c_int]),
     "bq_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "bq_dev_free": (C.c_int, [_vp, _vp]),
     "bq_upload": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -70,7 +71,11 @@ struct ProfEvent {
 
 struct bq_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr; // main stream: everything is ordered on it
+    hipStream_t aux = nullptr;    // high-priority panel stream of the look-ahead Cholesky
+    hipStream_t cur = nullptr;    // stream the launch helpers enqueue on (stream or aux)
+    hipEvent_t ev_panel = nullptr, ev_next = nullptr, ev_fork = nullptr;
+    int lookahead = 1;
     bool own_stream = false;
     int cus = 256;
     int nb_override = 0;
@@ -155,13 +160,13 @@ struct Bracket {
                 on = false;
                 return;
             }
-            (void)hipEventRecord(ev.a, c->stream);
+            (void)hipEventRecord(ev.a, c->cur);
         }
     }
     ~Bracket()
     {
         if (on) {
-            (void)hipEventRecord(ev.b, c->stream);
+            (void)hipEventRecord(ev.b, c->cur);
             c->prof_events.push_back(ev);
         }
     }
@@ -172,6 +177,8 @@ int prof_collect(bq_ctx *c)
     if (c->prof_events.empty())
         return BQ_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->aux)
+        HIPCHK(c, hipStreamSynchronize(c->aux));
     for (auto &e : c->prof_events) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
@@ -191,7 +198,7 @@ void launch_gram_sym_d(bq_ctx *c, const double *x, long xstride, const GaussPara
                        int gpstride, double *K, long ldk, long kstride, int n, int batch)
 {
     dim3 grid((n + 127) / 128, (n + 63) / 64, batch);
-    hipLaunchKernelGGL(gram_sym_kernel<D>, grid, dim3(256), 0, c->stream, x, xstride, gp, gpstride,
+    hipLaunchKernelGGL(gram_sym_kernel<D>, grid, dim3(256), 0, c->cur, x, xstride, gp, gpstride,
                        K, ldk, kstride, n);
 }
 
@@ -219,7 +226,7 @@ void launch_gram_cross_d(bq_ctx *c, const double *x1, int n1, const double *x2, 
                          const GaussParams &g, double *K, long ldk)
 {
     dim3 grid((n1 + 63) / 64, (n2 + 63) / 64, 1);
-    hipLaunchKernelGGL(gram_cross_kernel<D>, grid, dim3(256), 0, c->stream, x1, n1, x2, n2, g, K,
+    hipLaunchKernelGGL(gram_cross_kernel<D>, grid, dim3(256), 0, c->cur, x1, n1, x2, n2, g, K,
                        ldk);
 }
 
@@ -250,7 +257,7 @@ void launch_assemble_d(bq_ctx *c, const double *pts, long pstride, const double 
                        Layout L, int batch)
 {
     dim3 grid((L.ntot + 127) / 128, (L.ntot + 63) / 64, batch);
-    hipLaunchKernelGGL(assemble_kernel<D>, grid, dim3(256), 0, c->stream, pts, pstride, y, ystride,
+    hipLaunchKernelGGL(assemble_kernel<D>, grid, dim3(256), 0, c->cur, pts, pstride, y, ystride,
                        gp, gpstride, A, lda, astride, L);
 }
 
@@ -291,16 +298,24 @@ int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const dou
     const long cu = c->cus;
     if (tiles(128) >= cu) {
         dim3 grid((m + 127) / 128, (n + 127) / 128, batch);
-        hipLaunchKernelGGL((gemm_sub_kernel<4, 4>), grid, dim3(256), 0, c->stream, C, ldc, cstride,
+        hipLaunchKernelGGL((gemm_sub_kernel<4, 4>), grid, dim3(256), 0, c->cur, C, ldc, cstride,
                            P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, lower);
     } else if (tiles(64) >= cu / 2) {
         dim3 grid((m + 63) / 64, (n + 63) / 64, batch);
-        hipLaunchKernelGGL((gemm_sub_kernel<2, 2>), grid, dim3(256), 0, c->stream, C, ldc, cstride,
-                           P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, lower);
+        if (k == 64)
+            hipLaunchKernelGGL((gemm_k64_kernel<2, 2>), grid, dim3(256), 0, c->cur, C, ldc,
+                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, lower);
+        else
+            hipLaunchKernelGGL((gemm_sub_kernel<2, 2>), grid, dim3(256), 0, c->cur, C, ldc,
+                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, lower);
     } else {
         dim3 grid((m + 31) / 32, (n + 31) / 32, batch);
-        hipLaunchKernelGGL((gemm_sub_kernel<1, 1>), grid, dim3(256), 0, c->stream, C, ldc, cstride,
-                           P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, lower);
+        if (k == 64)
+            hipLaunchKernelGGL((gemm_k64_kernel<1, 1>), grid, dim3(256), 0, c->cur, C, ldc,
+                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, lower);
+        else
+            hipLaunchKernelGGL((gemm_sub_kernel<1, 1>), grid, dim3(256), 0, c->cur, C, ldc,
+                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, lower);
     }
     HIPCHK(c, hipGetLastError());
     return BQ_OK;
@@ -310,7 +325,7 @@ int launch_potf2(bq_ctx *c, double *A, long lda, long astride, int j0, double *d
                  int *info, int batch)
 {
     Bracket br(c, BQ_K_POTF2);
-    hipLaunchKernelGGL(potf2_64_kernel, dim3(1, 1, batch), dim3(64), 0, c->stream, A, lda, astride,
+    hipLaunchKernelGGL(potf2_64_kernel, dim3(1, 1, batch), dim3(64), 0, c->cur, A, lda, astride,
                        j0, dinv, dstride, info);
     HIPCHK(c, hipGetLastError());
     return BQ_OK;
@@ -323,53 +338,120 @@ int launch_trsm(bq_ctx *c, double *X, long ldx, long xstride, int m, const doubl
     if (m <= 0)
         return BQ_OK;
     Bracket br(c, BQ_K_TRSM);
-    hipLaunchKernelGGL(trsm_rows_kernel<TRANS>, dim3((m + 63) / 64, 1, batch), dim3(64), 0,
-                       c->stream, X, ldx, xstride, m, L11, ldl, lstride, dinv, dstride);
+    // short panels: four lanes per row (latency); long ones: a row per lane (throughput)
+    if ((long)((m + 15) / 16) * batch <= 4L * c->cus)
+        hipLaunchKernelGGL(trsm_quad_kernel<TRANS>, dim3((m + 15) / 16, 1, batch), dim3(64), 0,
+                           c->cur, X, ldx, xstride, m, L11, ldl, lstride, dinv, dstride);
+    else
+        hipLaunchKernelGGL(trsm_rows_kernel<TRANS>, dim3((m + 63) / 64, 1, batch), dim3(64), 0,
+                           c->cur, X, ldx, xstride, m, L11, ldl, lstride, dinv, dstride);
     HIPCHK(c, hipGetLastError());
     return BQ_OK;
 }
 
-int auto_nb(const bq_ctx *c, int ntot)
+int auto_nb(const bq_ctx *c, int ntot, int batch)
 {
     if (c->nb_override > 0)
         return c->nb_override;
-    if (ntot >= 8192)
+    // the trailing update re-reads and re-writes the whole remaining matrix once per
+    // outer block: when the batch's matrices do not fit the caches the outer block
+    // must be wide (256: 46 GB instead of 183 GB of traffic at N=16384), when they do
+    // a narrow block means fewer, shorter launches
+    const double mb = 8.0 * (double)ntot * ntot * batch / 1e6;
+    if (ntot >= 1024 && mb >= 100.0)
         return 256;
-    if (ntot >= 3072)
+    if (ntot >= 512 && mb >= 30.0)
         return 128;
     return 64;
 }
 
+// the 64-column slabs of one outer block [K0, K0+KB): left-looking update, diagonal
+// factor, panel solve -- enqueued on c->cur
+int enqueue_panel(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot, int K0,
+                  int KB, double *dinv, int *info)
+{
+    for (int j0 = K0; j0 < K0 + KB; j0 += 64) {
+        double *Ajj = A + j0 + (long)j0 * lda;
+        if (j0 > K0)
+            BQCHK(launch_gemm(c, BQ_K_GEMM, Ajj, lda, astride, A + j0 + (long)K0 * lda, lda,
+                              astride, A + j0 + (long)K0 * lda, 1, lda, astride, ntot - j0, 64,
+                              j0 - K0, 0, batch));
+        BQCHK(launch_potf2(c, A, lda, astride, j0, dinv, 64, info, batch));
+        BQCHK(launch_trsm<true>(c, Ajj + 64, lda, astride, ntot - j0 - 64, Ajj, lda, astride, dinv,
+                                64, batch));
+    }
+    return BQ_OK;
+}
+
 // Eliminate the first ncols columns (multiple of 64) of the ntot x ntot lower
 // matrix (ntot multiple of 64), batched.  dinv: 64 doubles per problem.
+//
+// With more than one outer block and a wide block the factorisation runs with a
+// look-ahead of one panel on two streams: after panel k, the trailing update is
+// split into the columns of panel k+1 (main stream, first) and the rest (main
+// stream); panel k+1 is factored on the high-priority aux stream as soon as its
+// columns are updated, i.e. concurrently with the bulk of trailing update k.
 int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
                           int ncols, double *dinv, int *info)
 {
     if ((ntot & 63) || (ncols & 63) || ncols > ntot)
         return fail(c, BQ_ERR_BAD_ARG, "potrf: sizes must be multiples of 64");
-    const int NB = auto_nb(c, ntot);
-    for (int K0 = 0; K0 < ncols; K0 += NB) {
-        const int KB = std::min(NB, ncols - K0);
-        for (int j0 = K0; j0 < K0 + KB; j0 += 64) {
-            double *Ajj = A + j0 + (long)j0 * lda;
-            if (j0 > K0) {
-                // left-looking update of this 64-column slab by the panel so far
-                BQCHK(launch_gemm(c, BQ_K_GEMM, Ajj, lda, astride, A + j0 + (long)K0 * lda, lda,
-                                  astride, A + j0 + (long)K0 * lda, 1, lda, astride, ntot - j0, 64,
-                                  j0 - K0, 0, batch));
+    const int NB = auto_nb(c, ntot, batch);
+    const bool la = c->lookahead && c->aux && NB >= 128 && ncols > NB;
+    if (!la) {
+        for (int K0 = 0; K0 < ncols; K0 += NB) {
+            const int KB = std::min(NB, ncols - K0);
+            BQCHK(enqueue_panel(c, A, lda, astride, batch, ntot, K0, KB, dinv, info));
+            const int r0 = K0 + KB;
+            if (r0 < ntot) {
+                const double *P = A + r0 + (long)K0 * lda;
+                BQCHK(launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda,
+                                  astride, P, 1, lda, astride, ntot - r0, ntot - r0, KB, 1,
+                                  batch));
             }
-            BQCHK(launch_potf2(c, A, lda, astride, j0, dinv, 64, info, batch));
-            BQCHK(launch_trsm<true>(c, Ajj + 64, lda, astride, ntot - j0 - 64, Ajj, lda, astride,
-                                    dinv, 64, batch));
         }
+        return BQ_OK;
+    }
+    // fork: the aux stream starts after everything already queued on the main stream
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+    int st = BQ_OK;
+    for (int K0 = 0; K0 < ncols && st == BQ_OK; K0 += NB) {
+        const int KB = std::min(NB, ncols - K0);
+        c->cur = c->aux;
+        st = enqueue_panel(c, A, lda, astride, batch, ntot, K0, KB, dinv, info);
+        c->cur = c->stream;
+        if (st != BQ_OK)
+            break;
+        HIPCHK(c, hipEventRecord(c->ev_panel, c->aux));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_panel, 0));
         const int r0 = K0 + KB;
-        if (r0 < ntot) {
-            const double *P = A + r0 + (long)K0 * lda;
-            BQCHK(launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda, astride,
-                              P, 1, lda, astride, ntot - r0, ntot - r0, KB, 1, batch));
+        if (r0 >= ntot)
+            break;
+        const double *P = A + r0 + (long)K0 * lda;
+        const int nw = (r0 < ncols) ? std::min(NB, ncols - r0) : 0; // width of the next panel
+        if (nw > 0) {
+            // columns of the next panel first ...
+            st = launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda, astride,
+                             P, 1, lda, astride, ntot - r0, nw, KB, 1, batch);
+            if (st != BQ_OK)
+                break;
+            HIPCHK(c, hipEventRecord(c->ev_next, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_next, 0));
+            // ... then the rest, overlapping the next panel's factorisation
+            const int r1 = r0 + nw;
+            if (r1 < ntot) {
+                const double *P1 = A + r1 + (long)K0 * lda;
+                st = launch_gemm(c, BQ_K_SYRK, A + r1 + (long)r1 * lda, lda, astride, P1, lda,
+                                 astride, P1, 1, lda, astride, ntot - r1, ntot - r1, KB, 1, batch);
+            }
+        } else {
+            st = launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda, astride,
+                             P, 1, lda, astride, ntot - r0, ntot - r0, KB, 1, batch);
         }
     }
-    return BQ_OK;
+    c->cur = c->stream;
+    return st;
 }
 
 // X (mrows x npad, ld ldx) <- X L^-T, L resident (npad x npad, ld ldl), dinv[npad]
@@ -452,6 +534,14 @@ static int ctx_init(bq_ctx *c, int device)
     c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(c, hipEventCreate(&c->t0));
     HIPCHK(c, hipEventCreate(&c->t1));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_next, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    int lo = 0, hi = 0;
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(c, hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, hi));
+    if (const char *e = std::getenv("BQ_LOOKAHEAD"))
+        c->lookahead = std::atoi(e);
     return BQ_OK;
 }
 
@@ -469,6 +559,7 @@ extern "C" int bq_ctx_create(int device, bq_ctx **out)
         if (e != hipSuccess)
             st = fail(c, BQ_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
         c->own_stream = true;
+        c->cur = c->stream;
     }
     if (st != BQ_OK) {
         fprintf(stderr, "bq_ctx_create: %s\n", c->err);
@@ -493,6 +584,7 @@ extern "C" int bq_ctx_create_on_stream(int device, void *hip_stream, bq_ctx **ou
         return st;
     }
     c->stream = static_cast<hipStream_t>(hip_stream);
+    c->cur = c->stream;
     c->own_stream = false;
     *out = c;
     return BQ_OK;
@@ -512,6 +604,13 @@ extern "C" void bq_ctx_destroy(bq_ctx *c)
         (void)hipEventDestroy(c->t0);
     if (c->t1)
         (void)hipEventDestroy(c->t1);
+    for (hipEvent_t e : {c->ev_panel, c->ev_next, c->ev_fork})
+        if (e)
+            (void)hipEventDestroy(e);
+    if (c->aux) {
+        (void)hipStreamSynchronize(c->aux);
+        (void)hipStreamDestroy(c->aux);
+    }
     if (c->own_stream && c->stream)
         (void)hipStreamDestroy(c->stream);
     delete c;
@@ -550,6 +649,14 @@ extern "C" int bq_set_block(bq_ctx *c, int nb)
     if (!c || nb < 0 || (nb & 63))
         return c ? fail(c, BQ_ERR_BAD_ARG, "block must be a multiple of 64") : BQ_ERR_BAD_ARG;
     c->nb_override = nb;
+    return BQ_OK;
+}
+
+extern "C" int bq_set_lookahead(bq_ctx *c, int on)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    c->lookahead = on ? 1 : 0;
     return BQ_OK;
 }
 

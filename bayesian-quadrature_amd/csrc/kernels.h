@@ -255,6 +255,9 @@ __global__ __launch_bounds__(64) void potf2_64_kernel(double *__restrict__ A, lo
                                                       int *__restrict__ info)
 {
     __shared__ __attribute__((aligned(16))) double col[2][64];
+    // the panel is the critical path; under look-ahead it shares SIMDs with the
+    // trailing update's MFMA waves and should win instruction issue
+    __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.z;
     double *Ab = A + (long)b * astride + j0 + (long)j0 * lda;
     const int lane = threadIdx.x;
@@ -344,6 +347,7 @@ __global__ __launch_bounds__(64) void trsm_rows_kernel(double *__restrict__ X, l
     // T[p][j]: multiplier of x_p in the update of x_j, rows of 64 doubles
     __shared__ __attribute__((aligned(16))) double T[64 * 64];
     __shared__ __attribute__((aligned(16))) double di[64];
+    __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.z;
     const int lane = threadIdx.x;
     const int row = blockIdx.x * 64 + lane;
@@ -444,6 +448,159 @@ __global__ __launch_bounds__(64) void trsm_rows_kernel(double *__restrict__ X, l
         for (int j = 0; j < 64; ++j) {
             *pw = x[j];
             pw += ldx;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Panel solve, FOUR lanes per row (a wave = 16 rows): the latency-oriented
+// variant used when the panel is short (few rows per CU).  Lane l works on row
+// l>>2 and on the 16 columns {8kk + 2g, 8kk + 2g + 1}, g = l&3, kk = 0..7, so a
+// column step costs each lane at most 16 FMAs instead of 63; the solved entry
+// x_p is handed to the other three lanes of the quad by DPP quad_perm.  The
+// multipliers come from an LDS copy of L11 whose inapplicable entries (j <= p,
+// or j >= p for the backward form) are stored as zeros, so the update needs no
+// per-lane predicate; lanes with equal g read the same address (broadcast).
+// ---------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ double quad_bcast_f64(double v)
+{
+    constexpr int ctrl = G | (G << 2) | (G << 4) | (G << 6); // quad_perm:[G,G,G,G]
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <bool TRANS, int P>
+__device__ __forceinline__ void trsm_quad_step(double (&x)[8][2], const double *T, const double *di,
+                                               int g, double2_t (&cur)[8], double2_t (&nxt)[8])
+{
+    constexpr int KK = P >> 3, GP = (P >> 1) & 3, SL = P & 1;
+    constexpr int PN = TRANS ? P + 1 : P - 1; // next column step
+    if (PN >= 0 && PN < 64) {
+        const double2_t *t2 = reinterpret_cast<const double2_t *>(T + PN * 64);
+        if (TRANS) {
+#pragma unroll
+            for (int kk = (PN >> 3); kk < 8; ++kk)
+                nxt[kk] = t2[4 * kk + g];
+        } else {
+#pragma unroll
+            for (int kk = 0; kk <= (PN >> 3); ++kk)
+                nxt[kk] = t2[4 * kk + g];
+        }
+    }
+    const double mine = x[KK][SL] * di[P];
+    const double xp = quad_bcast_f64<GP>(mine);
+    x[KK][SL] = (g == GP) ? xp : x[KK][SL];
+    if (TRANS) {
+#pragma unroll
+        for (int kk = KK; kk < 8; ++kk) {
+            x[kk][0] -= cur[kk][0] * xp;
+            x[kk][1] -= cur[kk][1] * xp;
+        }
+#pragma unroll
+        for (int kk = KK; kk < 8; ++kk) {
+            PIN(x[kk][0]);
+            PIN(x[kk][1]);
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk <= KK; ++kk) {
+            x[kk][0] -= cur[kk][0] * xp;
+            x[kk][1] -= cur[kk][1] * xp;
+        }
+#pragma unroll
+        for (int kk = 0; kk <= KK; ++kk) {
+            PIN(x[kk][0]);
+            PIN(x[kk][1]);
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+        cur[kk] = nxt[kk];
+}
+
+template <bool TRANS, int P>
+struct TrsmQuadSteps {
+    static __device__ __forceinline__ void run(double (&x)[8][2], const double *T, const double *di,
+                                               int g, double2_t (&cur)[8], double2_t (&nxt)[8])
+    {
+        trsm_quad_step<TRANS, TRANS ? P : 63 - P>(x, T, di, g, cur, nxt);
+        TrsmQuadSteps<TRANS, P + 1>::run(x, T, di, g, cur, nxt);
+    }
+};
+template <bool TRANS>
+struct TrsmQuadSteps<TRANS, 64> {
+    static __device__ __forceinline__ void run(double (&)[8][2], const double *, const double *, int,
+                                               double2_t (&)[8], double2_t (&)[8])
+    {
+    }
+};
+
+template <bool TRANS>
+__global__ __launch_bounds__(64) void trsm_quad_kernel(double *__restrict__ X, long ldx,
+                                                       long xstride, int m,
+                                                       const double *__restrict__ Lm, long ldl,
+                                                       long lstride,
+                                                       const double *__restrict__ dinv,
+                                                       long dstride)
+{
+    __shared__ __attribute__((aligned(16))) double T[64 * 64];
+    __shared__ __attribute__((aligned(16))) double di[64];
+    __builtin_amdgcn_s_setprio(3);
+    const int b = blockIdx.z;
+    const int lane = threadIdx.x;
+    const int g = lane & 3;
+    const int row = blockIdx.x * 16 + (lane >> 2);
+    X += (long)b * xstride;
+    const double *L11 = Lm + (long)b * lstride;
+    if (TRANS) {
+        // T[p][j] = L11[j][p] for j > p, else 0
+#pragma unroll 8
+        for (int p = 0; p < 64; ++p) {
+            const double v = L11[lane + (long)p * ldl];
+            T[p * 64 + lane] = (lane > p) ? v : 0.0;
+        }
+    } else {
+        // T[p][j] = L11[p][j] for j < p, else 0 (lane = p: coalesced global read)
+#pragma unroll 8
+        for (int j = 0; j < 64; ++j) {
+            const double v = L11[lane + (long)j * ldl];
+            T[lane * 64 + j] = (j < lane) ? v : 0.0;
+        }
+    }
+    di[lane] = dinv[(long)b * dstride + lane];
+    const bool ok = row < m;
+    double x[8][2];
+    {
+        const double *pr = X + (ok ? row : 0) + (long)(2 * g) * ldx;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            x[kk][0] = pr[0];
+            x[kk][1] = pr[ldx];
+            pr += 8 * ldx;
+        }
+    }
+    __syncthreads();
+    double2_t cur[8], nxt[8];
+    {
+        const double2_t *t2 = reinterpret_cast<const double2_t *>(T + (TRANS ? 0 : 63) * 64);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            cur[kk] = t2[4 * kk + g];
+            nxt[kk] = cur[kk];
+        }
+    }
+    TrsmQuadSteps<TRANS, 0>::run(x, T, di, g, cur, nxt);
+    if (ok) {
+        double *pw = X + row + (long)(2 * g) * ldx;
+        asm volatile("" : "+v"(pw));
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            pw[0] = x[kk][0];
+            pw[ldx] = x[kk][1];
+            pw += 8 * ldx;
         }
     }
 }
@@ -584,6 +741,102 @@ __global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C
                 double *dst = C + (r + l15) + (long)(c + l4 + 4 * rr) * ldc;
                 *dst -= acc[tm][tn][rr];
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The same product for k == 64 exactly (the trailing / panel update of small
+// systems, outer block 64): all 16 k-steps of fragments are requested up front
+// and the MFMAs drain them as they land, so a tile costs one memory round trip
+// instead of sixteen.  TM, TN <= 2.
+// ---------------------------------------------------------------------------
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_k64_kernel(double *__restrict__ C, long ldc,
+                                                       long cstride, const double *__restrict__ P,
+                                                       long ldp, long pstride,
+                                                       const double *__restrict__ Q, long qsj,
+                                                       long qsk, long qstride, int m, int n,
+                                                       int lower)
+{
+    const int b = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 2 + (wave & 1)) * (TM * 16);
+    const int col0 = (blockIdx.y * 2 + (wave >> 1)) * (TN * 16);
+    if (row0 >= m || col0 >= n)
+        return;
+    if (lower && col0 >= row0 + TM * 16)
+        return;
+    C += (long)b * cstride;
+    P += (long)b * pstride;
+    Q += (long)b * qstride;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double pa[16][TM], qa[16][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        int r = row0 + tm * 16;
+        if (r >= m)
+            r = row0;
+        const double *pp = P + r + l15 + (long)l4 * ldp;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+            pa[ks][tm] = pp[(long)ks * 4 * ldp];
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        int c = col0 + tn * 16;
+        if (c >= n)
+            c = col0;
+        const double *qq = Q + (long)(c + l15) * qsj + (long)l4 * qsk;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+            qa[ks][tn] = qq[(long)ks * 4 * qsk];
+    }
+    // C is read while the fragments are in flight
+    double cold[TM][TN][4];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                int r = row0 + tm * 16, c = col0 + tn * 16;
+                if (r >= m) r = row0;
+                if (c >= n) c = col0;
+                cold[tm][tn][rr] = C[(r + l15) + (long)(c + l4 + 4 * rr) * ldc];
+            }
+    // every load above is issued before the first MFMA (the scheduler otherwise
+    // interleaves them to save registers and serialises the round trips)
+    __builtin_amdgcn_sched_barrier(0);
+    double4_t acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[ks][tn], pa[ks][tm],
+                                                                   acc[tm][tn], 0, 0, 0);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int r = row0 + tm * 16;
+        if (r >= m)
+            continue;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int c = col0 + tn * 16;
+            if (c >= n)
+                continue;
+            if (lower && c >= r + 16)
+                continue;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                C[(r + l15) + (long)(c + l4 + 4 * rr) * ldc] = cold[tm][tn][rr] - acc[tm][tn][rr];
         }
     }
 }

@@ -93,6 +93,9 @@ class Engine(object):
     def set_block(self, nb):
         self._check(self._lib.bq_set_block(self._ctx, int(nb)))
 
+    def set_lookahead(self, on):
+        self._check(self._lib.bq_set_lookahead(self._ctx, 1 if on else 0))
+
     # -- raw device memory -------------------------------------------------
     def alloc(self, nbytes):
         p = C.c_void_p()

@@ -134,10 +134,16 @@ def class_work(n, M, nb_outer):
     return w, ntot
 
 
-def auto_nb(ntot, override):
+def auto_nb(ntot, override, batch=1):
+    """Mirror of auto_nb() in csrc/bqhip.hip (outer Cholesky block)."""
     if override:
         return override
-    return 256 if ntot >= 8192 else (128 if ntot >= 3072 else 64)
+    mb = 8.0 * ntot * ntot * batch / 1e6
+    if ntot >= 1024 and mb >= 100.0:
+        return 256
+    if ntot >= 512 and mb >= 30.0:
+        return 128
+    return 64
 
 
 def run_main(eng, wk, steps, warmup, dist):
@@ -255,35 +261,58 @@ def extras(eng, nb_override):
             # ---- C4: potrf on the matrix just built ------------------------------
             info = eng.alloc(64)
             nb = auto_nb(n, nb_override)
-            times = []
-            for rep in range(3):
-                eng._check(lib.bq_gram_gauss_dev(ctx, xd, d, n, h, L_.dptr(w), s, Kd, n))
-                eng.sync()
-                eng.timer_start()
-                eng._check(lib.bq_potrf_dev(ctx, Kd, n, n, info))
-                times.append(eng.timer_stop_ms())
-            hinfo = np.zeros(1, dtype=np.int32)
-            eng.download(hinfo, info)
-            # instrumented pass for the trailing-update share
-            eng._check(lib.bq_gram_gauss_dev(ctx, xd, d, n, h, L_.dptr(w), s, Kd, n))
-            eng.profile(True)
-            eng.profile_reset()
-            eng._check(lib.bq_potrf_dev(ctx, Kd, n, n, info))
-            prof = eng.profile_read()
-            eng.profile(False)
-            best = min(times[1:])
             tfl = wl.trailing_flops(n, nb)
-            sy = prof["syrk_trailing"]
+
+            def potrf_runs(reps):
+                ts = []
+                for rep in range(reps):
+                    eng._check(lib.bq_gram_gauss_dev(ctx, xd, d, n, h, L_.dptr(w), s, Kd, n))
+                    eng.sync()
+                    eng.timer_start()
+                    eng._check(lib.bq_potrf_dev(ctx, Kd, n, n, info))
+                    ts.append(eng.timer_stop_ms())
+                return ts
+
+            def potrf_profile():
+                eng._check(lib.bq_gram_gauss_dev(ctx, xd, d, n, h, L_.dptr(w), s, Kd, n))
+                eng.profile(True)
+                eng.profile_reset()
+                eng._check(lib.bq_potrf_dev(ctx, Kd, n, n, info))
+                pr = eng.profile_read()
+                eng.profile(False)
+                return pr
+
+            hinfo = np.zeros(1, dtype=np.int32)
+            # (1) the pipeline as shipped: look-ahead on two streams
+            eng.set_lookahead(True)
+            t_la = potrf_runs(3)
+            eng.download(hinfo, info)
+            prof_la = potrf_profile()
+            # (2) strictly sequential launches: the kernels timed in isolation
+            eng.set_lookahead(False)
+            t_seq = potrf_runs(3)
+            prof = potrf_profile()
+            eng.set_lookahead(True)
+            best = min(t_la[1:])
+            sy, sy_la = prof["syrk_trailing"], prof_la["syrk_trailing"]
             out["potrf_n16384"] = {
                 "ms": best, "gflops": wl.potrf_flops(n) / (best * 1e-3) / 1e9, "nb": nb,
-                "info": int(hinfo[0]), "all_ms": times, "class_ms": {k: v["ms"] for k, v in prof.items()},
-                "class_launches": {k: v["launches"] for k, v in prof.items()}}
+                "info": int(hinfo[0]), "lookahead_ms": t_la, "sequential_ms": t_seq,
+                "sequential_gflops": wl.potrf_flops(n) / (min(t_seq[1:]) * 1e-3) / 1e9,
+                "class_ms_sequential": {k: v["ms"] for k, v in prof.items()},
+                "class_ms_lookahead": {k: v["ms"] for k, v in prof_la.items()},
+                "class_launches_sequential": {k: v["launches"] for k, v in prof.items()}}
             out["trailing_update_n16384"] = {
-                "kernel": "gemm_sub_kernel<4,4> (trailing SYRK)", "bound": "mfma",
+                "kernel": "gemm_sub_kernel<4,4> (trailing SYRK), sequential launches",
+                "bound": "mfma",
                 "achieved": tfl / (sy["ms"] * 1e-3) / 1e12, "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s", "frac": tfl / (sy["ms"] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
                 "traffic": None, "algorithmic_flops": tfl, "launches": sy["launches"],
-                "ms_total": sy["ms"], "ms_per_launch": sy["ms"] / max(1, sy["launches"])}
+                "ms_total": sy["ms"], "ms_per_launch": sy["ms"] / max(1, sy["launches"]),
+                "in_lookahead_pipeline": {
+                    "ms_total": sy_la["ms"], "launches": sy_la["launches"],
+                    "achieved": tfl / (sy_la["ms"] * 1e-3) / 1e12,
+                    "note": "same flops while panel kernels of the next block share the GPU"}}
             eng.free(info)
         eng.free(xd)
         eng.free(Kd)
@@ -314,7 +343,7 @@ def main():
     if dist.rank == 0:
         info = eng.info()
         work, ntot = class_work(wk["n"], wk["M"], auto_nb(
-            -(-(-(-wk["n"] // 64) * 64 + wk["M"] + 1) // 64) * 64, a.nb))
+            -(-(-(-wk["n"] // 64) * 64 + wk["M"] + 1) // 64) * 64, a.nb, wk["B"]))
         prof = res["prof"]
         dom = max(prof, key=lambda k: prof[k]["ms"])
         dom_ms = prof[dom]["ms"]

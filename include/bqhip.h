@@ -60,6 +60,9 @@ const char *bq_last_error(const bq_ctx *ctx);
 int bq_device_info(bq_ctx *ctx, char *name, int *cus, size_t *hbm_bytes, int *clock_khz);
 /* outer Cholesky block (multiple of 64; 0 = automatic from the size) */
 int bq_set_block(bq_ctx *ctx, int nb);
+/* look-ahead of one panel on a second, high-priority stream (default on; the
+ * environment variable BQ_LOOKAHEAD=0 also disables it) */
+int bq_set_lookahead(bq_ctx *ctx, int on);
 
 /* ---- device memory -------------------------------------------------- */
 int bq_dev_alloc(bq_ctx *ctx, size_t bytes, void **dptr);
