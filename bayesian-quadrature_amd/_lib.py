@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(_HERE, "libbqhip.so")
 
 BQ_OK, BQ_ERR_NOT_PD, BQ_ERR_BAD_ARG, BQ_ERR_HIP, BQ_ERR_NOMEM = 0, 1, 2, 3, 4
 BQ_MAX_DIM = 8
-K_CLASSES = ("gram", "potf2", "trsm", "gemm_panel", "syrk_trailing", "reduce")
+K_CLASSES = ("gram", "potf2", "trsm", "gemm_panel", "syrk_trailing", "syrk_trailing_small",
+             "reduce")
 
 _dp = C.POINTER(C.c_double)
 _i32p = C.POINTER(C.c_int32)
@@ -43,7 +44,7 @@ SIGNATURES = {
     "bq_timer_stop_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "bq_profile_enable": (C.c_int, [_vp, C.c_int]),
     "bq_profile_reset": (C.c_int, [_vp]),
-    "bq_profile_read": (C.c_int, [_vp, _dp, _i64p]),
+    "bq_profile_read": (C.c_int, [_vp, _dp, _i64p, _dp]),
     "bq_cho_factor": (C.c_int, [_vp, _dp, _dp, _i64, _i64p]),
     "bq_cho_solve": (C.c_int, [_vp, _dp, _dp, _dp, _i64, _i64]),
     "bq_logdet": (C.c_int, [_vp, _dp, _i64, _dp]),

@@ -65,6 +65,7 @@ struct DevBuf {
 struct ProfEvent {
     hipEvent_t a, b;
     int cls;
+    double work;
 };
 
 } // namespace
@@ -85,6 +86,7 @@ struct bq_ctx {
     std::vector<ProfEvent> prof_events;
     double prof_ms[BQ_K_NCLASS] = {0};
     int64_t prof_n[BQ_K_NCLASS] = {0};
+    double prof_work[BQ_K_NCLASS] = {0};
     DevBuf gbuf;   // GaussParams of the single-problem entry points (cached)
     GaussParams gbuf_host{};
     bool gbuf_valid = false;
@@ -152,10 +154,11 @@ struct Bracket {
     bq_ctx *c;
     ProfEvent ev;
     bool on;
-    Bracket(bq_ctx *ctx, int cls) : c(ctx), on(ctx->prof)
+    Bracket(bq_ctx *ctx, int cls, double work = 0.0) : c(ctx), on(ctx->prof)
     {
         if (on) {
             ev.cls = cls;
+            ev.work = work;
             if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) {
                 on = false;
                 return;
@@ -184,6 +187,7 @@ int prof_collect(bq_ctx *c)
         if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
             c->prof_ms[e.cls] += ms;
             c->prof_n[e.cls] += 1;
+            c->prof_work[e.cls] += e.work;
         }
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -205,7 +209,7 @@ void launch_gram_sym_d(bq_ctx *c, const double *x, long xstride, const GaussPara
 int launch_gram_sym(bq_ctx *c, int d, const double *x, long xstride, const GaussParams *gp,
                     int gpstride, double *K, long ldk, long kstride, int n, int batch)
 {
-    Bracket br(c, BQ_K_GRAM);
+    Bracket br(c, BQ_K_GRAM, (8.0 * n * n + 8.0 * d * n) * batch);
     switch (d) {
     case 1: launch_gram_sym_d<1>(c, x, xstride, gp, gpstride, K, ldk, kstride, n, batch); break;
     case 2: launch_gram_sym_d<2>(c, x, xstride, gp, gpstride, K, ldk, kstride, n, batch); break;
@@ -235,7 +239,7 @@ int launch_gram_cross(bq_ctx *c, int d, const double *x1, int n1, const double *
 {
     if (n1 <= 0 || n2 <= 0)
         return BQ_OK;
-    Bracket br(c, BQ_K_GRAM);
+    Bracket br(c, BQ_K_GRAM, 8.0 * n1 * n2);
     switch (d) {
     case 1: launch_gram_cross_d<1>(c, x1, n1, x2, n2, g, K, ldk); break;
     case 2: launch_gram_cross_d<2>(c, x1, n1, x2, n2, g, K, ldk); break;
@@ -265,7 +269,7 @@ int launch_assemble(bq_ctx *c, int d, const double *pts, long pstride, const dou
                     long ystride, const GaussParams *gp, int gpstride, double *A, long lda,
                     long astride, Layout L, int batch)
 {
-    Bracket br(c, BQ_K_GRAM);
+    Bracket br(c, BQ_K_GRAM, 8.0 * L.ntot * (L.ntot + 1.0) / 2.0 * batch);
     switch (d) {
     case 1: launch_assemble_d<1>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch); break;
     case 2: launch_assemble_d<2>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch); break;
@@ -290,11 +294,17 @@ int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const dou
         return BQ_OK;
     if ((m & 15) || (n & 15) || (k & 7))
         return fail(c, BQ_ERR_BAD_ARG, "gemm: m,n must be multiples of 16 and k of 8");
-    Bracket br(c, cls);
     auto tiles = [&](int t) {
         long a = (long)((m + t - 1) / t) * ((n + t - 1) / t) * batch;
         return lower ? a / 2 + 1 : a;
     };
+    // algorithmic flops: full product 2mnk; lower trapezoid of a trailing block
+    // 2k(mn - n^2/2), i.e. m^2 k for the square update
+    const double flops = (lower ? 2.0 * k * ((double)m * n - 0.5 * (double)n * n)
+                                : 2.0 * (double)m * n * k) * batch;
+    if (cls == BQ_K_SYRK && tiles(128) < c->cus)
+        cls = BQ_K_SYRK_SMALL;
+    Bracket br(c, cls, flops);
     const long cu = c->cus;
     if (tiles(128) >= cu) {
         dim3 grid((m + 127) / 128, (n + 127) / 128, batch);
@@ -324,7 +334,7 @@ int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const dou
 int launch_potf2(bq_ctx *c, double *A, long lda, long astride, int j0, double *dinv, long dstride,
                  int *info, int batch)
 {
-    Bracket br(c, BQ_K_POTF2);
+    Bracket br(c, BQ_K_POTF2, 64.0 * 64 * 64 / 3.0 * batch);
     hipLaunchKernelGGL(potf2_64_kernel, dim3(1, 1, batch), dim3(64), 0, c->cur, A, lda, astride,
                        j0, dinv, dstride, info);
     HIPCHK(c, hipGetLastError());
@@ -337,7 +347,7 @@ int launch_trsm(bq_ctx *c, double *X, long ldx, long xstride, int m, const doubl
 {
     if (m <= 0)
         return BQ_OK;
-    Bracket br(c, BQ_K_TRSM);
+    Bracket br(c, BQ_K_TRSM, 64.0 * 64 * (double)m * batch);
     // short panels: four lanes per row (latency); long ones: a row per lane (throughput)
     if ((long)((m + 15) / 16) * batch <= 4L * c->cus)
         hipLaunchKernelGGL(trsm_quad_kernel<TRANS>, dim3((m + 15) / 16, 1, batch), dim3(64), 0,
@@ -748,11 +758,12 @@ extern "C" int bq_profile_reset(bq_ctx *c)
     for (int k = 0; k < BQ_K_NCLASS; ++k) {
         c->prof_ms[k] = 0;
         c->prof_n[k] = 0;
+        c->prof_work[k] = 0;
     }
     return BQ_OK;
 }
 
-extern "C" int bq_profile_read(bq_ctx *c, double *ms, int64_t *launches)
+extern "C" int bq_profile_read(bq_ctx *c, double *ms, int64_t *launches, double *work)
 {
     if (!c)
         return BQ_ERR_BAD_ARG;
@@ -762,6 +773,8 @@ extern "C" int bq_profile_read(bq_ctx *c, double *ms, int64_t *launches)
             ms[k] = c->prof_ms[k];
         if (launches)
             launches[k] = c->prof_n[k];
+        if (work)
+            work[k] = c->prof_work[k];
     }
     return BQ_OK;
 }

@@ -130,10 +130,11 @@ class Engine(object):
 
     def profile_read(self):
         ms = np.zeros(len(L.K_CLASSES))
+        work = np.zeros(len(L.K_CLASSES))
         cnt = np.zeros(len(L.K_CLASSES), dtype=np.int64)
         self._check(self._lib.bq_profile_read(self._ctx, L.dptr(ms),
-                                              cnt.ctypes.data_as(L._i64p)))
-        return {k: {"ms": float(ms[i]), "launches": int(cnt[i])}
+                                              cnt.ctypes.data_as(L._i64p), L.dptr(work)))
+        return {k: {"ms": float(ms[i]), "launches": int(cnt[i]), "work": float(work[i])}
                 for i, k in enumerate(L.K_CLASSES)}
 
     # -- linalg_c drop-ins (host arrays) ------------------------------------

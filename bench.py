@@ -37,6 +37,22 @@ PEAK_HBM_GBS = 8000.0
 PEAK_FP64_TFLOPS = 78.6
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary
+    (profiles/*_pmc_traffic.json, made by tools/pmc_summary.py from separate
+    `rocprofv3 --pmc` passes); None when there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        k = json.load(f)["kernels"].get(kernel)
+    if not k:
+        return None, None
+    return (k.get("FETCH_SIZE_bytes_avg", 0.0) + k.get("WRITE_SIZE_bytes_avg", 0.0),
+            os.path.basename(files[-1]))
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,29 +127,6 @@ def make_workload(name, batch, rank):
                 B=B, desc=desc)
 
 
-def class_work(n, M, nb_outer):
-    """Algorithmic flops (bytes for gram) per step of each kernel class for the
-    bordered system of one problem (DESIGN.md section 'per-unit figures')."""
-    npad = -(-n // 64) * 64
-    ntot = -(-(npad + M + 1) // 64) * 64
-    w = {"gram": 8.0 * ntot * (ntot + 1) / 2, "potf2": 0.0, "trsm": 0.0, "gemm_panel": 0.0,
-         "syrk_trailing": 0.0, "reduce": 8.0 * (n + 2 * M)}
-    K0 = 0
-    while K0 < npad:
-        KB = min(nb_outer, npad - K0)
-        j0 = K0
-        while j0 < K0 + KB:
-            if j0 > K0:
-                w["gemm_panel"] += 2.0 * (ntot - j0) * 64 * (j0 - K0)
-            w["potf2"] += 64.0 ** 3 / 3
-            w["trsm"] += (ntot - j0 - 64) * 64.0 * 64
-            j0 += 64
-        m = ntot - K0 - KB
-        w["syrk_trailing"] += float(m) * m * KB
-        K0 += KB
-    return w, ntot
-
-
 def auto_nb(ntot, override, batch=1):
     """Mirror of auto_nb() in csrc/bqhip.hip (outer Cholesky block)."""
     if override:
@@ -180,6 +173,7 @@ def run_main(eng, wk, steps, warmup, dist):
     eng.profile(False)
     for k in prof:
         prof[k]["ms"] /= ninstr
+        prof[k]["work"] /= ninstr
         prof[k]["launches"] //= ninstr
     nbytes = plan.nbytes()
     plan.close()
@@ -253,10 +247,12 @@ def extras(eng, nb_override):
             eng._check(lib.bq_gram_gauss_dev(ctx, xd, d, n, h, L_.dptr(w), s, Kd, n))
         ms = eng.timer_stop_ms() / reps
         alg = 8.0 * n * n + 8.0 * d * n
-        out[tag] = {"kernel": "gram_sym_kernel", "bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9,
-                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                    "traffic": None, "ms_per_launch": ms, "algorithmic_bytes": alg,
-                    "note": "HIP events around back-to-back launches"}
+        traffic, src = pmc_traffic("gram_sym_kernel<%d>" % d)
+        out[tag] = {"kernel": "gram_sym_kernel<%d>" % d, "bound": "hbm",
+                    "achieved": alg / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
+                    "traffic_source": src, "ms_per_launch": ms, "algorithmic_bytes": alg,
+                    "note": "HIP events around %d back-to-back launches" % reps}
         if n == 16384:
             # ---- C4: potrf on the matrix just built ------------------------------
             info = eng.alloc(64)
@@ -295,6 +291,7 @@ def extras(eng, nb_override):
             eng.set_lookahead(True)
             best = min(t_la[1:])
             sy, sy_la = prof["syrk_trailing"], prof_la["syrk_trailing"]
+            sm = prof["syrk_trailing_small"]
             out["potrf_n16384"] = {
                 "ms": best, "gflops": wl.potrf_flops(n) / (best * 1e-3) / 1e9, "nb": nb,
                 "info": int(hinfo[0]), "lookahead_ms": t_la, "sequential_ms": t_seq,
@@ -302,17 +299,27 @@ def extras(eng, nb_override):
                 "class_ms_sequential": {k: v["ms"] for k, v in prof.items()},
                 "class_ms_lookahead": {k: v["ms"] for k, v in prof_la.items()},
                 "class_launches_sequential": {k: v["launches"] for k, v in prof.items()}}
+            traffic, src = pmc_traffic("gemm_sub_kernel<4, 4>")
+            ach = sy["work"] / (sy["ms"] * 1e-3) / 1e12
             out["trailing_update_n16384"] = {
-                "kernel": "gemm_sub_kernel<4,4> (trailing SYRK), sequential launches",
-                "bound": "mfma",
-                "achieved": tfl / (sy["ms"] * 1e-3) / 1e12, "peak": PEAK_FP64_TFLOPS,
-                "unit": "TFLOP/s", "frac": tfl / (sy["ms"] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
-                "traffic": None, "algorithmic_flops": tfl, "launches": sy["launches"],
-                "ms_total": sy["ms"], "ms_per_launch": sy["ms"] / max(1, sy["launches"]),
+                "kernel": "gemm_sub_kernel<4, 4>", "bound": "mfma", "achieved": ach,
+                "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_TFLOPS,
+                "traffic": traffic, "traffic_source": src,
+                "algorithmic_flops_per_launch": sy["work"] / max(1, sy["launches"]),
+                "launches": sy["launches"], "ms_total": sy["ms"],
+                "ms_per_launch": sy["ms"] / max(1, sy["launches"]),
+                "whole_trailing_update": {
+                    "algorithmic_flops": tfl, "ms_total": sy["ms"] + sm["ms"],
+                    "launches": sy["launches"] + sm["launches"],
+                    "achieved": tfl / ((sy["ms"] + sm["ms"]) * 1e-3) / 1e12,
+                    "frac": tfl / ((sy["ms"] + sm["ms"]) * 1e-3) / 1e12 / PEAK_FP64_TFLOPS},
                 "in_lookahead_pipeline": {
-                    "ms_total": sy_la["ms"], "launches": sy_la["launches"],
-                    "achieved": tfl / (sy_la["ms"] * 1e-3) / 1e12,
-                    "note": "same flops while panel kernels of the next block share the GPU"}}
+                    "ms_total": sy_la["ms"] + prof_la["syrk_trailing_small"]["ms"],
+                    "achieved": tfl / ((sy_la["ms"] + prof_la["syrk_trailing_small"]["ms"])
+                                       * 1e-3) / 1e12,
+                    "note": "same flops while the next block's panel kernels share the GPU"},
+                "note": "sequential launches (look-ahead off), HIP events per launch; the "
+                        "algorithmic flops of a trailing launch are m^2 nb (lower half)"}
             eng.free(info)
         eng.free(xd)
         eng.free(Kd)
@@ -342,28 +349,29 @@ def main():
     line = None
     if dist.rank == 0:
         info = eng.info()
-        work, ntot = class_work(wk["n"], wk["M"], auto_nb(
-            -(-(-(-wk["n"] // 64) * 64 + wk["M"] + 1) // 64) * 64, a.nb, wk["B"]))
+        npad = -(-wk["n"] // 64) * 64
+        ntot = -(-(npad + wk["M"] + 1) // 64) * 64
         prof = res["prof"]
         dom = max(prof, key=lambda k: prof[k]["ms"])
         dom_ms = prof[dom]["ms"]
         per_launch_ms = dom_ms / max(1, prof[dom]["launches"])
         if dom in ("gram", "reduce"):
-            ach = work[dom] * wk["B"] / (dom_ms * 1e-3) / 1e9
+            ach = prof[dom]["work"] / (dom_ms * 1e-3) / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None}
         else:
-            ach = work[dom] * wk["B"] / (dom_ms * 1e-3) / 1e12
+            ach = prof[dom]["work"] / (dom_ms * 1e-3) / 1e12
             roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / PEAK_FP64_TFLOPS, "traffic": None}
         roof.update({"launches_per_step": prof[dom]["launches"], "ms_per_launch": per_launch_ms,
                      "ms_per_step_in_class": dom_ms,
-                     "algorithmic_work_per_step": work[dom] * wk["B"],
+                     "algorithmic_work_per_step": prof[dom]["work"],
                      "class_ms_per_step": {k: v["ms"] for k, v in prof.items()},
                      "class_launches_per_step": {k: v["launches"] for k, v in prof.items()},
-                     "note": "dominant kernel class of the timed workload, HIP events on the "
-                             "engine stream in an instrumented pass; potf2/trsm are fp64 VALU "
-                             "kernels (fp64 vector peak == fp64 MFMA peak on MI355X)"})
+                     "note": "dominant kernel class of the timed workload (HIP events on the "
+                             "engine stream, instrumented pass).  This workload is latency "
+                             "bound: potf2_64_kernel is one wave of fp64 VALU work per launch; "
+                             "the kernels with a roofline target are under 'rooflines'"})
         line = {
             "metric": "bq_fit_posterior_throughput",
             "value": value,

@@ -78,17 +78,20 @@ int bq_timer_stop_ms(bq_ctx *ctx, float *ms); /* records, synchronises, returns 
 /* per-kernel-class device time of everything enqueued since the last reset,
  * measured with HIP events around each launch (slows the pipeline: use in a
  * separate, instrumented pass).  Classes: */
-#define BQ_K_GRAM 0     /* gram_gauss / assemble kernels */
-#define BQ_K_POTF2 1    /* 64x64 diagonal factor */
-#define BQ_K_TRSM 2     /* panel solve */
-#define BQ_K_GEMM 3     /* in-panel (left-looking) MFMA update */
-#define BQ_K_SYRK 4     /* trailing MFMA update */
-#define BQ_K_REDUCE 5   /* finalize / reductions / predict */
-#define BQ_K_NCLASS 6
+#define BQ_K_GRAM 0       /* gram_gauss / assemble kernels            (work: bytes) */
+#define BQ_K_POTF2 1      /* 64x64 diagonal factor                    (work: flop)  */
+#define BQ_K_TRSM 2       /* panel solve                              (work: flop)  */
+#define BQ_K_GEMM 3       /* in-panel (left-looking) MFMA update      (work: flop)  */
+#define BQ_K_SYRK 4       /* trailing MFMA update, gemm_sub_kernel<4,4> launches    */
+#define BQ_K_SYRK_SMALL 5 /* trailing MFMA update, the smaller-tile launches        */
+#define BQ_K_REDUCE 6     /* finalize / reductions / predict          (work: bytes) */
+#define BQ_K_NCLASS 7
 int bq_profile_enable(bq_ctx *ctx, int on);
 int bq_profile_reset(bq_ctx *ctx);
-/* ms[BQ_K_NCLASS], launches[BQ_K_NCLASS]; synchronises */
-int bq_profile_read(bq_ctx *ctx, double *ms, int64_t *launches);
+/* ms[BQ_K_NCLASS], launches[BQ_K_NCLASS], work[BQ_K_NCLASS] = the ALGORITHMIC flops
+ * or bytes of the launches of each class (trailing update: the lower half only,
+ * m^2 k; Gram: 8 N^2 + 8 d N); synchronises.  Any pointer may be NULL. */
+int bq_profile_read(bq_ctx *ctx, double *ms, int64_t *launches, double *work);
 
 /* ---- linalg_c drop-ins: host buffers in and out --------------------- */
 /* L <- lower Cholesky factor of C (n x n, ld = n).  C == L allowed (in place).

@@ -1,0 +1,50 @@
+"""Summarises rocprofv3 passes of tools/roofline_run.py into profiles/:
+    python tools/pmc_summary.py gpurun_out/rf_trace gpurun_out/rf_pmc_write gpurun_out/rf_pmc_fetch r01
+writes profiles/<tag>_roofline_kernel_stats.csv (copy of the --stats summary) and
+profiles/<tag>_pmc_traffic.json (per-kernel average FETCH_SIZE / WRITE_SIZE in bytes).
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  Per MI355X_MICROARCH.md,
+WRITE_SIZE is exact for 16-B-per-lane streaming stores; FETCH_SIZE under-counts wide
+(16 B/lane) coalesced reads by 2x and is uncalibrated for other widths -- the GEMM
+reads 8 B/lane, so its fetch figure is kept raw and flagged."""
+import glob
+import json
+import os
+import shutil
+import sys
+
+import pandas as pd
+
+
+def main():
+    trace, pw, pf, tag = sys.argv[1:5]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stats = glob.glob(os.path.join(trace, "*", "*_kernel_stats.csv"))[0]
+    shutil.copy(stats, os.path.join(root, "profiles", "%s_roofline_kernel_stats.csv" % tag))
+    st = pd.read_csv(stats)
+    out = {"_source": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate passes) of "
+                      "`python3 tools/roofline_run.py`; bytes = counter KiB x 1024; "
+                      "fetch is RAW (no x2 wide-load correction: the GEMM loads 8 B/lane)",
+           "kernels": {}}
+    for path, name in ((pw, "WRITE_SIZE"), (pf, "FETCH_SIZE")):
+        f = glob.glob(os.path.join(path, "*", "*_counter_collection.csv"))[0]
+        t = pd.read_csv(f)
+        t = t[t.Counter_Name == name]
+        t["short"] = t.Kernel_Name.str.extract(r"(\w+_kernel(?:<[^>]*>)?)")
+        for k, g in t.groupby("short"):
+            d = out["kernels"].setdefault(k, {})
+            d[name + "_bytes_avg"] = float(g.Counter_Value.mean() * 1024)
+            d[name + "_bytes_total"] = float(g.Counter_Value.sum() * 1024)
+            d["launches"] = int(len(g))
+    st["short"] = st.Name.str.extract(r"(\w+_kernel(?:<[^>]*>)?)")
+    for _, r in st.iterrows():
+        if r.short in out["kernels"]:
+            out["kernels"][r.short]["avg_ns"] = float(r.AverageNs)
+            out["kernels"][r.short]["calls_in_trace"] = int(r.Calls)
+    with open(os.path.join(root, "profiles", "%s_pmc_traffic.json" % tag), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(json.dumps(out["kernels"].get("gemm_sub_kernel<4, 4>"), indent=1))
+    print(json.dumps(out["kernels"].get("gram_sym_kernel<2>"), indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,48 @@
+"""A short, fixed sequence of the two north-star kernels for profiler passes:
+  * gram_sym_kernel<2> on the C3 points (N=4096, d=2), 10 launches
+  * gram_sym_kernel<1> at N=16384, 3 launches
+  * one sequential (no look-ahead) potrf at N=16384, nb=256 -> 63 trailing updates
+Used under `rocprofv3 --kernel-trace --stats` and under `rocprofv3 --pmc ...`."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bayesian_quadrature_amd import Engine, _lib as L_  # noqa: E402
+from bayesian_quadrature_amd import workloads as wl  # noqa: E402
+
+
+def main():
+    e = Engine(0)
+    e.set_lookahead(False)
+    lib, ctx = e._lib, e._ctx
+    c3 = wl.c3()
+    pts = np.asfortranarray(c3["x"])
+    w3 = np.ascontiguousarray(c3["w"][200])
+    xd = e.alloc(8 * 2 * 4096)
+    Kd = e.alloc(8 * 4096 * 4096)
+    e.upload(xd, pts)
+    for _ in range(10):
+        e._check(lib.bq_gram_gauss_dev(ctx, xd, 2, 4096, float(c3["h"][200]), L_.dptr(w3), c3["s"], Kd, 4096))
+    e.sync()
+    e.free(xd), e.free(Kd)
+    n = 16384
+    c4 = wl.c4(n)
+    w4 = np.ascontiguousarray(c4["w"])
+    xd = e.alloc(8 * n)
+    Kd = e.alloc(8 * n * n)
+    info = e.alloc(64)
+    e.upload(xd, np.ascontiguousarray(c4["x"]))
+    for _ in range(3):
+        e._check(lib.bq_gram_gauss_dev(ctx, xd, 1, n, c4["h"], L_.dptr(w4), c4["s"], Kd, n))
+    e._check(lib.bq_potrf_dev(ctx, Kd, n, n, info))
+    e.sync()
+    h = np.zeros(1, dtype=np.int32)
+    e.download(h, info)
+    print("potrf info", h[0])
+    e.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -31,7 +31,7 @@ def main():
     mean, var, logml, status = plan.results()
     e.profile(True); e.profile_reset(); plan.run(); prof = e.profile_read(); e.profile(False)
     out["c5_shard"] = {"batch": B, "ms_per_batch": ms, "problems_per_s": B / ms * 1e3,
-                       "failed": int((status != 0).sum()), "class_ms": {k: v["ms"] for k, v in prof.items()},
+                       "failed": int((status != 0).sum()), "class_ms": {k: v["ms"] for k, v in prof.items()}, "class_tflops_or_gbs": {k: (v["work"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else 0) for k, v in prof.items()},
                        "class_launches": {k: v["launches"] for k, v in prof.items()},
                        "plan_GB": plan.nbytes() / 1e9}
     plan.close()
