@@ -77,6 +77,9 @@ struct bq_ctx {
     hipStream_t cur = nullptr;    // stream the launch helpers enqueue on (stream or aux)
     hipEvent_t ev_panel = nullptr, ev_next = nullptr, ev_fork = nullptr;
     int lookahead = 1;
+    int potf2_waves = 4; // 4: potf2_64x4_kernel, 1: potf2_64_kernel (BQ_POTF2_WAVES)
+    int gram_nt = 0;     // non-temporal stores in the Gram kernel (BQ_GRAM_NT)
+    int use_graph = 1;   // replay plans from a captured hipGraph (BQ_GRAPH=0 disables)
     bool own_stream = false;
     int cus = 256;
     int nb_override = 0;
@@ -203,7 +206,7 @@ void launch_gram_sym_d(bq_ctx *c, const double *x, long xstride, const GaussPara
 {
     dim3 grid((n + 127) / 128, (n + 63) / 64, batch);
     hipLaunchKernelGGL(gram_sym_kernel<D>, grid, dim3(256), 0, c->cur, x, xstride, gp, gpstride,
-                       K, ldk, kstride, n);
+                       K, ldk, kstride, n, c->gram_nt);
 }
 
 int launch_gram_sym(bq_ctx *c, int d, const double *x, long xstride, const GaussParams *gp,
@@ -335,8 +338,12 @@ int launch_potf2(bq_ctx *c, double *A, long lda, long astride, int j0, double *d
                  int *info, int batch)
 {
     Bracket br(c, BQ_K_POTF2, 64.0 * 64 * 64 / 3.0 * batch);
-    hipLaunchKernelGGL(potf2_64_kernel, dim3(1, 1, batch), dim3(64), 0, c->cur, A, lda, astride,
-                       j0, dinv, dstride, info);
+    if (c->potf2_waves == 1)
+        hipLaunchKernelGGL(potf2_64_kernel, dim3(1, 1, batch), dim3(64), 0, c->cur, A, lda,
+                           astride, j0, dinv, dstride, info);
+    else
+        hipLaunchKernelGGL(potf2_64x4_kernel, dim3(1, 1, batch), dim3(256), 0, c->cur, A, lda,
+                           astride, j0, dinv, dstride, info);
     HIPCHK(c, hipGetLastError());
     return BQ_OK;
 }
@@ -552,6 +559,12 @@ static int ctx_init(bq_ctx *c, int device)
     HIPCHK(c, hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, hi));
     if (const char *e = std::getenv("BQ_LOOKAHEAD"))
         c->lookahead = std::atoi(e);
+    if (const char *e = std::getenv("BQ_GRAM_NT"))
+        c->gram_nt = std::atoi(e);
+    if (const char *e = std::getenv("BQ_GRAPH"))
+        c->use_graph = std::atoi(e);
+    if (const char *e = std::getenv("BQ_POTF2_WAVES"))
+        c->potf2_waves = std::atoi(e) == 1 ? 1 : 4;
     return BQ_OK;
 }
 
@@ -1013,6 +1026,12 @@ struct bq_plan {
     DevBuf A, pts, y, gp, dinv, info, scal, mean, var;
     std::vector<GaussParams> hgp;
     bool has_inputs = false;
+    // the launch sequence of a plan is static: it is captured once into a hipGraph
+    // and replayed (cuts the host launch cost of the ~50 short kernels of a step)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    int graph_state = 0; // 0 = not tried, 1 = ready, -1 = unavailable (eager launches)
+    int graph_nb = 0, graph_la = 0, graph_pw = 0;
 };
 
 namespace {
@@ -1075,6 +1094,10 @@ extern "C" int bq_plan_create(bq_ctx *c, int64_t nprob, int64_t d, int64_t n, in
     return BQ_OK;
 }
 
+namespace {
+void plan_drop_graph(bq_plan *p);
+}
+
 extern "C" void bq_plan_destroy(bq_ctx *c, bq_plan *p)
 {
     if (!p)
@@ -1083,6 +1106,7 @@ extern "C" void bq_plan_destroy(bq_ctx *c, bq_plan *p)
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
     }
+    plan_drop_graph(p);
     delete p;
 }
 
@@ -1127,12 +1151,10 @@ extern "C" int bq_plan_set_inputs(bq_ctx *c, bq_plan *p, const double *x, const 
     return BQ_OK;
 }
 
-extern "C" int bq_plan_run(bq_ctx *c, bq_plan *p)
+namespace {
+
+int plan_enqueue(bq_ctx *c, bq_plan *p)
 {
-    if (!c || !p)
-        return BQ_ERR_BAD_ARG;
-    if (!p->has_inputs)
-        return fail(c, BQ_ERR_BAD_ARG, "plan has no inputs");
     HIPCHK(c, hipMemsetAsync(p->info.p, 0, sizeof(int) * p->nprob, c->stream));
     BQCHK(launch_assemble(c, p->d, p->pts.d(), (long)p->d * p->L.ntot, p->y.d(), p->L.npad,
                           static_cast<GaussParams *>(p->gp.p), 1, p->A.d(), p->lda, p->astride,
@@ -1140,13 +1162,68 @@ extern "C" int bq_plan_run(bq_ctx *c, bq_plan *p)
     BQCHK(enqueue_potrf_partial(c, p->A.d(), p->lda, p->astride, p->nprob, p->L.ntot, p->L.npad,
                                 p->dinv.d(), p->info.i()));
     {
-        Bracket br(c, BQ_K_REDUCE);
+        Bracket br(c, BQ_K_REDUCE, 8.0 * (p->n + 2.0 * p->M) * p->nprob);
         hipLaunchKernelGGL(finalize_kernel, dim3(1, 1, p->nprob), dim3(256), 0, c->stream,
                            p->A.d(), p->lda, p->astride, p->L, p->scal.d(), p->mean.d(),
                            p->var.d(), (long)std::max(p->M, 1));
         HIPCHK(c, hipGetLastError());
     }
     return BQ_OK;
+}
+
+void plan_drop_graph(bq_plan *p)
+{
+    if (p->gexec)
+        (void)hipGraphExecDestroy(p->gexec);
+    if (p->graph)
+        (void)hipGraphDestroy(p->graph);
+    p->gexec = nullptr;
+    p->graph = nullptr;
+}
+
+} // namespace
+
+extern "C" int bq_plan_run(bq_ctx *c, bq_plan *p)
+{
+    if (!c || !p)
+        return BQ_ERR_BAD_ARG;
+    if (!p->has_inputs)
+        return fail(c, BQ_ERR_BAD_ARG, "plan has no inputs");
+    if (c->prof || !c->use_graph || !c->own_stream)
+        return plan_enqueue(c, p);
+    // settings that change the launch sequence invalidate the captured graph
+    if (p->graph_state == 1 && (p->graph_nb != c->nb_override || p->graph_la != c->lookahead ||
+                                p->graph_pw != c->potf2_waves)) {
+        plan_drop_graph(p);
+        p->graph_state = 0;
+    }
+    if (p->graph_state == 0) {
+        p->graph_nb = c->nb_override;
+        p->graph_la = c->lookahead;
+        p->graph_pw = c->potf2_waves;
+        p->graph_state = -1;
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
+            const int st = plan_enqueue(c, p);
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(c->stream, &g);
+            if (st == BQ_OK && e == hipSuccess && g &&
+                hipGraphInstantiate(&p->gexec, g, nullptr, nullptr, 0) == hipSuccess) {
+                p->graph = g;
+                p->graph_state = 1;
+            } else {
+                if (g)
+                    (void)hipGraphDestroy(g);
+                (void)hipGetLastError(); // clear; fall back to eager launches
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (p->graph_state == 1) {
+        HIPCHK(c, hipGraphLaunch(p->gexec, c->stream));
+        return BQ_OK;
+    }
+    return plan_enqueue(c, p);
 }
 
 extern "C" int bq_plan_results(bq_ctx *c, bq_plan *p, double *mean, double *var, double *logml,
@@ -1652,6 +1729,25 @@ extern "C" int bq_probe_hbm(bq_ctx *c, size_t bytes, double *write_gbs, double *
     }
     if (copy_gbs)
         *copy_gbs = 5.0 * 2.0 * bytes / (ms * 1e-3) / 1e9;
+    return BQ_OK;
+}
+
+extern "C" int bq_probe_launch(bq_ctx *c, int64_t n, double *us_per_launch)
+{
+    if (!c || !us_per_launch || n < 1)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf o;
+    HIPCHK(c, o.alloc(64));
+    for (int i = 0; i < 10; ++i)
+        hipLaunchKernelGGL(probe_empty_kernel, dim3(1), dim3(64), 0, c->stream, o.d());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    BQCHK(bq_timer_start(c));
+    for (int64_t i = 0; i < n; ++i)
+        hipLaunchKernelGGL(probe_empty_kernel, dim3(1), dim3(64), 0, c->stream, o.d());
+    BQCHK(bq_timer_stop_ms(c, &ms));
+    *us_per_launch = ms * 1e3 / (double)n;
     return BQ_OK;
 }
 

@@ -263,6 +263,11 @@ class Engine(object):
                                            C.cast(C.byref(b), _dp)))
         return float(a.value), float(b.value)
 
+    def probe_launch(self, n=2000):
+        v = C.c_double()
+        self._check(self._lib.bq_probe_launch(self._ctx, int(n), C.cast(C.byref(v), _dp)))
+        return float(v.value)
+
     def probe_mfma_layout(self):
         out = np.empty(256)
         self._check(self._lib.bq_probe_mfma_layout(self._ctx, L.dptr(out)))

@@ -191,6 +191,8 @@ int bq_probe_mfma_f64(bq_ctx *ctx, double *tflops);
 int bq_probe_fma_f64(bq_ctx *ctx, double *tflops);
 /* streaming fp64 write / copy bandwidth in GB/s over `bytes` */
 int bq_probe_hbm(bq_ctx *ctx, size_t bytes, double *write_gbs, double *copy_gbs);
+/* device time per launch of a chain of n empty, dependent kernels (us) */
+int bq_probe_launch(bq_ctx *ctx, int64_t n, double *us_per_launch);
 /* dump of the f64 MFMA D-register layout: out[64*4] receives, for lane l and
  * register r, the value row*16+col of the D element it holds */
 int bq_probe_mfma_layout(bq_ctx *ctx, double *out256);

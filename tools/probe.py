@@ -18,6 +18,7 @@ def main():
                               "lane0": lay[0].tolist(), "lane16": lay[16].tolist()}
     out["mfma_f64_tflops"] = [e.probe_mfma_f64() for _ in range(3)]
     out["fma_f64_tflops"] = [e.probe_fma_f64() for _ in range(3)]
+    out["empty_kernel_chain_us_per_launch"] = [e.probe_launch(2000) for _ in range(3)]
     out["hbm_write_copy_gbs_1GiB"] = e.probe_hbm(1 << 30)
     out["hbm_write_copy_gbs_128MiB"] = e.probe_hbm(1 << 27)
     print(json.dumps(out, indent=1))
