@@ -404,10 +404,12 @@ int enqueue_panel(bq_ctx *c, double *A, long lda, long astride, int batch, int n
 // matrix (ntot multiple of 64), batched.  dinv: 64 doubles per problem.
 //
 // With more than one outer block and a wide block the factorisation runs with a
-// look-ahead of one panel on two streams: after panel k, the trailing update is
-// split into the columns of panel k+1 (main stream, first) and the rest (main
-// stream); panel k+1 is factored on the high-priority aux stream as soon as its
-// columns are updated, i.e. concurrently with the bulk of trailing update k.
+// look-ahead of one panel on two streams.  The main stream carries only the bulk
+// trailing updates (everything right of the next panel), back to back; the
+// high-priority aux stream updates the next panel's columns and factors that
+// panel meanwhile.  The two meet through events: update k+1 waits for panel k+1,
+// the panel-column update k+1 waits for trailing update k (which last wrote
+// those columns).
 int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
                           int ncols, double *dinv, int *info)
 {
@@ -433,36 +435,48 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
     int st = BQ_OK;
+    // aux stream: panel 0
+    c->cur = c->aux;
+    st = enqueue_panel(c, A, lda, astride, batch, ntot, 0, std::min(NB, ncols), dinv, info);
+    c->cur = c->stream;
+    if (st != BQ_OK)
+        return st;
+    HIPCHK(c, hipEventRecord(c->ev_panel, c->aux));
+    bool have_b = false; // a trailing update is in flight on the main stream
     for (int K0 = 0; K0 < ncols && st == BQ_OK; K0 += NB) {
         const int KB = std::min(NB, ncols - K0);
-        c->cur = c->aux;
-        st = enqueue_panel(c, A, lda, astride, batch, ntot, K0, KB, dinv, info);
-        c->cur = c->stream;
-        if (st != BQ_OK)
-            break;
-        HIPCHK(c, hipEventRecord(c->ev_panel, c->aux));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_panel, 0));
         const int r0 = K0 + KB;
+        // main stream: wait for panel K0
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_panel, 0));
         if (r0 >= ntot)
             break;
         const double *P = A + r0 + (long)K0 * lda;
         const int nw = (r0 < ncols) ? std::min(NB, ncols - r0) : 0; // width of the next panel
         if (nw > 0) {
-            // columns of the next panel first ...
+            // aux stream: bring the next panel's columns up to date (they were last
+            // written by the previous trailing update on the main stream), factor it
+            if (have_b)
+                HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_next, 0));
+            c->cur = c->aux;
             st = launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda, astride,
                              P, 1, lda, astride, ntot - r0, nw, KB, 1, batch);
+            if (st == BQ_OK)
+                st = enqueue_panel(c, A, lda, astride, batch, ntot, r0, nw, dinv, info);
+            c->cur = c->stream;
             if (st != BQ_OK)
                 break;
-            HIPCHK(c, hipEventRecord(c->ev_next, c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_next, 0));
-            // ... then the rest, overlapping the next panel's factorisation
+            HIPCHK(c, hipEventRecord(c->ev_panel, c->aux));
+            // main stream: everything right of the next panel, concurrently
             const int r1 = r0 + nw;
             if (r1 < ntot) {
                 const double *P1 = A + r1 + (long)K0 * lda;
                 st = launch_gemm(c, BQ_K_SYRK, A + r1 + (long)r1 * lda, lda, astride, P1, lda,
                                  astride, P1, 1, lda, astride, ntot - r1, ntot - r1, KB, 1, batch);
+                HIPCHK(c, hipEventRecord(c->ev_next, c->stream));
+                have_b = true;
             }
         } else {
+            // no further panel: the remaining trailing block is pure Schur complement
             st = launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda, astride,
                              P, 1, lda, astride, ntot - r0, ntot - r0, KB, 1, batch);
         }

@@ -45,6 +45,33 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane)
     return __hiloint2double(hi, lo);
 }
 
+// exp(x) for the Gaussian-kernel exponent (x <= 0): range reduction by ln 2 with a
+// hi/lo split, degree-13 Taylor polynomial on |r| <= ln2/2 (truncation 6e-18),
+// v_ldexp_f64 for the scale.  20 fp64 instructions against ~28 of the library
+// routine, <= 1 ulp; x is clamped at -800 where the result is 0 anyway.
+__device__ __forceinline__ double exp_gauss(double x)
+{
+    x = __builtin_fmax(x, -800.0);
+    const double k = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(k, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(k, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;            // 1/13!
+    p = __builtin_fma(p, r, 2.0876756987868100e-09); // 1/12!
+    p = __builtin_fma(p, r, 2.5052108385441720e-08); // 1/11!
+    p = __builtin_fma(p, r, 2.7557319223985888e-07); // 1/10!
+    p = __builtin_fma(p, r, 2.7557319223985893e-06); // 1/9!
+    p = __builtin_fma(p, r, 2.4801587301587302e-05); // 1/8!
+    p = __builtin_fma(p, r, 1.9841269841269841e-04); // 1/7!
+    p = __builtin_fma(p, r, 1.3888888888888889e-03); // 1/6!
+    p = __builtin_fma(p, r, 8.3333333333333332e-03); // 1/5!
+    p = __builtin_fma(p, r, 4.1666666666666664e-02); // 1/4!
+    p = __builtin_fma(p, r, 1.6666666666666666e-01); // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)k);
+}
+
 template <int D>
 __device__ __forceinline__ double gauss_q(const double *p, const double *q, const GaussParams &g)
 {
@@ -95,8 +122,14 @@ __global__ __launch_bounds__(256) void gram_sym_kernel(const double *__restrict_
 #pragma unroll
         for (int k = 0; k < D; ++k)
             xj[k] = x[k + (long)j * D];
-        double v0 = g.c * exp(gauss_q<D>(xi0, xj, g));
-        double v1 = g.c * exp(gauss_q<D>(xi1, xj, g));
+        double v0, v1;
+        if (nt & 2) { // timing diagnostic only (BQ_GRAM_NT=2): no exp, wrong values
+            v0 = g.c * gauss_q<D>(xi0, xj, g);
+            v1 = g.c * gauss_q<D>(xi1, xj, g);
+        } else {
+            v0 = g.c * exp_gauss(gauss_q<D>(xi0, xj, g));
+            v1 = g.c * exp_gauss(gauss_q<D>(xi1, xj, g));
+        }
         if (i == j)
             v0 += g.s2;
         if (i + 1 == j)
@@ -104,7 +137,7 @@ __global__ __launch_bounds__(256) void gram_sym_kernel(const double *__restrict_
         double *dst = K + i + (long)j * ldk;
         if (vec) {
             double2_t v = {v0, v1};
-            if (nt)
+            if (nt & 1)
                 __builtin_nontemporal_store(v, reinterpret_cast<double2_t *>(dst));
             else
                 *reinterpret_cast<double2_t *>(dst) = v;
@@ -140,7 +173,7 @@ __global__ __launch_bounds__(256) void gram_cross_kernel(const double *__restric
 #pragma unroll
         for (int k = 0; k < D; ++k)
             xj[k] = x2[k + (long)j * D];
-        K[i + (long)j * ldk] = g.c * exp(gauss_q<D>(xi, xj, g));
+        K[i + (long)j * ldk] = g.c * exp_gauss(gauss_q<D>(xi, xj, g));
     }
 }
 
@@ -207,7 +240,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(const double *__restrict_
             const int ii = i + r;
             double val;
             if (pi[r] && pj) {
-                val = g.c * exp(gauss_q<D>(xi[r], xj, g));
+                val = g.c * exp_gauss(gauss_q<D>(xi[r], xj, g));
                 if (ii == j && ii < L.n)
                     val += g.s2;
             } else if (ii == L.yrow) {
@@ -867,19 +900,23 @@ __global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C
     const int ksteps = k >> 2; // even (k is a multiple of 8): the body below has no branch
     for (int ks = 0; ks < ksteps; ks += 2) {
         // fragments of step ks+1 are requested before the MFMAs of step ks issue,
-        // those of step ks+2 before the MFMAs of step ks+1
+        // those of step ks+2 before the MFMAs of step ks+1.  The scheduling
+        // barriers keep that order: without them the scheduler sinks each load
+        // group down to its first use and the prefetch distance collapses to zero.
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
             pb[tm] = pp[tm][(long)(ks + 1) * pstep];
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
             qb[tn] = qq[tn][(long)(ks + 1) * qstep];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
                 acc[tm][tn] =
                     __builtin_amdgcn_mfma_f64_16x16x4f64(qa[tn], pa[tm], acc[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         const long o2 = (ks + 2 < ksteps) ? (long)(ks + 2) : (long)ks; // clamped, value unused
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -887,12 +924,14 @@ __global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
             qa[tn] = qq[tn][o2 * qstep];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
                 acc[tm][tn] =
                     __builtin_amdgcn_mfma_f64_16x16x4f64(qb[tn], pb[tm], acc[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // D^T tile: D[jj][ii], jj = l4 + 4 r (column of C), ii = l15 (row of C)
@@ -1113,7 +1152,7 @@ __global__ __launch_bounds__(256) void predict_mean_kernel(const double *__restr
 #pragma unroll
         for (int k = 0; k < D; ++k)
             q[k] = x[k + (long)j * D];
-        s += exp(gauss_q<D>(p, q, g)) * alpha[j];
+        s += exp_gauss(gauss_q<D>(p, q, g)) * alpha[j];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
