@@ -309,26 +309,30 @@ int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const dou
         cls = BQ_K_SYRK_SMALL;
     Bracket br(c, cls, flops);
     const long cu = c->cus;
+    // square trailing updates launch only their lower workgroup tiles (mode 2)
+    const bool tri = lower && m == n;
+    const int mode = tri ? 2 : lower;
+    auto grid_for = [&](int t) {
+        const unsigned gm = (unsigned)((m + t - 1) / t), gn = (unsigned)((n + t - 1) / t);
+        return tri ? dim3(gm * (gm + 1) / 2, 1, batch) : dim3(gm, gn, batch);
+    };
     if (tiles(128) >= cu) {
-        dim3 grid((m + 127) / 128, (n + 127) / 128, batch);
-        hipLaunchKernelGGL((gemm_sub_kernel<4, 4>), grid, dim3(256), 0, c->cur, C, ldc, cstride,
-                           P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, lower);
+        hipLaunchKernelGGL((gemm_sub_kernel<4, 4>), grid_for(128), dim3(256), 0, c->cur, C, ldc,
+                           cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, mode);
     } else if (tiles(64) >= cu / 2) {
-        dim3 grid((m + 63) / 64, (n + 63) / 64, batch);
         if (k == 64)
-            hipLaunchKernelGGL((gemm_k64_kernel<2, 2>), grid, dim3(256), 0, c->cur, C, ldc,
-                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, lower);
+            hipLaunchKernelGGL((gemm_k64_kernel<2, 2>), grid_for(64), dim3(256), 0, c->cur, C, ldc,
+                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, mode);
         else
-            hipLaunchKernelGGL((gemm_sub_kernel<2, 2>), grid, dim3(256), 0, c->cur, C, ldc,
-                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, lower);
+            hipLaunchKernelGGL((gemm_sub_kernel<2, 2>), grid_for(64), dim3(256), 0, c->cur, C, ldc,
+                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, mode);
     } else {
-        dim3 grid((m + 31) / 32, (n + 31) / 32, batch);
         if (k == 64)
-            hipLaunchKernelGGL((gemm_k64_kernel<1, 1>), grid, dim3(256), 0, c->cur, C, ldc,
-                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, lower);
+            hipLaunchKernelGGL((gemm_k64_kernel<1, 1>), grid_for(32), dim3(256), 0, c->cur, C, ldc,
+                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, mode);
         else
-            hipLaunchKernelGGL((gemm_sub_kernel<1, 1>), grid, dim3(256), 0, c->cur, C, ldc,
-                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, lower);
+            hipLaunchKernelGGL((gemm_sub_kernel<1, 1>), grid_for(32), dim3(256), 0, c->cur, C, ldc,
+                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, mode);
     }
     HIPCHK(c, hipGetLastError());
     return BQ_OK;
