@@ -63,6 +63,14 @@ SIGNATURES = {
     "bq_gp_logml_grid": (C.c_int, [_vp, _dp, _dp, _i64, _i64, _dp, _dp, _dbl, _i64, _dp, _i64]),
     "bq_batch_fit_predict": (C.c_int, [_vp, _i64, _dp, _dp, _i64, _i64, _dbl, _dp, _dbl, _dp, _i64,
                                        _dp, _dp, _dp, _i32p]),
+    "bq_int_K": (C.c_int, [_vp, _dp, _i64, _i64, _dbl, _dp, _dp, _dp, _dp]),
+    "bq_int_K1_K2": (C.c_int, [_vp, _dp, _i64, _dp, _i64, _i64, _dbl, _dp, _dbl, _dp, _dp, _dp,
+                               _dp]),
+    "bq_int_int_K1_K2_K1": (C.c_int, [_vp, _dp, _i64, _i64, _dbl, _dp, _dbl, _dp, _dp, _dp, _dp]),
+    "bq_int_int_K1_K2": (C.c_int, [_vp, _dp, _i64, _i64, _dbl, _dp, _dbl, _dp, _dp, _dp, _dp]),
+    "bq_gp_solve": (C.c_int, [_vp, _vp, _dp, _i64, _dp]),
+    "bq_bq_Z_mean": (C.c_int, [_vp, _vp, _dp, _dp, _dp]),
+    "bq_bq_Z_var": (C.c_int, [_vp, _vp, _vp, _dp, _dp, _dp]),
     "bq_plan_create": (C.c_int, [_vp, _i64, _i64, _i64, _i64, C.POINTER(_vp)]),
     "bq_plan_destroy": (None, [_vp, _vp]),
     "bq_plan_set_inputs": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp, _dp, _dp]),

@@ -11,12 +11,14 @@ are likewise not part of this package.
 """
 import logging
 from copy import copy, deepcopy
+from warnings import warn
 
 import numpy as np
 
 from . import bq_c
 from . import linalg as la
 from . import util
+from .engine import get_engine
 from .gp import GP, GaussianKernel, PeriodicKernel
 
 logger = logging.getLogger("bayesian_quadrature")
@@ -114,20 +116,26 @@ class BQ(object):
         return self._exact_Z_mean()
 
     def _exact_Z_mean(self):
-        h, w = self.gp_l.K.params
-        return bq_c.Z_mean(_row(self.x_sc), self.gp_l.inv_Kxx_y, h, np.array([w]),
-                           self.options["x_mean"], self.options["x_cov"])
+        """E[Z] = (int K_l(x, x_sc) p(x) dx) . alpha_l, fused on the device with the
+        resident fit of the second GP (bq_c.pyx:157-213)."""
+        m_Z = get_engine().Z_mean(self.gp_l._device_fit(), self.options["x_mean"],
+                                  self.options["x_cov"])
+        if m_Z <= 0:
+            warn("m_Z = %s" % m_Z)
+        return m_Z
 
     def Z_var(self):
         self._require_exact()
         return self._exact_Z_var()
 
     def _exact_Z_var(self):
-        h_l, w_l = self.gp_l.K.params
-        h_tl, w_tl = self.gp_log_l.K.params
-        return bq_c.Z_var(_row(self.x_s), _row(self.x_sc), self.gp_l.inv_Kxx_y,
-                          np.array(self.gp_log_l.Lxx, order="F"), h_l, np.array([w_l]),
-                          h_tl, np.array([w_tl]), self.options["x_mean"], self.options["x_cov"])
+        """V(Z) from the two resident fits (bq_c.pyx:264-355); no n x n matrix leaves
+        the device."""
+        V_Z = get_engine().Z_var(self.gp_log_l._device_fit(), self.gp_l._device_fit(),
+                                 self.options["x_mean"], self.options["x_cov"])
+        if V_Z <= 0:
+            warn("V_Z = %s" % V_Z)
+        return V_Z
 
     # ------------------------------------------------- expected moments given x_a
     def expected_Z_var(self, x_a):

@@ -1676,6 +1676,8 @@ extern "C" int bq_gp_predict(bq_ctx *c, bq_fit *f, const double *xo, int64_t M, 
     return BQ_OK;
 }
 
+#include "integrals.inc"
+
 // ===========================================================================
 // hardware probes
 // ===========================================================================

@@ -1293,3 +1293,201 @@ __global__ void probe_layout_kernel(double *out)
     for (int r = 0; r < 4; ++r)
         out[l * 4 + r] = c[r];
 }
+
+// ===========================================================================
+// Closed-form Gaussian-kernel integrals (gauss_c.pyx) and the BQ moments that
+// consume them (bq_c.pyx:157-213,264-355).  Each result is
+//     scale * exp( log N(z | 0, C) + per-point terms ),
+// with z a D-vector built from one or two points.  The host supplies the
+// inverse Cholesky factor of the small D x D covariance (D <= 16), so the
+// Mahalanobis term is || Linv z ||^2 with no division on the device.
+// ===========================================================================
+template <int D>
+struct GaussForm {
+    double mu[D];        // subtracted from the point(s) to form z
+    double linv[D * D];  // row-major lower-triangular inverse Cholesky factor
+    double logc;         // -(D log 2pi + log|C|) / 2
+};
+
+template <int D>
+__device__ __forceinline__ double gauss_form_eval(const GaussForm<D> &f, const double (&z)[D])
+{
+    double maha = 0.0;
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+        double y = 0.0;
+#pragma unroll
+        for (int c = 0; c <= r; ++c)
+            y += f.linv[r * D + c] * z[c];
+        maha += y * y;
+    }
+    return f.logc - 0.5 * maha;
+}
+
+// out_i = scale * exp(add + log N(x_i - mu | 0, C)); also, if alpha != null,
+// accumulates sum_i out_i alpha_i into acc[0] (Z_mean) -- one block per 256 points
+template <int D>
+__global__ __launch_bounds__(256) void int_K_kernel(const double *__restrict__ x, int n,
+                                                    GaussForm<D> f, double scale, double add,
+                                                    double *__restrict__ out,
+                                                    const double *__restrict__ alpha,
+                                                    double *__restrict__ acc)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double v = 0.0;
+    if (i < n) {
+        double z[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            z[k] = x[k + (long)i * D] - f.mu[k];
+        v = scale * exp(add + gauss_form_eval<D>(f, z));
+        if (out)
+            out[i] = v;
+        if (alpha)
+            v *= alpha[i];
+    }
+    if (acc) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            v += __shfl_down(v, off, 64);
+        __shared__ double part[4];
+        if ((threadIdx.x & 63) == 0)
+            part[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            acc[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+    }
+}
+
+// out_ij = scale * exp(log N([x1_i - mu; x2_j - mu] | 0, C2)), n1 x n2 column-major.
+// With alpha (length n2) and beta (length n1): beta_i = sum_j out_ij alpha_j is
+// accumulated instead of (or besides) storing the matrix; one block = 64 rows,
+// its four waves split the columns.
+template <int D>
+__global__ __launch_bounds__(256) void int_K1_K2_kernel(const double *__restrict__ x1, int n1,
+                                                        const double *__restrict__ x2, int n2,
+                                                        GaussForm<2 * D> f, double scale,
+                                                        double *__restrict__ out,
+                                                        const double *__restrict__ alpha,
+                                                        double *__restrict__ beta)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    double z[2 * D];
+    const bool ok = i < n1;
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+        z[k] = ok ? x1[k + (long)i * D] - f.mu[k] : 0.0;
+    double acc = 0.0;
+    for (int j = wave; j < n2; j += 4) {
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            z[D + k] = x2[k + (long)j * D] - f.mu[D + k];
+        const double v = scale * exp(gauss_form_eval<2 * D>(f, z));
+        if (out && ok)
+            out[i + (long)j * n1] = v;
+        if (alpha)
+            acc += v * alpha[j];
+    }
+    if (beta) {
+        __shared__ double part[4][64];
+        part[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && ok)
+            beta[i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    }
+}
+
+// out_ij = scale * exp(n1_i + n1_j + log N(b_i - b_j | 0, C)), n x n; with alpha the
+// bilinear form sum_ij alpha_i alpha_j out_ij goes to acc[block] instead.
+template <int D>
+__global__ __launch_bounds__(256) void int_int_K1_K2_K1_kernel(const double *__restrict__ bpts,
+                                                               const double *__restrict__ n1v,
+                                                               int n, GaussForm<D> f, double scale,
+                                                               double *__restrict__ out,
+                                                               const double *__restrict__ alpha,
+                                                               double *__restrict__ acc)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    const bool ok = i < n;
+    double bi[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+        bi[k] = ok ? bpts[k + (long)i * D] : 0.0;
+    const double ni = ok ? n1v[i] : 0.0;
+    const double ai = (alpha && ok) ? alpha[i] : 0.0;
+    double sum = 0.0;
+    const int j0 = blockIdx.y * 256;
+    const int j1 = (j0 + 256 < n) ? j0 + 256 : n;
+    for (int j = j0 + wave; j < j1; j += 4) {
+        double z[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            z[k] = bi[k] - bpts[k + (long)j * D];
+        const double v = scale * exp(ni + n1v[j] + gauss_form_eval<D>(f, z));
+        if (out && ok)
+            out[i + (long)j * n] = v;
+        if (alpha)
+            sum += ai * v * alpha[j];
+    }
+    if (acc) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            sum += __shfl_down(sum, off, 64);
+        __shared__ double part[4];
+        if (lane == 0)
+            part[wave] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            acc[blockIdx.x + (long)blockIdx.y * gridDim.x] = (part[0] + part[1]) + (part[2] + part[3]);
+    }
+}
+
+// b_i = G x_i (D x D, row-major G), n1_i = log N(x_i - mu | 0, C1)
+template <int D>
+__global__ __launch_bounds__(256) void iikk_prepare_kernel(const double *__restrict__ x, int n,
+                                                           GaussForm<D> f1, GaussForm<D> g,
+                                                           double *__restrict__ bpts,
+                                                           double *__restrict__ n1v)
+{
+    // g.linv carries the full D x D matrix G (row-major), g.mu / g.logc unused
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    double xi[D], z[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        xi[k] = x[k + (long)i * D];
+        z[k] = xi[k] - f1.mu[k];
+    }
+    n1v[i] = gauss_form_eval<D>(f1, z);
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c)
+            s += g.linv[r * D + c] * xi[c];
+        bpts[r + (long)i * D] = s;
+    }
+}
+
+// out[0] = sum_k v[k]  (k < n), one block; out[1] = sum_k u[k] v[k] if u
+__global__ __launch_bounds__(256) void reduce_sum_kernel(const double *__restrict__ v,
+                                                         const double *__restrict__ u, int n,
+                                                         double *__restrict__ out)
+{
+    const int t = threadIdx.x;
+    double s = 0.0;
+    for (int k = t; k < n; k += 256)
+        s += u ? u[k] * v[k] : v[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        s += __shfl_down(s, off, 64);
+    __shared__ double part[4];
+    if ((t & 63) == 0)
+        part[t >> 6] = s;
+    __syncthreads();
+    if (t == 0)
+        out[0] = (part[0] + part[1]) + (part[2] + part[3]);
+}

@@ -176,6 +176,77 @@ class Engine(object):
                                                   x2.shape[1], d, float(h), L.dptr(w), L.dptr(K)))
         return K
 
+    # -- closed-form integrals (gauss_c), host arrays -------------------------
+    @staticmethod
+    def _mc(d, mu, cov):
+        mu = np.ascontiguousarray(np.atleast_1d(mu), dtype=np.float64)
+        cov = np.asfortranarray(np.atleast_2d(cov), dtype=np.float64)
+        if mu.shape != (d,):
+            raise ValueError("mu has invalid shape")
+        if cov.shape != (d, d):
+            raise ValueError("cov has invalid shape")
+        return mu, cov
+
+    def int_K(self, x, h, w, mu, cov):
+        x = _pts(x)
+        d, n = x.shape
+        w = _wvec(w, d)
+        mu, cov = self._mc(d, mu, cov)
+        out = np.empty(n)
+        self._check(self._lib.bq_int_K(self._ctx, L.dptr(x), d, n, float(h), L.dptr(w), L.dptr(mu),
+                                       L.dptr(cov), L.dptr(out)))
+        return out
+
+    def int_K1_K2(self, x1, x2, h1, w1, h2, w2, mu, cov):
+        x1, x2 = _pts(x1), _pts(x2)
+        d = x1.shape[0]
+        if x2.shape[0] != d:
+            raise ValueError("x2 has invalid shape")
+        w1, w2 = _wvec(w1, d), _wvec(w2, d)
+        mu, cov = self._mc(d, mu, cov)
+        out = np.empty((x1.shape[1], x2.shape[1]), order="F")
+        self._check(self._lib.bq_int_K1_K2(self._ctx, L.dptr(x1), x1.shape[1], L.dptr(x2),
+                                           x2.shape[1], d, float(h1), L.dptr(w1), float(h2),
+                                           L.dptr(w2), L.dptr(mu), L.dptr(cov), L.dptr(out)))
+        return out
+
+    def int_int_K1_K2_K1(self, x, h1, w1, h2, w2, mu, cov):
+        x = _pts(x)
+        d, n = x.shape
+        w1, w2 = _wvec(w1, d), _wvec(w2, d)
+        mu, cov = self._mc(d, mu, cov)
+        out = np.empty((n, n), order="F")
+        self._check(self._lib.bq_int_int_K1_K2_K1(self._ctx, L.dptr(x), d, n, float(h1), L.dptr(w1),
+                                                  float(h2), L.dptr(w2), L.dptr(mu), L.dptr(cov),
+                                                  L.dptr(out)))
+        return out
+
+    def int_int_K1_K2(self, x, h1, w1, h2, w2, mu, cov):
+        x = _pts(x)
+        d, n = x.shape
+        w1, w2 = _wvec(w1, d), _wvec(w2, d)
+        mu, cov = self._mc(d, mu, cov)
+        out = np.empty(n)
+        self._check(self._lib.bq_int_int_K1_K2(self._ctx, L.dptr(x), d, n, float(h1), L.dptr(w1),
+                                               float(h2), L.dptr(w2), L.dptr(mu), L.dptr(cov),
+                                               L.dptr(out)))
+        return out
+
+    # -- BQ moments on resident fits (bq_c) -------------------------------------
+    def Z_mean(self, fit_l, mu, cov):
+        mu, cov = self._mc(fit_l.d, mu, cov)
+        out = C.c_double()
+        self._check(self._lib.bq_bq_Z_mean(self._ctx, fit_l._h, L.dptr(mu), L.dptr(cov),
+                                           C.cast(C.byref(out), _dp)))
+        return float(out.value)
+
+    def Z_var(self, fit_tl, fit_l, mu, cov):
+        mu, cov = self._mc(fit_l.d, mu, cov)
+        out = C.c_double()
+        self._check(self._lib.bq_bq_Z_var(self._ctx, fit_tl._h, fit_l._h, L.dptr(mu), L.dptr(cov),
+                                          C.cast(C.byref(out), _dp)))
+        return float(out.value)
+
     # -- GP fits --------------------------------------------------------------
     def gp_fit(self, x, y, h, w, s=0.0):
         return Fit(self, x, y, h, w, s)
@@ -329,6 +400,17 @@ class Fit(object):
 
     def K(self):
         return self._get(3, (self.n, self.n))
+
+    def solve(self, B):
+        """Kxx^-1 B with the resident factor; B is (n,) or (n, nrhs)."""
+        B = np.asfortranarray(B, dtype=np.float64)
+        nrhs = 1 if B.ndim == 1 else B.shape[1]
+        if B.shape[0] != self.n:
+            raise ValueError("b has invalid size")
+        X = np.empty_like(B, order="F")
+        e = self._eng
+        e._check(e._lib.bq_gp_solve(e._ctx, self._h, L.dptr(B), nrhs, L.dptr(X)))
+        return X
 
     def predict(self, xo, want_mean=True, want_var=True, want_cov=False):
         xo = _pts(xo)

@@ -4,9 +4,9 @@ Mirror of the exact half of the reference's ``gauss_c`` module
 (gauss_c.pyx:20-164,235-339,416-531,617-713,796-855): same names, same argument
 order (caller-allocated output first), points ``d x n``, ``w``/``mu`` length-d,
 ``cov`` d x d.  Every result is "scale x exp(log-pdf of a small Gaussian)" over n or
-n^2 points; the d x d algebra is done once on the host and the per-point part is
-vectorised.  (SURVEY.md section 8f row 1 moves the per-point part onto the device;
-it is not part of the section-8a hot path.)
+n^2 points: the d x d algebra is done once on the host side of the C ABI, the
+per-point / per-pair work runs in HIP kernels.  The scalar
+helpers (``mvn_logpdf``, ``int_exp_norm``, ``int_int_K``) stay on the host.
 
 The trapezoid ``approx_*`` twins are out of scope (non-Gaussian kernels only).
 """
@@ -80,6 +80,11 @@ def int_exp_norm(c, m, S):
     return float(np.exp(out))
 
 
+def _eng():
+    from .engine import get_engine
+    return get_engine()
+
+
 def int_K(out, x, h, w, mu, cov):
     """out_i = h^2 N(x_i | mu, diag(w^2) + cov)   (gauss_c.pyx:95-164)."""
     x = _pts(x, "x")
@@ -87,8 +92,7 @@ def int_K(out, x, h, w, mu, cov):
     if out.shape[0] != n:
         raise ValueError("out has invalid shape")
     _check(d, w, mu, cov)
-    L = _chol(np.asarray(cov, dtype=np.float64) + np.diag(np.asarray(w) ** 2))
-    out[:] = (h ** 2) * np.exp(_logpdf_cols(x - np.asarray(mu)[:, None], L))
+    out[:] = _eng().int_K(x, h, w, mu, cov)
     return 0
 
 
@@ -105,14 +109,7 @@ def int_K1_K2(out, x1, x2, h1, w1, h2, w2, mu, cov):
     _check(d, w1, mu, cov, "w1")
     if w2.shape[0] != d:
         raise ValueError("w2 has invalid shape")
-    S = np.asarray(cov, dtype=np.float64)
-    C = np.block([[S + np.diag(np.asarray(w1) ** 2), S], [S, S + np.diag(np.asarray(w2) ** 2)]])
-    L = _chol(C)
-    m = np.asarray(mu, dtype=np.float64)[:, None]
-    D = np.empty((2 * d, n1 * n2))
-    D[:d] = np.repeat(x1 - m, n2, axis=1)          # pair (i, j) at column i * n2 + j
-    D[d:] = np.tile(x2 - m, (1, n1))
-    out[:, :] = ((h1 ** 2) * (h2 ** 2) * np.exp(_logpdf_cols(D, L))).reshape(n1, n2)
+    out[:, :] = _eng().int_K1_K2(x1, x2, h1, w1, h2, w2, mu, cov)
     return 0
 
 
@@ -127,18 +124,7 @@ def int_int_K1_K2_K1(out, x, h1, w1, h2, w2, mu, cov):
     _check(d, w1, mu, cov, "w1")
     if w2.shape[0] != d:
         raise ValueError("w2 has invalid shape")
-    S = np.asarray(cov, dtype=np.float64)
-    W1S = S + np.diag(np.asarray(w1) ** 2)
-    L1 = _chol(W1S)
-    G = np.linalg.solve(W1S, S).T            # S W1S^-1 (both symmetric)
-    A = G.dot(S)
-    B = G.dot(x)
-    N1 = _logpdf_cols(x - np.asarray(mu)[:, None], L1)
-    C = np.diag(np.asarray(w2) ** 2) + 2 * S - 2 * A
-    L2 = _chol(C)
-    D = (B[:, :, None] - B[:, None, :]).reshape(d, n * n)
-    N2 = _logpdf_cols(D, L2).reshape(n, n)
-    out[:, :] = (h1 ** 4) * (h2 ** 2) * np.exp(N1[:, None] + N1[None, :] + N2)
+    out[:, :] = _eng().int_int_K1_K2_K1(x, h1, w1, h2, w2, mu, cov)
     return 0
 
 
@@ -152,12 +138,7 @@ def int_int_K1_K2(out, x, h1, w1, h2, w2, mu, cov):
     _check(d, w1, mu, cov, "w1")
     if w2.shape[0] != d:
         raise ValueError("w2 has invalid shape")
-    S = np.asarray(cov, dtype=np.float64)
-    W = 2 * S + np.diag(np.asarray(w1) ** 2)
-    N = _logpdf_cols(np.zeros((d, 1)), _chol(W))[0]
-    C = np.diag(np.asarray(w2) ** 2) + S - S.dot(np.linalg.solve(W, S))
-    L = _chol(C)
-    out[:] = (h1 ** 2) * (h2 ** 2) * np.exp(N + _logpdf_cols(x - np.asarray(mu)[:, None], L))
+    out[:] = _eng().int_int_K1_K2(x, h1, w1, h2, w2, mu, cov)
     return 0
 
 

@@ -166,6 +166,35 @@ int bq_batch_fit_predict(bq_ctx *ctx, int64_t nprob, const double *x, const doub
                          const double *xo, int64_t M, double *mean, double *var, double *logml,
                          int32_t *status);
 
+/* ---- closed-form Gaussian-kernel integrals (gauss_c.pyx) ------------ */
+/* Host buffers in and out; points d x n, w / mu length d, cov d x d (symmetric).
+ * out_i = h^2 N(x_i | mu, diag(w^2) + cov)                       gauss_c.pyx:95-164 */
+int bq_int_K(bq_ctx *ctx, const double *x, int64_t d, int64_t n, double h, const double *w,
+             const double *mu, const double *cov, double *out);
+/* out (n1 x n2) = int K1(x1, x') K2(x', x2) N(x' | mu, cov) dx'    gauss_c.pyx:235-339 */
+int bq_int_K1_K2(bq_ctx *ctx, const double *x1, int64_t n1, const double *x2, int64_t n2,
+                 int64_t d, double h1, const double *w1, double h2, const double *w2,
+                 const double *mu, const double *cov, double *out);
+/* out (n x n) = int int K1 K2 K1                                   gauss_c.pyx:416-531 */
+int bq_int_int_K1_K2_K1(bq_ctx *ctx, const double *x, int64_t d, int64_t n, double h1,
+                        const double *w1, double h2, const double *w2, const double *mu,
+                        const double *cov, double *out);
+/* out (n) = int int K1 K2                                          gauss_c.pyx:617-713 */
+int bq_int_int_K1_K2(bq_ctx *ctx, const double *x, int64_t d, int64_t n, double h1,
+                     const double *w1, double h2, const double *w2, const double *mu,
+                     const double *cov, double *out);
+
+/* ---- BQ moments on device-resident fits (bq_c.pyx) ------------------- */
+/* X <- Kxx^-1 B with the resident factor of `fit`; B, X are n x nrhs (host) */
+int bq_gp_solve(bq_ctx *ctx, bq_fit *fit, const double *B, int64_t nrhs, double *X);
+/* E[Z] = (int K_l(x, x_sc) p(x) dx) . alpha_l, fused on the device: gp_l is the fit
+ * of the second GP (its points are x_sc)                           bq_c.pyx:157-213 */
+int bq_bq_Z_mean(bq_ctx *ctx, bq_fit *gp_l, const double *mu, const double *cov, double *out);
+/* V(Z) = alpha' (int int K_l K_tl K_l) alpha - beta' K_tl^-1 beta, beta =
+ * (int K_tl K_l) alpha; nothing n x n is materialised              bq_c.pyx:264-355 */
+int bq_bq_Z_var(bq_ctx *ctx, bq_fit *gp_log_l, bq_fit *gp_l, const double *mu, const double *cov,
+                double *out);
+
 /* ---- resident batch pipeline (what bench.py times) ------------------ */
 /* A plan owns device copies of the inputs and all workspaces, so that a run
  * starts with everything resident in HBM and only enqueues kernels. */

@@ -17,6 +17,7 @@ class FitDouble(object):
         self.x = np.asarray(x, dtype=np.float64)
         self.y = np.ascontiguousarray(y, dtype=np.float64)
         self.n = self.y.shape[0]
+        self.d = 1 if self.x.ndim == 1 else self.x.shape[0]
         self.refit(h, w, s)
 
     def refit(self, h, w, s):
@@ -34,6 +35,9 @@ class FitDouble(object):
 
     def z(self):
         return self.o.trsm_lower(self._L, self.y)
+
+    def solve(self, B):
+        return self.o.cho_solve(self._L, B)
 
     def K(self):
         return self.o.gram(self.x, self.h, self.w, self.s)
@@ -77,6 +81,25 @@ class EngineDouble(object):
 
     def gp_fit(self, x, y, h, w, s=0.0):
         return FitDouble(self.o, x, y, h, w, s)
+
+    def int_K(self, x, h, w, mu, cov):
+        return self.o.int_K(x, h, w, mu, cov)
+
+    def int_K1_K2(self, x1, x2, h1, w1, h2, w2, mu, cov):
+        return self.o.int_K1_K2(x1, x2, h1, w1, h2, w2, mu, cov)
+
+    def int_int_K1_K2_K1(self, x, h1, w1, h2, w2, mu, cov):
+        return self.o.int_int_K1_K2_K1(x, h1, w1, h2, w2, mu, cov)
+
+    def int_int_K1_K2(self, x, h1, w1, h2, w2, mu, cov):
+        return self.o.int_int_K1_K2(x, h1, w1, h2, w2, mu, cov)
+
+    def Z_mean(self, fit_l, mu, cov):
+        return self.o.Z_mean(fit_l.x, fit_l._alpha, fit_l.h, fit_l.w, mu, cov)
+
+    def Z_var(self, fit_tl, fit_l, mu, cov):
+        return self.o.Z_var(fit_tl.x, fit_l.x, fit_l._alpha, fit_tl._L, fit_l.h, fit_l.w,
+                            fit_tl.h, fit_tl.w, mu, cov)
 
     def batch_fit_predict(self, x, y, h, w, s, xo):
         P = len(x)

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     text = open(os.path.join(ROOT, "include", "bqhip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(bq_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(bq_[A-Za-z0-9_]+)\s*\(", text)))
 
 
 def test_header_symbols_exported():

@@ -335,3 +335,86 @@ def test_c4_size_cholesky_property(engine):
     ref = c["h"] ** 2 / (np.sqrt(2 * np.pi) * w[0]) * np.exp(-(x[i] - x[j]) ** 2 / (2 * w[0] ** 2)) \
         + (i == j) * c["s"] ** 2
     assert np.allclose(K[i, j], ref, rtol=1e-13, atol=0)
+
+
+# ---- closed-form integrals and BQ moments on the device ------
+MU1, COV1 = np.array([0.3]), np.array([[10.0]])
+
+
+@pytest.mark.parametrize("n", [1, 9, 63, 300, 1000])
+def test_device_integrals_1d(engine, oracle, n):
+    rs = np.random.RandomState(n)
+    x = np.sort(rs.uniform(-5, 5, n))
+    x2 = np.sort(rs.uniform(-6, 4, max(1, n // 2 + 3)))
+    w1, w2 = np.array([1.3]), np.array([2.0])
+    assert relmax(engine.int_K(x, 0.2, w1, MU1, COV1), oracle.int_K(x, 0.2, w1, MU1, COV1)) < 1e-13
+    assert relmax(engine.int_K1_K2(x, x2, 0.2, w1, 15.0, w2, MU1, COV1),
+                  oracle.int_K1_K2(x, x2, 0.2, w1, 15.0, w2, MU1, COV1)) < 1e-12
+    assert relmax(engine.int_int_K1_K2_K1(x, 0.2, w1, 15.0, w2, MU1, COV1),
+                  oracle.int_int_K1_K2_K1(x, 0.2, w1, 15.0, w2, MU1, COV1)) < 1e-12
+    assert relmax(engine.int_int_K1_K2(x, 0.2, w1, 15.0, w2, MU1, COV1),
+                  oracle.int_int_K1_K2(x, 0.2, w1, 15.0, w2, MU1, COV1)) < 1e-13
+
+
+@pytest.mark.parametrize("d", [2, 3, 8])
+def test_device_integrals_nd(engine, oracle, d):
+    rs = np.random.RandomState(d)
+    x = rs.uniform(-2, 2, (d, 70))
+    x2 = rs.uniform(-2, 2, (d, 41))
+    w1, w2 = rs.uniform(0.5, 1.5, d), rs.uniform(0.5, 1.5, d)
+    A = rs.rand(d, d)
+    cov = A.dot(A.T) + d * np.eye(d)
+    mu = rs.uniform(-0.5, 0.5, d)
+    assert relmax(engine.int_K(x, 0.7, w1, mu, cov), oracle.int_K(x, 0.7, w1, mu, cov)) < 1e-12
+    if d <= 4:   # the oracle's small-matrix buffers stop at 2d = 8
+        assert relmax(engine.int_K1_K2(x, x2, 0.7, w1, 1.2, w2, mu, cov),
+                      oracle.int_K1_K2(x, x2, 0.7, w1, 1.2, w2, mu, cov)) < 1e-11
+    assert relmax(engine.int_int_K1_K2_K1(x, 0.7, w1, 1.2, w2, mu, cov),
+                  oracle.int_int_K1_K2_K1(x, 0.7, w1, 1.2, w2, mu, cov)) < 1e-11
+    assert relmax(engine.int_int_K1_K2(x, 0.7, w1, 1.2, w2, mu, cov),
+                  oracle.int_int_K1_K2(x, 0.7, w1, 1.2, w2, mu, cov)) < 1e-12
+
+
+def test_device_moments_known_answers(engine, oracle):
+    """E[Z] and V(Z) of the reference's notebook fixture from device-resident fits."""
+    from fixture_chain import build_chain, known_answers
+    c = build_chain(lambda x, y, h, w, s: oracle.gp_fit(x, y, h, w, s),
+                    lambda x, h, w, L, a, xo: oracle.gp_predict(x, h, w, L, a, xo, want_var=False),
+                    oracle.filter_candidates)
+    f1 = engine.gp_fit(c["xs"], np.log(c["ls"]), c["h1"], c["w1"], 0.0)
+    f2 = engine.gp_fit(c["xsc"], c["lsc"], c["h2"], c["w2"], 0.0)
+    exp = known_answers()["expected"]
+    assert abs(engine.Z_mean(f2, c["mu"], c["cov"]) - exp["Z_mean"]["value"]) < 1e-12
+    zv = engine.Z_var(f1, f2, c["mu"], c["cov"])
+    assert abs(zv - exp["Z_var"]["value"]) / exp["Z_var"]["value"] < 1e-7
+    f1.close(), f2.close()
+
+
+@pytest.mark.parametrize("ns,nc", [(30, 5), (200, 17), (700, 64)])
+def test_device_moments_vs_oracle(engine, oracle, ns, nc):
+    rs = np.random.RandomState(ns)
+    dx = 10.0 / (ns - 1)
+    xs = np.linspace(-5, 5, ns) + rs.uniform(-dx / 4, dx / 4, ns)
+    ls = np.exp(wl.norm_logpdf(xs))
+    xc = np.sort(rs.uniform(-6, 6, nc))
+    h1, w1, s1 = 15.0, 1.5 * dx, 1e-3
+    h2, w2, s2 = 0.2, 1.5 * dx, 1e-3
+    L1, a1, _ = oracle.gp_fit(xs, np.log(ls), h1, w1, s1)
+    lc = np.exp(oracle.gp_predict(xs, h1, w1, L1, a1, xc, want_var=False))
+    xsc, lsc = np.concatenate([xs, xc]), np.concatenate([ls, lc])
+    L2, a2, _ = oracle.gp_fit(xsc, lsc, h2, w2, s2)
+    f1 = engine.gp_fit(xs, np.log(ls), h1, w1, s1)
+    f2 = engine.gp_fit(xsc, lsc, h2, w2, s2)
+    zm = oracle.Z_mean(xsc, a2, h2, w2, MU1, COV1)
+    assert abs(engine.Z_mean(f2, MU1, COV1) - zm) <= 1e-10 * abs(zm)
+    # V(Z) is a difference of two nearly equal terms: compare at the scale of the terms
+    I3 = oracle.int_int_K1_K2_K1(xsc, h2, w2, h1, w1, MU1, COV1)
+    t1 = a2.dot(I3).dot(a2)
+    zv = oracle.Z_var(xs, xsc, a2, L1, h2, w2, h1, w1, MU1, COV1)
+    assert abs(engine.Z_var(f1, f2, MU1, COV1) - zv) <= 1e-10 * abs(t1)
+    # resident solve
+    b = rs.randn(ns)
+    assert relmax(f1.solve(b), oracle.cho_solve(L1, b)) < 1e-9
+    B = rs.randn(ns, 3)
+    assert relmax(f1.solve(B), oracle.cho_solve(L1, B)) < 1e-9
+    f1.close(), f2.close()
