@@ -71,6 +71,8 @@ SIGNATURES = {
     "bq_gp_solve": (C.c_int, [_vp, _vp, _dp, _i64, _dp]),
     "bq_bq_Z_mean": (C.c_int, [_vp, _vp, _dp, _dp, _dp]),
     "bq_bq_Z_var": (C.c_int, [_vp, _vp, _vp, _dp, _dp, _dp]),
+    "bq_esm_batch": (C.c_int, [_vp, _dp, _dp, _i64, _i64, _dp, _i64, _dbl, _dbl, _dbl, _dp, _dp, _dp,
+                               _dp, _i32p]),
     "bq_plan_create": (C.c_int, [_vp, _i64, _i64, _i64, _i64, C.POINTER(_vp)]),
     "bq_plan_destroy": (None, [_vp, _vp]),
     "bq_plan_set_inputs": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp, _dp, _dp]),

@@ -144,65 +144,82 @@ class BQ(object):
         return second_moment - self.expected_squared_mean(x_a)
 
     def expected_squared_mean(self, x_a):
-        x_a = np.asarray(x_a, dtype=DTYPE)
-        return np.array([self._esm_and_em(x_a[[i]])[0] for i in range(x_a.shape[0])])
+        return self._esm_and_em_batch(x_a)[:, 0].copy()
 
     def expected_mean(self, x_a):
-        x_a = np.asarray(x_a, dtype=DTYPE)
-        return np.array([self._esm_and_em(x_a[[i]])[1] for i in range(x_a.shape[0])])
+        return self._esm_and_em_batch(x_a)[:, 1].copy()
 
     def expected_squared_mean_and_mean(self, x_a):
-        x_a = np.asarray(x_a, dtype=DTYPE)
-        out = np.empty((x_a.shape[0], 2))
-        for i in range(x_a.shape[0]):
-            out[i] = self._esm_and_em(x_a[[i]])
-        return out
-
-    def _current_mean_pair(self):
-        em = self.Z_mean()
-        return em ** 2, em
+        return self._esm_and_em_batch(x_a)
 
     def _esm_and_em(self, x_a):
         """(E[m(Z)^2], E[m(Z)]) after a hypothetical observation at the single
         point x_a (bq.py:447-527)."""
-        self._require_exact()
-        if x_a is None or np.isnan(x_a) or np.isinf(x_a):
+        if x_a is None:
             raise ValueError("invalid value for x_a: %s" % x_a)
-        # a point we (almost) already have cannot move the mean
-        if np.isclose(x_a, self.x_s, atol=1e-4).any():
-            return self._current_mean_pair()
-
-        x_sca = np.concatenate([self.x_sc, x_a])
-        K_l = self.gp_l.Kxoxo(x_sca)
-        jitter = np.zeros(self.nsc + 1)
-        # candidates near x_a are the ones most likely to change: loosen them,
-        # and always loosen the new point itself
-        close = np.abs(self.x_c - x_a) < self.options["candidate_thresh"]
-        if close.any():
-            bq_c.improve_covariance_conditioning(K_l, jitter, np.nonzero(close)[0] + self.ns)
-        bq_c.improve_covariance_conditioning(K_l, jitter, np.array([self.nsc]))
-
-        L = np.empty(K_l.shape, order="F")
-        try:
-            la.cho_factor(np.array(K_l, order="F"), L)
-        except np.linalg.LinAlgError:
-            # singular: x_a duplicates information we have, the mean will not move
-            return self._current_mean_pair()
-
-        tm_a, tC_a = self.gp_log_l.mean_var(x_a)
-        esm, em = bq_c.expected_squared_mean_and_mean(
-            self.l_sc, L, tm_a, tC_a, _row(x_sca), self.gp_l.K.h, np.array([self.gp_l.K.w]),
-            self.options["x_mean"], np.array(self.options["x_cov"], order="F"))
-
-        if np.isnan(esm) or esm < 0:
-            raise RuntimeError("invalid expected squared mean for x_a=%s: %s" % (x_a, esm))
-        if np.isnan(em):
-            raise RuntimeError("invalid expected mean for x_a=%s: %s" % (x_a, em))
-        if np.isinf(esm):
-            logger.warning("expected squared mean for x_a=%s is infinity!", x_a)
-        if np.isinf(em):
-            logger.warning("expected mean for x_a=%s is infinity!", x_a)
+        esm, em = self._esm_and_em_batch(np.atleast_1d(np.asarray(x_a, dtype=DTYPE)))[0]
         return esm, em
+
+    def _esm_and_em_batch(self, x_a):
+        """All candidates of x_a at once.  The reference loops over them and
+        re-factors an (nsc+1)^2 Gram for each (bq.py:399-402,447-527); here the
+        bordered systems are assembled and factored in one batched launch sequence
+        (bq_esm_batch) and the closed forms of bq_c.pyx:425-490 are applied to the
+        results.  Same short-circuit, jitter and fallback rules."""
+        self._require_exact()
+        x_a = np.atleast_1d(np.asarray(x_a, dtype=DTYPE))
+        if x_a.ndim != 1 or np.isnan(x_a).any() or np.isinf(x_a).any():
+            raise ValueError("invalid value for x_a: %s" % x_a)
+        M = x_a.shape[0]
+        out = np.empty((M, 2))
+        current = None  # (Z_mean^2, Z_mean), computed only if some candidate needs it
+
+        def fallback(rows):
+            nonlocal current
+            if current is None:
+                em = self.Z_mean()
+                current = (em ** 2, em)
+            out[rows] = current
+
+        # a point we (almost) already have cannot move the mean (bq.py:456-459)
+        near = np.isclose(x_a[:, None], self.x_s[None, :], atol=1e-4).any(axis=1)
+        if near.any():
+            fallback(near)
+        idx = np.nonzero(~near)[0]
+        if idx.size == 0:
+            return out
+        xa = np.ascontiguousarray(x_a[idx])
+        A_a, A_sc_l, status = get_engine().esm_batch(
+            self.x_sc, self.l_sc, self.ns, xa, self.gp_l.K.h, self.gp_l.K.w,
+            self.options["candidate_thresh"], self.options["x_mean"], self.options["x_cov"])
+        tm_a, tC_a = self.gp_log_l.mean_var(xa)
+        # int exp(c x) N(x | m, S) dx = exp(c m + c^2 S / 2), saturating (gauss_c.pyx:65-92)
+        arg1 = tm_a + 0.5 * tC_a
+        arg2 = 2.0 * tm_a + 2.0 * tC_a
+        with np.errstate(over="ignore", invalid="ignore"):
+            e1 = np.where(arg1 > MAX, np.inf, np.exp(np.minimum(arg1, MAX)))
+            e2 = np.where(arg2 > MAX, np.inf, np.exp(np.minimum(arg2, MAX)))
+            em = A_sc_l + A_a * e1
+            esm = (A_sc_l ** 2) + (2 * A_sc_l * A_a * e1) + (A_a ** 2 * e2)
+        esm = np.where(np.isinf(e1) | np.isinf(e2), np.inf, esm)
+        em = np.where(np.isinf(e1), np.inf, em)
+        ok = status == 0
+        for k in np.nonzero(ok)[0]:
+            if np.isnan(esm[k]) or esm[k] < 0:
+                raise RuntimeError(
+                    "invalid expected squared mean for x_a=%s: %s" % (xa[k], esm[k]))
+            if np.isnan(em[k]):
+                raise RuntimeError("invalid expected mean for x_a=%s: %s" % (xa[k], em[k]))
+            if np.isinf(esm[k]):
+                logger.warning("expected squared mean for x_a=%s is infinity!", xa[k])
+            if np.isinf(em[k]):
+                logger.warning("expected mean for x_a=%s is infinity!", xa[k])
+        out[idx[ok], 0] = esm[ok]
+        out[idx[ok], 1] = em[ok]
+        if (~ok).any():
+            # singular system: x_a duplicates information we have (bq.py:481-490)
+            fallback(idx[~ok])
+        return out
 
     # ------------------------------------------------------- hyper-parameters
     def _make_llh_params(self, params):

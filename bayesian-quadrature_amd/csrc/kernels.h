@@ -1491,3 +1491,94 @@ __global__ __launch_bounds__(256) void reduce_sum_kernel(const double *__restric
     if (t == 0)
         out[0] = (part[0] + part[1]) + (part[2] + part[3]);
 }
+
+// ===========================================================================
+// Batched expected-squared-mean systems (bq.py:447-527, bq_c.pyx:425-535).
+// Batch element a is the Gram of the nsc points x_sc plus the candidate x_a[a]
+// (no noise term: gp.Kxoxo), with the reference's jitter on the diagonal --
+// jit1[a] on the candidates within `thresh` of x_a[a], jit2[a] on the new point
+// (bq_c.pyx:127-140) -- bordered by two rows: int K(x_sca) p(x) dx and [l_sc, 0].
+// After eliminating the npad columns, A_a and A_sc . l_sc are read off the panel
+// and the Schur complement (esm_finalize_kernel); no back substitution.
+// ===========================================================================
+struct EsmLayout {
+    int ns, nsc, npad, ntot; // points [0, nsc] (nsc+1 of them), border rows npad, npad+1
+};
+
+__global__ __launch_bounds__(256) void assemble_esm_kernel(const double *__restrict__ x_sc,
+                                                           const double *__restrict__ x_a,
+                                                           const double *__restrict__ intk_sc,
+                                                           const double *__restrict__ intk_a,
+                                                           const double *__restrict__ l_sc,
+                                                           const double *__restrict__ jit1,
+                                                           const double *__restrict__ jit2,
+                                                           double thresh, GaussParams g,
+                                                           double *__restrict__ A, long lda,
+                                                           long astride, EsmLayout L)
+{
+    const int b = blockIdx.z;
+    const int t = threadIdx.x;
+    const int ib = blockIdx.x * 128, jb = blockIdx.y * 64;
+    if (jb > ib + 127)
+        return;
+    A += (long)b * astride;
+    const double xa = x_a[b];
+    const int n1 = L.nsc + 1;
+    const int i = ib + (t & 63) * 2;
+    const int jbase = jb + (t >> 6) * 16;
+    if (i >= L.ntot)
+        return;
+    double xi[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int ii = i + r;
+        xi[r] = ii < L.nsc ? x_sc[ii] : xa;
+    }
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = jbase + jj;
+        if (j >= L.ntot)
+            break;
+        const double xj = j < L.nsc ? x_sc[j] : xa;
+        double v[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int ii = i + r;
+            double val;
+            if (ii < n1 && j < n1) {
+                const double tdiff = xi[r] - xj;
+                val = g.c * exp_gauss((tdiff * tdiff) * g.nh[0]);
+                if (ii == j) {
+                    if (ii == L.nsc)
+                        val += jit2[b];
+                    else if (ii >= L.ns && fabs(xi[r] - xa) < thresh)
+                        val += jit1[b];
+                }
+            } else if (ii == L.npad) {
+                val = j < L.nsc ? intk_sc[j] : (j == L.nsc ? intk_a[b] : 0.0);
+            } else if (ii == L.npad + 1) {
+                val = j < L.nsc ? l_sc[j] : 0.0;
+            } else {
+                val = (ii == j) ? 1.0 : 0.0;
+            }
+            v[r] = val;
+        }
+        double2_t vv = {v[0], v[1]};
+        *reinterpret_cast<double2_t *>(A + i + (long)j * lda) = vv;
+    }
+}
+
+// out[2b] = A_a = (K^-1 intK)[last], out[2b+1] = A_sc . l_sc
+__global__ void esm_finalize_kernel(const double *__restrict__ A, long lda, long astride,
+                                    EsmLayout L, int batch, double *__restrict__ out)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch)
+        return;
+    const double *Ab = A + (long)b * astride;
+    const double z_last = Ab[L.npad + (long)L.nsc * lda];
+    const double l_last = Ab[L.nsc + (long)L.nsc * lda];
+    // A = L^-T z: the last component is z_last / L_nn
+    out[2 * b] = z_last / l_last;
+    // (L^-1 [l_sc, 0]) . z  sits, negated, in the Schur complement at (npad+1, npad)
+    out[2 * b + 1] = -Ab[(L.npad + 1) + (long)L.npad * lda];
+}

@@ -247,6 +247,21 @@ class Engine(object):
                                           C.cast(C.byref(out), _dp)))
         return float(out.value)
 
+    def esm_batch(self, x_sc, l_sc, ns, x_a, h, w, thresh, mu, cov):
+        """(A_a, A_sc_l, status) for every candidate of x_a (1-D); see bq_esm_batch."""
+        x_sc = np.ascontiguousarray(x_sc, dtype=np.float64)
+        l_sc = np.ascontiguousarray(l_sc, dtype=np.float64)
+        x_a = np.ascontiguousarray(x_a, dtype=np.float64)
+        mu, cov = self._mc(1, mu, cov)
+        M = x_a.shape[0]
+        A_a, A_sc_l = np.empty(M), np.empty(M)
+        status = np.zeros(M, dtype=np.int32)
+        self._check(self._lib.bq_esm_batch(
+            self._ctx, L.dptr(x_sc), L.dptr(l_sc), int(ns), x_sc.shape[0], L.dptr(x_a), M,
+            float(h), float(w), float(thresh), L.dptr(mu), L.dptr(cov), L.dptr(A_a),
+            L.dptr(A_sc_l), status.ctypes.data_as(L._i32p)))
+        return A_a, A_sc_l, status
+
     # -- GP fits --------------------------------------------------------------
     def gp_fit(self, x, y, h, w, s=0.0):
         return Fit(self, x, y, h, w, s)

@@ -195,6 +195,17 @@ int bq_bq_Z_mean(bq_ctx *ctx, bq_fit *gp_l, const double *mu, const double *cov,
 int bq_bq_Z_var(bq_ctx *ctx, bq_fit *gp_log_l, bq_fit *gp_l, const double *mu, const double *cov,
                 double *out);
 
+/* Active-sampling acquisition, batched over M candidate locations x_a (1-D):
+ * for each a, the Gram of [x_sc, x_a[a]] (no noise, the reference's jitter on the
+ * candidates within `thresh` of x_a[a] and on the new point) is factored and
+ * A = K^-1 int K p is reduced to A_a[a] = A[last] and A_sc_l[a] = A[:nsc] . l_sc
+ * -- the two numbers bq_c._esm_and_em needs (bq.py:447-527, bq_c.pyx:425-490).
+ * One batched bordered Cholesky instead of M sequential refactorisations.
+ * status[a] > 0: the system of candidate a is not positive definite. */
+int bq_esm_batch(bq_ctx *ctx, const double *x_sc, const double *l_sc, int64_t ns, int64_t nsc,
+                 const double *x_a, int64_t M, double h, double w, double thresh, const double *mu,
+                 const double *cov, double *A_a, double *A_sc_l, int32_t *status);
+
 /* ---- resident batch pipeline (what bench.py times) ------------------ */
 /* A plan owns device copies of the inputs and all workspaces, so that a run
  * starts with everything resident in HBM and only enqueues kernels. */

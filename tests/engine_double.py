@@ -94,6 +94,32 @@ class EngineDouble(object):
     def int_int_K1_K2(self, x, h1, w1, h2, w2, mu, cov):
         return self.o.int_int_K1_K2(x, h1, w1, h2, w2, mu, cov)
 
+    def esm_batch(self, x_sc, l_sc, ns, x_a, h, w, thresh, mu, cov):
+        """The reference's per-candidate recipe (bq.py:462-480, bq_c.pyx:425-455)."""
+        x_sc = np.asarray(x_sc, dtype=np.float64)
+        nsc = x_sc.shape[0]
+        M = len(x_a)
+        A_a, A_sc_l = np.empty(M), np.empty(M)
+        status = np.zeros(M, dtype=np.int32)
+        for k in range(M):
+            x_sca = np.concatenate([x_sc, [x_a[k]]])
+            K = np.ascontiguousarray(self.o.gram_cross(x_sca, x_sca, h, w))
+            jitter = np.zeros(nsc + 1)
+            close = np.abs(x_sc[ns:] - x_a[k]) < thresh
+            if close.any():
+                self.o.improve_covariance_conditioning(K, jitter, np.nonzero(close)[0] + ns)
+            self.o.improve_covariance_conditioning(K, jitter, np.array([nsc]))
+            try:
+                L = self.o.cho_factor(K)
+            except np.linalg.LinAlgError:
+                status[k] = 1
+                A_a[k] = A_sc_l[k] = np.nan
+                continue
+            A = self.o.cho_solve(L, self.o.int_K(x_sca, h, w, mu, cov))
+            A_a[k] = A[nsc]
+            A_sc_l[k] = A[:nsc].dot(l_sc)
+        return A_a, A_sc_l, status
+
     def Z_mean(self, fit_l, mu, cov):
         return self.o.Z_mean(fit_l.x, fit_l._alpha, fit_l.h, fit_l.w, mu, cov)
 

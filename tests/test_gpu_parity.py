@@ -418,3 +418,66 @@ def test_device_moments_vs_oracle(engine, oracle, ns, nc):
     B = rs.randn(ns, 3)
     assert relmax(f1.solve(B), oracle.cho_solve(L1, B)) < 1e-9
     f1.close(), f2.close()
+
+
+# ---- batched active-sampling systems ---------------------------
+@pytest.mark.parametrize("ns,nc,M", [(9, 2, 25), (60, 8, 40), (300, 20, 64)])
+def test_esm_batch_vs_reference_recipe(engine, oracle, ns, nc, M):
+    from engine_double import EngineDouble
+    rs = np.random.RandomState(ns + M)
+    from bayesian_quadrature_amd import bq_c
+    xs = np.linspace(-5, 5, ns)
+    dx = 10.0 / (ns - 1)
+    # candidates as BQ._choose_candidates makes them: spaced from the samples and
+    # from each other (here by 0.4 dx so that some survive on a fine grid)
+    xc = rs.uniform(-6, 6, 4 * nc)
+    bq_c.filter_candidates(xc, xs, 0.4 * dx)
+    xc = np.sort(xc[~np.isnan(xc)])[:nc]
+    x_sc = np.concatenate([xs, xc])
+    l_sc = np.exp(wl.norm_logpdf(x_sc))
+    # candidates: random, plus some within candidate_thresh of a candidate point and one
+    # nearly on top of a sample (a near-singular bordered system)
+    x_a = np.concatenate([rs.uniform(-7, 7, M - 3), xc[:2] + 0.05, [xs[3] + 2e-4]])
+    h, w, thresh = 0.2, 1.04 * dx, 0.5     # w ~ dx: the conditioning regime of the configs
+    ref = EngineDouble(oracle).esm_batch(x_sc, l_sc, ns, x_a, h, w, thresh, MU1, COV1)
+    got = engine.esm_batch(x_sc, l_sc, ns, x_a, h, w, thresh, MU1, COV1)
+    assert (got[2] == 0).all() and (ref[2] == 0).all()
+    # the solved coefficients are conditioned like K_l^-1: compare at cond * eps
+    K = oracle.gram_cross(x_sc, x_sc, h, w)
+    tol = max(1e-10, 50 * np.linalg.cond(K + 1e-4 * K.max() * np.eye(len(x_sc))) * 2.2e-16)
+    scale = max(np.abs(ref[0]).max(), np.abs(ref[1]).max())
+    assert np.max(np.abs(got[0] - ref[0])) <= tol * scale
+    assert np.max(np.abs(got[1] - ref[1])) <= tol * scale
+
+
+def test_bq_expected_moments_gpu_vs_double(engine, oracle):
+    """The whole BQ acquisition path: HIP engine against the oracle-backed double."""
+    import bayesian_quadrature_amd as pkg
+    from bayesian_quadrature_amd import engine as eng_mod
+    from engine_double import EngineDouble
+    import scipy.stats
+    x = np.linspace(-5, 5, 9)
+    opts = dict(n_candidate=10, x_mean=0.0, x_var=10.0, candidate_thresh=0.5,
+                optim_method="L-BFGS-B", kernel=pkg.GaussianKernel)
+    x_a = np.concatenate([np.linspace(-8, 8, 37), x[:2], [np.nextafter(x[4], 9)]])
+    res = {}
+    saved = dict(eng_mod._engines)
+    try:
+        for name, eng in (("double", EngineDouble(oracle)), ("gpu", engine)):
+            eng_mod._engines.clear()
+            eng_mod.set_engine(eng, 0)
+            np.random.seed(8728)
+            bq = pkg.BQ(x, scipy.stats.norm.pdf(x), **opts)
+            bq.init(params_tl=(15, 2, 0), params_l=(0.2, 1.3, 0))
+            res[name] = (bq.Z_mean(), bq.Z_var(), bq.expected_squared_mean_and_mean(x_a),
+                         bq.expected_Z_var(x_a), bq.l_mean(x_a), bq.l_var(x_a))
+    finally:
+        eng_mod._engines.clear()
+        eng_mod._engines.update(saved)
+    d, g = res["double"], res["gpu"]
+    assert abs(d[0] - g[0]) <= 1e-10 * abs(d[0])
+    assert abs(d[1] - g[1]) <= 1e-6 * abs(d[1])     # cancellation-limited, see DESIGN.md
+    assert np.allclose(d[2], g[2], rtol=1e-8, atol=1e-14)
+    assert np.allclose(d[3], g[3], rtol=1e-8, atol=1e-9 * d[0] ** 2)
+    assert np.allclose(d[4], g[4], rtol=1e-9, atol=1e-13)
+    assert np.allclose(d[5], g[5], rtol=1e-6, atol=1e-13)
