@@ -79,6 +79,7 @@ class GP(object):
     def __init__(self, K, x, y, s=0):
         self._memoized = {}
         self._fit = None
+        self._fit_params = None
         self.K = K
         self._x = None
         self._y = None
@@ -88,12 +89,16 @@ class GP(object):
         self.s = s
 
     # -- memoisation ----------------------------------------------------------
-    def _invalidate(self):
+    def _invalidate(self, data_changed=True):
+        """Drop every cached quantity.  The device fit object survives a pure
+        parameter change: it keeps x and y resident and is re-factored in place
+        (bq_gp_refit) on next use -- the hyper-parameter loop's common case."""
         self._memoized = {}
         fit = getattr(self, "_fit", None)
-        if fit is not None:
+        if fit is not None and data_changed:
             fit.close()
-        self._fit = None
+            self._fit = None
+        self._fit_params = None
 
     def _memo(self, key, fn):
         if key not in self._memoized:
@@ -102,8 +107,17 @@ class GP(object):
 
     def _device_fit(self):
         """Gram + Cholesky + z + log-ML on the GPU; raises LinAlgError."""
+        params = (self.K.h, self.K.w, self._s)
         if self._fit is None:
-            self._fit = get_engine().gp_fit(self._x, self._y, self.K.h, self.K.w, self._s)
+            self._fit = get_engine().gp_fit(self._x, self._y, *params)
+            self._fit_params = params
+        elif self._fit_params != params:
+            try:
+                self._fit.refit(*params)
+            except Exception:
+                self._fit_params = None
+                raise
+            self._fit_params = params
         return self._fit
 
     # -- data and parameters --------------------------------------------------
@@ -146,7 +160,7 @@ class GP(object):
             raise ValueError("invalid value for s: %s" % val)
         if self._s is not None and val == self._s:
             return
-        self._invalidate()
+        self._invalidate(data_changed=False)
         self._s = val
 
     @property
@@ -171,7 +185,7 @@ class GP(object):
         if float(val) == getattr(self.K, name):
             return
         self.K.set_param(name, val)  # ValueError on invalid values (bq.py:539-543)
-        self._invalidate()
+        self._invalidate(data_changed=False)
 
     def copy(self, deep=True):
         new = GP(self.K.copy(), self._x, self._y, s=self._s)
@@ -244,6 +258,7 @@ class GP(object):
     def __setstate__(self, state):
         self._memoized = {}
         self._fit = None
+        self._fit_params = None
         self.K = state["K"]
         self._x, self._y, self._s = state["x"], state["y"], state["s"]
         if "jitter" in state:

@@ -323,6 +323,41 @@ def extras(eng, nb_override):
             eng.free(info)
         eng.free(xd)
         eng.free(Kd)
+    out.update(batched_configs(eng))
+    return out
+
+
+def batched_configs(eng):
+    """The two batched BASELINE configs on this one GPU, for the record (not the
+    headline): a C5 shard (64 of the 512 problems, N=2048, M=256) and the C3
+    hyper-grid (20 x 20 log-MLs at N=4096, d=2)."""
+    from bayesian_quadrature_amd import workloads as wl
+    out = {}
+    B = 64
+    c = wl.c5(list(range(B)))
+    plan = eng.plan(B, 1, 2048, 256)
+    plan.set_inputs(c["x"], c["y"], c["xo"], c["h"], c["w"], c["s"])
+    plan.run()
+    eng.sync()
+    eng.timer_start()
+    for _ in range(3):
+        plan.run()
+    ms = eng.timer_stop_ms() / 3
+    status = plan.results()[3]
+    plan.close()
+    flops = B * ((2048 + 64) ** 3 / 3.0)   # the factorisation alone, per problem N^3/3
+    out["c5_shard_64x2048"] = {"ms_per_batch": ms, "problems_per_s": B / ms * 1e3,
+                               "failed": int((status != 0).sum()),
+                               "potrf_tflops_lower_bound": flops / (ms * 1e-3) / 1e12}
+    c3 = wl.c3()
+    t0 = time.perf_counter()
+    lm = eng.logml_grid(c3["x"], c3["y"], c3["h"], c3["w"], c3["s"], chunk=100)
+    wall = time.perf_counter() - t0
+    out["c3_grid_400x4096"] = {"wall_ms": wall * 1e3, "ms_per_point": wall * 1e3 / len(lm),
+                               "n_minus_inf": int(np.isinf(lm).sum()),
+                               "potrf_tflops_lower_bound": len(lm) * (4096 ** 3 / 3.0) / wall / 1e12,
+                               "note": "host wall clock incl. the upload of the 400 parameter "
+                                       "sets and the read-back of the 400 results"}
     return out
 
 
