@@ -78,6 +78,7 @@ struct bq_ctx {
     hipEvent_t ev_panel = nullptr, ev_next = nullptr, ev_fork = nullptr;
     int lookahead = 1;
     int potf2_waves = 4; // 4: potf2_64x4_kernel, 1: potf2_64_kernel (BQ_POTF2_WAVES)
+    int fuse = 1;        // diagonal factor fused into the launch that last updates it (BQ_FUSE)
     int gram_nt = 0;     // non-temporal stores in the Gram kernel (BQ_GRAM_NT)
     int use_graph = 1;   // replay plans from a captured hipGraph (BQ_GRAPH=0 disables)
     bool own_stream = false;
@@ -289,9 +290,12 @@ int launch_assemble(bq_ctx *c, int d, const double *pts, long pstride, const dou
 }
 
 // C(m x n) -= P(m x k) Q(n x k)^T; tile shape from the amount of parallelism
+// fuse_j0 >= 0: also factor the leading 64x64 block of C (global column fuse_j0) in the
+// same launch (see gemm_sub_kernel); dinv / info as for launch_potf2
 int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const double *P, long ldp,
                 long pstride, const double *Q, long qsj, long qsk, long qstride, int m, int n,
-                int k, int lower, int batch)
+                int k, int lower, int batch, int fuse_j0 = -1, double *dinv = nullptr,
+                long dstride = 0, int *info = nullptr)
 {
     if (m <= 0 || n <= 0 || k <= 0)
         return BQ_OK;
@@ -318,21 +322,26 @@ int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const dou
     };
     if (tiles(128) >= cu) {
         hipLaunchKernelGGL((gemm_sub_kernel<4, 4>), grid_for(128), dim3(256), 0, c->cur, C, ldc,
-                           cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, mode);
+                           cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, mode, fuse_j0, dinv,
+                           dstride, info);
     } else if (tiles(64) >= cu / 2) {
         if (k == 64)
             hipLaunchKernelGGL((gemm_k64_kernel<2, 2>), grid_for(64), dim3(256), 0, c->cur, C, ldc,
-                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, mode);
+                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, mode, fuse_j0, dinv, dstride,
+                               info);
         else
             hipLaunchKernelGGL((gemm_sub_kernel<2, 2>), grid_for(64), dim3(256), 0, c->cur, C, ldc,
-                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, mode);
+                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, mode, fuse_j0, dinv,
+                           dstride, info);
     } else {
         if (k == 64)
             hipLaunchKernelGGL((gemm_k64_kernel<1, 1>), grid_for(32), dim3(256), 0, c->cur, C, ldc,
-                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, mode);
+                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, mode, fuse_j0, dinv, dstride,
+                               info);
         else
             hipLaunchKernelGGL((gemm_sub_kernel<1, 1>), grid_for(32), dim3(256), 0, c->cur, C, ldc,
-                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, mode);
+                               cstride, P, ldp, pstride, Q, qsj, qsk, qstride, m, n, k, mode, fuse_j0, dinv,
+                           dstride, info);
     }
     HIPCHK(c, hipGetLastError());
     return BQ_OK;
@@ -387,17 +396,24 @@ int auto_nb(const bq_ctx *c, int ntot, int batch)
 }
 
 // the 64-column slabs of one outer block [K0, K0+KB): left-looking update, diagonal
-// factor, panel solve -- enqueued on c->cur
+// factor, panel solve -- enqueued on c->cur.  With fusion on, the diagonal factor of a
+// slab rides in the launch that last updates it (the slab update here, or the
+// trailing update of the previous block: `diag_done`).
 int enqueue_panel(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot, int K0,
-                  int KB, double *dinv, int *info)
+                  int KB, double *dinv, int *info, bool diag_done)
 {
     for (int j0 = K0; j0 < K0 + KB; j0 += 64) {
         double *Ajj = A + j0 + (long)j0 * lda;
-        if (j0 > K0)
+        if (j0 > K0) {
+            const int fj = c->fuse ? j0 : -1;
             BQCHK(launch_gemm(c, BQ_K_GEMM, Ajj, lda, astride, A + j0 + (long)K0 * lda, lda,
                               astride, A + j0 + (long)K0 * lda, 1, lda, astride, ntot - j0, 64,
-                              j0 - K0, 0, batch));
-        BQCHK(launch_potf2(c, A, lda, astride, j0, dinv, 64, info, batch));
+                              j0 - K0, 0, batch, fj, dinv, 64, info));
+            if (fj < 0)
+                BQCHK(launch_potf2(c, A, lda, astride, j0, dinv, 64, info, batch));
+        } else if (!diag_done) {
+            BQCHK(launch_potf2(c, A, lda, astride, j0, dinv, 64, info, batch));
+        }
         BQCHK(launch_trsm<true>(c, Ajj + 64, lda, astride, ntot - j0 - 64, Ajj, lda, astride, dinv,
                                 64, batch));
     }
@@ -422,15 +438,20 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
     const int NB = auto_nb(c, ntot, batch);
     const bool la = c->lookahead && c->aux && NB >= 128 && ncols > NB;
     if (!la) {
+        bool diag_done = false;
         for (int K0 = 0; K0 < ncols; K0 += NB) {
             const int KB = std::min(NB, ncols - K0);
-            BQCHK(enqueue_panel(c, A, lda, astride, batch, ntot, K0, KB, dinv, info));
+            BQCHK(enqueue_panel(c, A, lda, astride, batch, ntot, K0, KB, dinv, info, diag_done));
             const int r0 = K0 + KB;
+            diag_done = false;
             if (r0 < ntot) {
                 const double *P = A + r0 + (long)K0 * lda;
+                // the trailing update also factors the next diagonal block if there is one
+                const int fj = (c->fuse && r0 < ncols) ? r0 : -1;
                 BQCHK(launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda,
-                                  astride, P, 1, lda, astride, ntot - r0, ntot - r0, KB, 1,
-                                  batch));
+                                  astride, P, 1, lda, astride, ntot - r0, ntot - r0, KB, 1, batch,
+                                  fj, dinv, 64, info));
+                diag_done = fj >= 0;
             }
         }
         return BQ_OK;
@@ -441,7 +462,7 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
     int st = BQ_OK;
     // aux stream: panel 0
     c->cur = c->aux;
-    st = enqueue_panel(c, A, lda, astride, batch, ntot, 0, std::min(NB, ncols), dinv, info);
+    st = enqueue_panel(c, A, lda, astride, batch, ntot, 0, std::min(NB, ncols), dinv, info, false);
     c->cur = c->stream;
     if (st != BQ_OK)
         return st;
@@ -462,10 +483,11 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
             if (have_b)
                 HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_next, 0));
             c->cur = c->aux;
+            const int fj = c->fuse ? r0 : -1;
             st = launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda, astride,
-                             P, 1, lda, astride, ntot - r0, nw, KB, 1, batch);
+                             P, 1, lda, astride, ntot - r0, nw, KB, 1, batch, fj, dinv, 64, info);
             if (st == BQ_OK)
-                st = enqueue_panel(c, A, lda, astride, batch, ntot, r0, nw, dinv, info);
+                st = enqueue_panel(c, A, lda, astride, batch, ntot, r0, nw, dinv, info, fj >= 0);
             c->cur = c->stream;
             if (st != BQ_OK)
                 break;
@@ -577,6 +599,8 @@ static int ctx_init(bq_ctx *c, int device)
     HIPCHK(c, hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, hi));
     if (const char *e = std::getenv("BQ_LOOKAHEAD"))
         c->lookahead = std::atoi(e);
+    if (const char *e = std::getenv("BQ_FUSE"))
+        c->fuse = std::atoi(e);
     if (const char *e = std::getenv("BQ_GRAM_NT"))
         c->gram_nt = std::atoi(e);
     if (const char *e = std::getenv("BQ_GRAPH"))
@@ -1211,14 +1235,14 @@ extern "C" int bq_plan_run(bq_ctx *c, bq_plan *p)
         return plan_enqueue(c, p);
     // settings that change the launch sequence invalidate the captured graph
     if (p->graph_state == 1 && (p->graph_nb != c->nb_override || p->graph_la != c->lookahead ||
-                                p->graph_pw != c->potf2_waves)) {
+                                p->graph_pw != c->potf2_waves * 2 + c->fuse)) {
         plan_drop_graph(p);
         p->graph_state = 0;
     }
     if (p->graph_state == 0) {
         p->graph_nb = c->nb_override;
         p->graph_la = c->lookahead;
-        p->graph_pw = c->potf2_waves;
+        p->graph_pw = c->potf2_waves * 2 + c->fuse;
         p->graph_state = -1;
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
             const int st = plan_enqueue(c, p);
@@ -1749,6 +1773,24 @@ extern "C" int bq_probe_hbm(bq_ctx *c, size_t bytes, double *write_gbs, double *
     }
     if (copy_gbs)
         *copy_gbs = 5.0 * 2.0 * bytes / (ms * 1e-3) / 1e9;
+    return BQ_OK;
+}
+
+extern "C" int bq_probe_rsq(bq_ctx *c, const double *x, int64_t n, double *err3)
+{
+    if (!c || !x || !err3 || n < 1)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf xd, od;
+    HIPCHK(c, xd.alloc(sizeof(double) * n));
+    HIPCHK(c, od.alloc(sizeof(double) * 3 * n));
+    HIPCHK(c, hipMemcpyAsync(xd.p, x, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(probe_rsq_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                       xd.d(), od.d(), (int)n);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(err3, od.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return BQ_OK;
 }
 

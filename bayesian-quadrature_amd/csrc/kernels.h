@@ -480,16 +480,13 @@ struct Potf2WSteps<16> {
     static __device__ __forceinline__ void run(Potf2W &, double *, int, int, int) {}
 };
 
-__global__ __launch_bounds__(256) void potf2_64x4_kernel(double *__restrict__ A, long lda,
-                                                         long astride, int j0,
-                                                         double *__restrict__ dinv, long dstride,
-                                                         int *__restrict__ info)
+// The factorisation proper, callable by any 256-thread workgroup: Ab points at
+// the 64x64 block (leading dimension lda), j0 is its global column (for the
+// failure report), dinv_b / info_b belong to this batch element.
+__device__ __forceinline__ void potf2_64x4_body(double *__restrict__ Ab, long lda, int j0,
+                                                double *__restrict__ dinv_b,
+                                                int *__restrict__ info_b, double *ring, int *sbad)
 {
-    __shared__ __attribute__((aligned(16))) double ring[3 * 4 * 64];
-    __shared__ int sbad[4];
-    __builtin_amdgcn_s_setprio(3);
-    const int b = blockIdx.z;
-    double *Ab = A + (long)b * astride + j0 + (long)j0 * lda;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     Potf2W st;
@@ -517,7 +514,7 @@ __global__ __launch_bounds__(256) void potf2_64x4_kernel(double *__restrict__ A,
         }
     }
     if (((lane >> 2) & 3) == w)
-        dinv[(long)b * dstride + lane] = st.myr;
+        dinv_b[lane] = st.myr;
     if (lane == 0)
         sbad[w] = st.bad;
     __syncthreads();
@@ -526,9 +523,22 @@ __global__ __launch_bounds__(256) void potf2_64x4_kernel(double *__restrict__ A,
         for (int k = 0; k < 4; ++k)
             if (sbad[k] != 0 && (first == 0 || sbad[k] < first))
                 first = sbad[k];
-        if (first != 0 && info[b] == 0)
-            info[b] = first;
+        if (first != 0 && info_b[0] == 0)
+            info_b[0] = first;
     }
+}
+
+__global__ __launch_bounds__(256) void potf2_64x4_kernel(double *__restrict__ A, long lda,
+                                                         long astride, int j0,
+                                                         double *__restrict__ dinv, long dstride,
+                                                         int *__restrict__ info)
+{
+    __shared__ __attribute__((aligned(16))) double ring[3 * 4 * 64];
+    __shared__ int sbad[4];
+    __builtin_amdgcn_s_setprio(3);
+    const int b = blockIdx.z;
+    potf2_64x4_body(A + (long)b * astride + j0 + (long)j0 * lda, lda, j0, dinv + (long)b * dstride,
+                    info + b, ring, sbad);
 }
 
 // ---------------------------------------------------------------------------
@@ -854,28 +864,14 @@ __device__ __forceinline__ void tri_decode(int t, int &bx, int &by)
     by = t - bx * (bx + 1) / 2;
 }
 
+// one wave tile of C -= P Q^T (see gemm_sub_kernel); C, P, Q already point at the batch element
 template <int TM, int TN>
-__global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C, long ldc,
-                                                       long cstride, const double *__restrict__ P,
-                                                       long ldp, long pstride,
-                                                       const double *__restrict__ Q, long qsj,
-                                                       long qsk, long qstride, int m, int n,
-                                                       int k, int lower)
+__device__ __forceinline__ void gemm_sub_tile(double *__restrict__ C, long ldc,
+                                              const double *__restrict__ P, long ldp,
+                                              const double *__restrict__ Q, long qsj, long qsk,
+                                              int m, int n, int k, int lower, int row0, int col0,
+                                              int lane)
 {
-    const int b = blockIdx.z;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (lower == 2)
-        tri_decode(blockIdx.x, bx, by);
-    const int row0 = (bx * 2 + (wave & 1)) * (TM * 16);
-    const int col0 = (by * 2 + (wave >> 1)) * (TN * 16);
-    if (row0 >= m || col0 >= n)
-        return;
-    if (lower && col0 >= row0 + TM * 16)
-        return;
-    C += (long)b * cstride;
-    P += (long)b * pstride;
-    Q += (long)b * qstride;
     const int l15 = lane & 15, l4 = lane >> 4;
 
     // clamp fragment rows at the edge (m, n multiples of 16 but maybe not of
@@ -972,6 +968,57 @@ __global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C
     }
 }
 
+// Fused diagonal factor: when fuse_j0 >= 0 the launch also factors the leading 64x64
+// block of C (the next diagonal block of the Cholesky) right after updating it.
+// Workgroup 0 owns every workgroup tile that intersects that block, updates them,
+// and runs potf2_64x4_body on the result; the other workgroups of the block exit.
+// This removes one dependent launch (and the block's trip through L2) per 64 columns.
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C, long ldc,
+                                                          long cstride, const double *__restrict__ P,
+                                                          long ldp, long pstride,
+                                                          const double *__restrict__ Q, long qsj,
+                                                          long qsk, long qstride, int m, int n,
+                                                          int k, int lower, int fuse_j0,
+                                                          double *__restrict__ dinv, long dstride,
+                                                          int *__restrict__ info)
+{
+    __shared__ __attribute__((aligned(16))) double ring[3 * 4 * 64];
+    __shared__ int sbad[4];
+    const int b = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (lower == 2)
+        tri_decode(blockIdx.x, bx, by);
+    C += (long)b * cstride;
+    P += (long)b * pstride;
+    Q += (long)b * qstride;
+    constexpr int WT = 32 * TM; // rows (and, TM == TN, columns) of a workgroup tile
+    if (fuse_j0 >= 0 && bx * WT < 64 && by * (32 * TN) < 64) {
+        if (bx != 0 || by != 0)
+            return; // inside the diagonal block: workgroup 0 does it
+        constexpr int NS = (WT >= 64) ? 1 : 64 / WT;
+        for (int sx = 0; sx < NS; ++sx)
+            for (int sy = 0; sy <= sx; ++sy) {
+                const int row0 = (sx * 2 + (wave & 1)) * (TM * 16);
+                const int col0 = (sy * 2 + (wave >> 1)) * (TN * 16);
+                if (row0 < m && col0 < n && !(lower && col0 >= row0 + TM * 16))
+                    gemm_sub_tile<TM, TN>(C, ldc, P, ldp, Q, qsj, qsk, m, n, k, lower, row0, col0,
+                                          lane);
+            }
+        __syncthreads(); // the updated block is visible to the whole workgroup
+        potf2_64x4_body(C, ldc, fuse_j0, dinv + (long)b * dstride, info + b, ring, sbad);
+        return;
+    }
+    const int row0 = (bx * 2 + (wave & 1)) * (TM * 16);
+    const int col0 = (by * 2 + (wave >> 1)) * (TN * 16);
+    if (row0 >= m || col0 >= n)
+        return;
+    if (lower && col0 >= row0 + TM * 16)
+        return;
+    gemm_sub_tile<TM, TN>(C, ldc, P, ldp, Q, qsj, qsk, m, n, k, lower, row0, col0, lane);
+}
+
 // ---------------------------------------------------------------------------
 // The same product for k == 64 exactly (the trailing / panel update of small
 // systems, outer block 64): all 16 k-steps of fragments are requested up front
@@ -979,27 +1026,11 @@ __global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C
 // instead of sixteen.  TM, TN <= 2.
 // ---------------------------------------------------------------------------
 template <int TM, int TN>
-__global__ __launch_bounds__(256) void gemm_k64_kernel(double *__restrict__ C, long ldc,
-                                                       long cstride, const double *__restrict__ P,
-                                                       long ldp, long pstride,
-                                                       const double *__restrict__ Q, long qsj,
-                                                       long qsk, long qstride, int m, int n,
-                                                       int lower)
+__device__ __forceinline__ void gemm_k64_tile(double *__restrict__ C, long ldc,
+                                              const double *__restrict__ P, long ldp,
+                                              const double *__restrict__ Q, long qsj, long qsk,
+                                              int m, int n, int lower, int row0, int col0, int lane)
 {
-    const int b = blockIdx.z;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (lower == 2)
-        tri_decode(blockIdx.x, bx, by);
-    const int row0 = (bx * 2 + (wave & 1)) * (TM * 16);
-    const int col0 = (by * 2 + (wave >> 1)) * (TN * 16);
-    if (row0 >= m || col0 >= n)
-        return;
-    if (lower && col0 >= row0 + TM * 16)
-        return;
-    C += (long)b * cstride;
-    P += (long)b * pstride;
-    Q += (long)b * qstride;
     const int l15 = lane & 15, l4 = lane >> 4;
     double pa[16][TM], qa[16][TN];
 #pragma unroll
@@ -1069,6 +1100,52 @@ __global__ __launch_bounds__(256) void gemm_k64_kernel(double *__restrict__ C, l
                 C[(r + l15) + (long)(c + l4 + 4 * rr) * ldc] = cold[tm][tn][rr] - acc[tm][tn][rr];
         }
     }
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_k64_kernel(double *__restrict__ C, long ldc,
+                                                       long cstride, const double *__restrict__ P,
+                                                       long ldp, long pstride,
+                                                       const double *__restrict__ Q, long qsj,
+                                                       long qsk, long qstride, int m, int n,
+                                                       int lower, int fuse_j0,
+                                                       double *__restrict__ dinv, long dstride,
+                                                       int *__restrict__ info)
+{
+    __shared__ __attribute__((aligned(16))) double ring[3 * 4 * 64];
+    __shared__ int sbad[4];
+    const int b = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (lower == 2)
+        tri_decode(blockIdx.x, bx, by);
+    C += (long)b * cstride;
+    P += (long)b * pstride;
+    Q += (long)b * qstride;
+    constexpr int WT = 32 * TM;
+    if (fuse_j0 >= 0 && bx * WT < 64 && by * (32 * TN) < 64) { // see gemm_sub_kernel
+        if (bx != 0 || by != 0)
+            return;
+        constexpr int NS = (WT >= 64) ? 1 : 64 / WT;
+        for (int sx = 0; sx < NS; ++sx)
+            for (int sy = 0; sy <= sx; ++sy) {
+                const int row0 = (sx * 2 + (wave & 1)) * (TM * 16);
+                const int col0 = (sy * 2 + (wave >> 1)) * (TN * 16);
+                if (row0 < m && col0 < n && !(lower && col0 >= row0 + TM * 16))
+                    gemm_k64_tile<TM, TN>(C, ldc, P, ldp, Q, qsj, qsk, m, n, lower, row0, col0,
+                                          lane);
+            }
+        __syncthreads();
+        potf2_64x4_body(C, ldc, fuse_j0, dinv + (long)b * dstride, info + b, ring, sbad);
+        return;
+    }
+    const int row0 = (bx * 2 + (wave & 1)) * (TM * 16);
+    const int col0 = (by * 2 + (wave >> 1)) * (TN * 16);
+    if (row0 >= m || col0 >= n)
+        return;
+    if (lower && col0 >= row0 + TM * 16)
+        return;
+    gemm_k64_tile<TM, TN>(C, ldc, P, ldp, Q, qsj, qsk, m, n, lower, row0, col0, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -1226,6 +1303,26 @@ __global__ __launch_bounds__(256) void logdet_kernel(const double *__restrict__ 
 // ---------------------------------------------------------------------------
 // hardware probes
 // ---------------------------------------------------------------------------
+// relative error of the raw v_rsq_f64 seed, of one and of two Newton steps, against
+// the correctly rounded 1/sqrt; out[3*i + k]
+__global__ void probe_rsq_kernel(const double *x, double *out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const double d = x[i];
+    const double ref = 1.0 / sqrt(d);
+    double y = __builtin_amdgcn_rsq(d);
+    out[3 * i] = fabs(y - ref) / ref;
+    const double hd = 0.5 * d;
+    double t = __builtin_fma(-hd * y, y, 0.5);
+    y = __builtin_fma(y, t, y);
+    out[3 * i + 1] = fabs(y - ref) / ref;
+    t = __builtin_fma(-hd * y, y, 0.5);
+    y = __builtin_fma(y, t, y);
+    out[3 * i + 2] = fabs(y - ref) / ref;
+}
+
 __global__ void probe_empty_kernel(double *out)
 {
     if (out == nullptr && threadIdx.x == 9999)

@@ -231,6 +231,9 @@ int bq_probe_mfma_f64(bq_ctx *ctx, double *tflops);
 int bq_probe_fma_f64(bq_ctx *ctx, double *tflops);
 /* streaming fp64 write / copy bandwidth in GB/s over `bytes` */
 int bq_probe_hbm(bq_ctx *ctx, size_t bytes, double *write_gbs, double *copy_gbs);
+/* relative error of v_rsq_f64 raw / after one / after two Newton steps at x[0..n):
+ * err3[3*i + {0,1,2}] */
+int bq_probe_rsq(bq_ctx *ctx, const double *x, int64_t n, double *err3);
 /* device time per launch of a chain of n empty, dependent kernels (us) */
 int bq_probe_launch(bq_ctx *ctx, int64_t n, double *us_per_launch);
 /* dump of the f64 MFMA D-register layout: out[64*4] receives, for lane l and

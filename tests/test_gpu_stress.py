@@ -1,0 +1,96 @@
+"""Randomised sweep of the bordered pipeline over sizes, dimensions, batch sizes, outer
+blocks and launch modes (look-ahead on / off), each case against the CPU oracle."""
+import numpy as np
+import pytest
+
+from bayesian_quadrature_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+
+
+def _case(rs, n, M, d):
+    side = max(2, int(round(n ** (1.0 / d))))
+    if d == 1:
+        dx = 10.0 / max(n - 1, 1)
+        x = (np.linspace(-5, 5, n) + rs.uniform(-dx / 4, dx / 4, n))[None, :]
+        w = np.array([1.1 * dx])
+    else:
+        g = np.linspace(-3, 3, side)
+        dx = 6.0 / (side - 1)
+        X, Y = np.meshgrid(g, g, indexing="ij")
+        x = np.stack([X.ravel(), Y.ravel()])[:, :n]
+        x = x + rs.uniform(-dx / 4, dx / 4, x.shape)
+        w = np.array([0.9 * dx, 1.1 * dx])
+    y = sum(wl.norm_logpdf(x[k]) for k in range(d)) + 0.01 * rs.randn(x.shape[1])
+    xo = rs.uniform(-3, 3, (d, M))
+    return x, y, xo, 1.2, w, 0.05
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_shapes(engine, oracle, seed):
+    rs = np.random.RandomState(100 + seed)
+    try:
+        for _ in range(6):
+            d = int(rs.choice([1, 1, 2]))
+            n = int(rs.randint(1, 700))
+            M = int(rs.randint(1, 200))
+            engine.set_block(int(rs.choice([0, 64, 128, 256])))
+            engine.set_lookahead(bool(rs.randint(0, 2)))
+            x, y, xo, h, w, s = _case(rs, n, M, d)
+            n = x.shape[1]
+            mean, var, logml = engine.fit_predict(x, y, h, w, s, xo)
+            Lo, ao, lmo = oracle.gp_fit(x, y, h, w, s)
+            mo, vo = oracle.gp_predict(x, h, w, Lo, ao, xo)
+            k0 = oracle.kernel_scale(d, h, w)
+            assert np.max(np.abs(mean - mo)) <= RTOL * max(np.abs(mo).max(), 1e-300), (d, n, M)
+            assert np.max(np.abs(var - vo)) <= RTOL * k0, (d, n, M)
+            assert abs(logml - lmo) <= RTOL * abs(lmo), (d, n, M)
+    finally:
+        engine.set_block(0)
+        engine.set_lookahead(True)
+
+
+@pytest.mark.parametrize("nb,la", [(0, True), (128, True), (256, False), (64, True)])
+def test_batch_through_lookahead_path(engine, oracle, nb, la):
+    """A batch whose working set selects a wide outer block: several outer blocks, the
+    two-stream look-ahead, batched launches and the fused diagonal factor together."""
+    P, n, M = 12, 1100, 100
+    c = wl.c5(list(range(P)), n=n, m=M)
+    w = c["w"] * 1.2
+    try:
+        engine.set_block(nb)
+        engine.set_lookahead(la)
+        mean, var, logml, status = engine.batch_fit_predict(c["x"], c["y"], c["h"], w, c["s"],
+                                                            c["xo"])
+    finally:
+        engine.set_block(0)
+        engine.set_lookahead(True)
+    assert (status == 0).all()
+    k0 = oracle.kernel_scale(1, c["h"], w)
+    for p in (0, 5, 11):
+        Lo, ao, lmo = oracle.gp_fit(c["x"][p], c["y"][p], c["h"], w, c["s"])
+        mo, vo = oracle.gp_predict(c["x"][p], c["h"], w, Lo, ao, c["xo"][p])
+        cond_tol = max(RTOL, 1e-15 * np.linalg.cond(oracle.gram(c["x"][p], c["h"], w, c["s"])))
+        assert np.max(np.abs(mean[p] - mo)) <= cond_tol * np.abs(mo).max()
+        assert np.max(np.abs(var[p] - vo)) <= cond_tol * k0
+        assert abs(logml[p] - lmo) <= cond_tol * abs(lmo)
+
+
+def test_failure_flags_in_a_batch(engine):
+    """One hopeless problem in a batch fails alone (status > 0, logml = -inf)."""
+    P, n, M = 4, 200, 10
+    rs = np.random.RandomState(0)
+    dx = 10.0 / (n - 1)
+    x = np.linspace(-5, 5, n)[None, :] + rs.uniform(-dx / 4, dx / 4, (P, n))
+    y = wl.norm_logpdf(x)
+    xo = np.tile(np.linspace(-4, 4, M), (P, 1))
+    w = np.full(P, dx)
+    w[2] = 50 * dx               # numerically singular Gaussian Gram, no noise
+    plan = engine.plan(P, 1, n, M)
+    plan.set_inputs(x, y, xo, 1.0, w, 0.0)
+    plan.run()
+    mean, var, logml, status = plan.results()
+    plan.close()
+    assert status[2] > 0 and logml[2] == -np.inf
+    assert (np.delete(status, 2) == 0).all() and np.isfinite(np.delete(logml, 2)).all()
