@@ -1,0 +1,73 @@
+// common.h -- types and device helpers shared by every kernel of libbqhip.so.
+//
+// GaussParams, the fp64 lane broadcast, the scheduling pin, the Gaussian-kernel exp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BQ_MAXD 8
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// Gaussian kernel parameters of one batch element:
+//   k(p,q) = c * exp( sum_k nh[k] (p_k - q_k)^2 ),  c = h^2 / prod(sqrt(2 pi) w_k),
+//   nh[k] = -1 / (2 w_k^2);  s2 = s^2 is added on the diagonal of Kxx.
+struct GaussParams {
+    double c;
+    double s2;
+    double nh[BQ_MAXD];
+};
+
+// Pins a value's computation at this point of the program: without it LLVM
+// sinks the rank-1 updates of the right-looking factorisations down to their
+// first use (a left-looking schedule), keeps every broadcast multiplier alive
+// and spills thousands of registers.
+#define PIN(v) asm volatile("" : "+v"(v))
+
+__device__ __forceinline__ double readlane_f64(double v, int srclane)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, srclane);
+    hi = __builtin_amdgcn_readlane(hi, srclane);
+    return __hiloint2double(hi, lo);
+}
+
+// exp(x) for the Gaussian-kernel exponent (x <= 0): range reduction by ln 2 with a
+// hi/lo split, degree-13 Taylor polynomial on |r| <= ln2/2 (truncation 6e-18),
+// v_ldexp_f64 for the scale.  20 fp64 instructions against ~28 of the library
+// routine, <= 1 ulp; x is clamped at -800 where the result is 0 anyway.
+__device__ __forceinline__ double exp_gauss(double x)
+{
+    x = __builtin_fmax(x, -800.0);
+    const double k = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(k, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(k, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;            // 1/13!
+    p = __builtin_fma(p, r, 2.0876756987868100e-09); // 1/12!
+    p = __builtin_fma(p, r, 2.5052108385441720e-08); // 1/11!
+    p = __builtin_fma(p, r, 2.7557319223985888e-07); // 1/10!
+    p = __builtin_fma(p, r, 2.7557319223985893e-06); // 1/9!
+    p = __builtin_fma(p, r, 2.4801587301587302e-05); // 1/8!
+    p = __builtin_fma(p, r, 1.9841269841269841e-04); // 1/7!
+    p = __builtin_fma(p, r, 1.3888888888888889e-03); // 1/6!
+    p = __builtin_fma(p, r, 8.3333333333333332e-03); // 1/5!
+    p = __builtin_fma(p, r, 4.1666666666666664e-02); // 1/4!
+    p = __builtin_fma(p, r, 1.6666666666666666e-01); // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)k);
+}
+
+template <int D>
+__device__ __forceinline__ double gauss_q(const double *p, const double *q, const GaussParams &g)
+{
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const double t = p[k] - q[k];
+        acc += (t * t) * g.nh[k];
+    }
+    return acc;
+}

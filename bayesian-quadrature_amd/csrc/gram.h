@@ -1,0 +1,175 @@
+// gram.h -- Gaussian-kernel Gram matrices and the bordered GP system (HBM-write bound)
+// Part of the libbqhip.so kernel set; included through kernels.h.
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// Full symmetric Gram, K[i,j] = k(x_i,x_j) + s2 [i==j].
+// Block = 256 threads = a 128(i) x 64(j) tile: lane pairs two consecutive rows
+// (one 16-byte store), a wave stores 1 KiB of one column per instruction, the
+// four waves take 16 columns each.  x is d x n.
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void gram_sym_kernel(const double *__restrict__ x, long xstride,
+                                                       const GaussParams *__restrict__ gp,
+                                                       int gpstride, double *__restrict__ K,
+                                                       long ldk, long kstride, int n, int nt)
+{
+    const int b = blockIdx.z;
+    x += (long)b * xstride;
+    K += (long)b * kstride;
+    const GaussParams g = gp[(long)b * gpstride];
+    const int t = threadIdx.x;
+    const int i = blockIdx.x * 128 + (t & 63) * 2;
+    const int jbase = blockIdx.y * 64 + (t >> 6) * 16;
+    if (i >= n)
+        return;
+    const bool two = (i + 1 < n);
+    double xi0[D], xi1[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        xi0[k] = x[k + (long)i * D];
+        xi1[k] = two ? x[k + (long)(i + 1) * D] : 0.0;
+    }
+    const bool vec = two && ((ldk & 1) == 0);
+#pragma unroll 4
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = jbase + jj;
+        if (j >= n)
+            break;
+        double xj[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            xj[k] = x[k + (long)j * D];
+        double v0, v1;
+        if (nt & 2) { // timing diagnostic only (BQ_GRAM_NT=2): no exp, wrong values
+            v0 = g.c * gauss_q<D>(xi0, xj, g);
+            v1 = g.c * gauss_q<D>(xi1, xj, g);
+        } else {
+            v0 = g.c * exp_gauss(gauss_q<D>(xi0, xj, g));
+            v1 = g.c * exp_gauss(gauss_q<D>(xi1, xj, g));
+        }
+        if (i == j)
+            v0 += g.s2;
+        if (i + 1 == j)
+            v1 += g.s2;
+        double *dst = K + i + (long)j * ldk;
+        if (vec) {
+            double2_t v = {v0, v1};
+            if (nt & 1)
+                __builtin_nontemporal_store(v, reinterpret_cast<double2_t *>(dst));
+            else
+                *reinterpret_cast<double2_t *>(dst) = v;
+        } else {
+            dst[0] = v0;
+            if (two)
+                dst[1] = v1;
+        }
+    }
+}
+
+// Rectangular Gram K[i,j] = k(x1_i, x2_j), n1 x n2, ld = ldk.
+template <int D>
+__global__ __launch_bounds__(256) void gram_cross_kernel(const double *__restrict__ x1, int n1,
+                                                         const double *__restrict__ x2, int n2,
+                                                         GaussParams g, double *__restrict__ K,
+                                                         long ldk)
+{
+    const int t = threadIdx.x;
+    const int i = blockIdx.x * 64 + (t & 63);
+    const int jbase = blockIdx.y * 64 + (t >> 6) * 16;
+    if (i >= n1)
+        return;
+    double xi[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+        xi[k] = x1[k + (long)i * D];
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = jbase + jj;
+        if (j >= n2)
+            break;
+        double xj[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            xj[k] = x2[k + (long)j * D];
+        K[i + (long)j * ldk] = g.c * exp_gauss(gauss_q<D>(xi, xj, g));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Bordered GP system, lower triangle only (tiles strictly above the diagonal
+// are skipped).  Index space of size ntot (multiple of 64):
+//   [0, n)              samples x            -> Kxx + s2 I
+//   [n, npad)           identity padding     -> delta_ij
+//   [npad, npad + M)    prediction points xo -> K(xo, x), K(xo, xo)
+//   yrow = npad + M     (if has_y) the row y^T, zero elsewhere, zero diagonal
+//   (yrow, ntot)        identity padding
+// pts is d x ntot with x at [0,n) and xo at [npad, npad+M); other columns are
+// never read.  After eliminating the first npad columns, the Schur complement
+// holds the posterior covariance, -mean in row yrow and -y'K^-1 y at
+// (yrow, yrow); see DESIGN.md.
+// ---------------------------------------------------------------------------
+struct Layout {
+    int n, npad, M, yrow, ntot; // yrow < 0: no y row
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void assemble_kernel(const double *__restrict__ pts,
+                                                       long pstride, const double *__restrict__ y,
+                                                       long ystride,
+                                                       const GaussParams *__restrict__ gp,
+                                                       int gpstride, double *__restrict__ A,
+                                                       long lda, long astride, Layout L)
+{
+    const int b = blockIdx.z;
+    const int t = threadIdx.x;
+    const int ib = blockIdx.x * 128, jb = blockIdx.y * 64;
+    if (jb > ib + 127) // whole tile strictly above the diagonal
+        return;
+    pts += (long)b * pstride;
+    y += (long)b * ystride;
+    A += (long)b * astride;
+    const GaussParams g = gp[(long)b * gpstride];
+    const int i = ib + (t & 63) * 2;
+    const int jbase = jb + (t >> 6) * 16;
+    if (i >= L.ntot)
+        return;
+    bool pi[2];
+    double xi[2][D];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int ii = i + r;
+        pi[r] = (ii < L.n) || (ii >= L.npad && ii < L.npad + L.M);
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            xi[r][k] = pi[r] ? pts[k + (long)ii * D] : 0.0;
+    }
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = jbase + jj;
+        if (j >= L.ntot)
+            break;
+        const bool pj = (j < L.n) || (j >= L.npad && j < L.npad + L.M);
+        double xj[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            xj[k] = pj ? pts[k + (long)j * D] : 0.0;
+        double v[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int ii = i + r;
+            double val;
+            if (pi[r] && pj) {
+                val = g.c * exp_gauss(gauss_q<D>(xi[r], xj, g));
+                if (ii == j && ii < L.n)
+                    val += g.s2;
+            } else if (ii == L.yrow) {
+                val = (j < L.n) ? y[j] : 0.0;
+            } else {
+                val = (ii == j) ? 1.0 : 0.0;
+            }
+            v[r] = val;
+        }
+        double2_t vv = {v[0], v[1]};
+        *reinterpret_cast<double2_t *>(A + i + (long)j * lda) = vv; // ntot, lda even
+    }
+}

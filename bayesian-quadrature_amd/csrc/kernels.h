@@ -1,1681 +1,15 @@
-// kernels.h -- gfx950 (CDNA4) device kernels of libbqhip.so.
+// kernels.h -- gfx950 (CDNA4) device kernels of libbqhip.so, by topic.
 //
-// Everything here is fp64 and column-major.  All kernels take a batch
-// dimension in blockIdx.z (independent problems / hyper-parameter points) with
-// element strides, so one launch covers a whole shard of problems.
-//
-// Kernel inventory (DESIGN.md has the roofline of each):
-//   gram_sym_kernel       full symmetric Gaussian Gram (HBM-write bound)
-//   gram_cross_kernel     rectangular Gram
-//   assemble_kernel       lower triangle of the bordered GP system
-//   potf2_64_kernel       64x64 diagonal Cholesky, one wave, register resident
-//   trsm_rows_kernel      panel solve X <- X L11^-T (or X L11^-1), row per lane
-//   gemm_sub_kernel       C -= P Q^T on v_mfma_f64_16x16x4_f64 (panel + trailing)
-//   finalize_kernel       log-det / log-ML / posterior mean+var read-out
-//   rowdot_kernel, predict_mean_kernel, misc copies
+// Everything is fp64 and column-major.  All kernels take a batch dimension in
+// blockIdx.z (independent problems / hyper-parameter points) with element
+// strides, so one launch covers a whole shard of problems.  DESIGN.md section 4 has
+// the roofline that bounds each kernel and its algorithmic work.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#define BQ_MAXD 8
-
-typedef double double4_t __attribute__((ext_vector_type(4)));
-typedef double double2_t __attribute__((ext_vector_type(2)));
-
-// Gaussian kernel parameters of one batch element:
-//   k(p,q) = c * exp( sum_k nh[k] (p_k - q_k)^2 ),  c = h^2 / prod(sqrt(2 pi) w_k),
-//   nh[k] = -1 / (2 w_k^2);  s2 = s^2 is added on the diagonal of Kxx.
-struct GaussParams {
-    double c;
-    double s2;
-    double nh[BQ_MAXD];
-};
-
-// Pins a value's computation at this point of the program: without it LLVM
-// sinks the rank-1 updates of the right-looking factorisations down to their
-// first use (a left-looking schedule), keeps every broadcast multiplier alive
-// and spills thousands of registers.
-#define PIN(v) asm volatile("" : "+v"(v))
-
-__device__ __forceinline__ double readlane_f64(double v, int srclane)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, srclane);
-    hi = __builtin_amdgcn_readlane(hi, srclane);
-    return __hiloint2double(hi, lo);
-}
-
-// exp(x) for the Gaussian-kernel exponent (x <= 0): range reduction by ln 2 with a
-// hi/lo split, degree-13 Taylor polynomial on |r| <= ln2/2 (truncation 6e-18),
-// v_ldexp_f64 for the scale.  20 fp64 instructions against ~28 of the library
-// routine, <= 1 ulp; x is clamped at -800 where the result is 0 anyway.
-__device__ __forceinline__ double exp_gauss(double x)
-{
-    x = __builtin_fmax(x, -800.0);
-    const double k = __builtin_rint(x * 1.4426950408889634074);
-    double r = __builtin_fma(k, -6.93147180369123816490e-01, x);
-    r = __builtin_fma(k, -1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;            // 1/13!
-    p = __builtin_fma(p, r, 2.0876756987868100e-09); // 1/12!
-    p = __builtin_fma(p, r, 2.5052108385441720e-08); // 1/11!
-    p = __builtin_fma(p, r, 2.7557319223985888e-07); // 1/10!
-    p = __builtin_fma(p, r, 2.7557319223985893e-06); // 1/9!
-    p = __builtin_fma(p, r, 2.4801587301587302e-05); // 1/8!
-    p = __builtin_fma(p, r, 1.9841269841269841e-04); // 1/7!
-    p = __builtin_fma(p, r, 1.3888888888888889e-03); // 1/6!
-    p = __builtin_fma(p, r, 8.3333333333333332e-03); // 1/5!
-    p = __builtin_fma(p, r, 4.1666666666666664e-02); // 1/4!
-    p = __builtin_fma(p, r, 1.6666666666666666e-01); // 1/3!
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
-    return __builtin_amdgcn_ldexp(p, (int)k);
-}
-
-template <int D>
-__device__ __forceinline__ double gauss_q(const double *p, const double *q, const GaussParams &g)
-{
-    double acc = 0.0;
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        const double t = p[k] - q[k];
-        acc += (t * t) * g.nh[k];
-    }
-    return acc;
-}
-
-// ---------------------------------------------------------------------------
-// Full symmetric Gram, K[i,j] = k(x_i,x_j) + s2 [i==j].
-// Block = 256 threads = a 128(i) x 64(j) tile: lane pairs two consecutive rows
-// (one 16-byte store), a wave stores 1 KiB of one column per instruction, the
-// four waves take 16 columns each.  x is d x n.
-// ---------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(256) void gram_sym_kernel(const double *__restrict__ x, long xstride,
-                                                       const GaussParams *__restrict__ gp,
-                                                       int gpstride, double *__restrict__ K,
-                                                       long ldk, long kstride, int n, int nt)
-{
-    const int b = blockIdx.z;
-    x += (long)b * xstride;
-    K += (long)b * kstride;
-    const GaussParams g = gp[(long)b * gpstride];
-    const int t = threadIdx.x;
-    const int i = blockIdx.x * 128 + (t & 63) * 2;
-    const int jbase = blockIdx.y * 64 + (t >> 6) * 16;
-    if (i >= n)
-        return;
-    const bool two = (i + 1 < n);
-    double xi0[D], xi1[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        xi0[k] = x[k + (long)i * D];
-        xi1[k] = two ? x[k + (long)(i + 1) * D] : 0.0;
-    }
-    const bool vec = two && ((ldk & 1) == 0);
-#pragma unroll 4
-    for (int jj = 0; jj < 16; ++jj) {
-        const int j = jbase + jj;
-        if (j >= n)
-            break;
-        double xj[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k)
-            xj[k] = x[k + (long)j * D];
-        double v0, v1;
-        if (nt & 2) { // timing diagnostic only (BQ_GRAM_NT=2): no exp, wrong values
-            v0 = g.c * gauss_q<D>(xi0, xj, g);
-            v1 = g.c * gauss_q<D>(xi1, xj, g);
-        } else {
-            v0 = g.c * exp_gauss(gauss_q<D>(xi0, xj, g));
-            v1 = g.c * exp_gauss(gauss_q<D>(xi1, xj, g));
-        }
-        if (i == j)
-            v0 += g.s2;
-        if (i + 1 == j)
-            v1 += g.s2;
-        double *dst = K + i + (long)j * ldk;
-        if (vec) {
-            double2_t v = {v0, v1};
-            if (nt & 1)
-                __builtin_nontemporal_store(v, reinterpret_cast<double2_t *>(dst));
-            else
-                *reinterpret_cast<double2_t *>(dst) = v;
-        } else {
-            dst[0] = v0;
-            if (two)
-                dst[1] = v1;
-        }
-    }
-}
-
-// Rectangular Gram K[i,j] = k(x1_i, x2_j), n1 x n2, ld = ldk.
-template <int D>
-__global__ __launch_bounds__(256) void gram_cross_kernel(const double *__restrict__ x1, int n1,
-                                                         const double *__restrict__ x2, int n2,
-                                                         GaussParams g, double *__restrict__ K,
-                                                         long ldk)
-{
-    const int t = threadIdx.x;
-    const int i = blockIdx.x * 64 + (t & 63);
-    const int jbase = blockIdx.y * 64 + (t >> 6) * 16;
-    if (i >= n1)
-        return;
-    double xi[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k)
-        xi[k] = x1[k + (long)i * D];
-    for (int jj = 0; jj < 16; ++jj) {
-        const int j = jbase + jj;
-        if (j >= n2)
-            break;
-        double xj[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k)
-            xj[k] = x2[k + (long)j * D];
-        K[i + (long)j * ldk] = g.c * exp_gauss(gauss_q<D>(xi, xj, g));
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Bordered GP system, lower triangle only (tiles strictly above the diagonal
-// are skipped).  Index space of size ntot (multiple of 64):
-//   [0, n)              samples x            -> Kxx + s2 I
-//   [n, npad)           identity padding     -> delta_ij
-//   [npad, npad + M)    prediction points xo -> K(xo, x), K(xo, xo)
-//   yrow = npad + M     (if has_y) the row y^T, zero elsewhere, zero diagonal
-//   (yrow, ntot)        identity padding
-// pts is d x ntot with x at [0,n) and xo at [npad, npad+M); other columns are
-// never read.  After eliminating the first npad columns, the Schur complement
-// holds the posterior covariance, -mean in row yrow and -y'K^-1 y at
-// (yrow, yrow); see DESIGN.md.
-// ---------------------------------------------------------------------------
-struct Layout {
-    int n, npad, M, yrow, ntot; // yrow < 0: no y row
-};
-
-template <int D>
-__global__ __launch_bounds__(256) void assemble_kernel(const double *__restrict__ pts,
-                                                       long pstride, const double *__restrict__ y,
-                                                       long ystride,
-                                                       const GaussParams *__restrict__ gp,
-                                                       int gpstride, double *__restrict__ A,
-                                                       long lda, long astride, Layout L)
-{
-    const int b = blockIdx.z;
-    const int t = threadIdx.x;
-    const int ib = blockIdx.x * 128, jb = blockIdx.y * 64;
-    if (jb > ib + 127) // whole tile strictly above the diagonal
-        return;
-    pts += (long)b * pstride;
-    y += (long)b * ystride;
-    A += (long)b * astride;
-    const GaussParams g = gp[(long)b * gpstride];
-    const int i = ib + (t & 63) * 2;
-    const int jbase = jb + (t >> 6) * 16;
-    if (i >= L.ntot)
-        return;
-    bool pi[2];
-    double xi[2][D];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int ii = i + r;
-        pi[r] = (ii < L.n) || (ii >= L.npad && ii < L.npad + L.M);
-#pragma unroll
-        for (int k = 0; k < D; ++k)
-            xi[r][k] = pi[r] ? pts[k + (long)ii * D] : 0.0;
-    }
-    for (int jj = 0; jj < 16; ++jj) {
-        const int j = jbase + jj;
-        if (j >= L.ntot)
-            break;
-        const bool pj = (j < L.n) || (j >= L.npad && j < L.npad + L.M);
-        double xj[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k)
-            xj[k] = pj ? pts[k + (long)j * D] : 0.0;
-        double v[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int ii = i + r;
-            double val;
-            if (pi[r] && pj) {
-                val = g.c * exp_gauss(gauss_q<D>(xi[r], xj, g));
-                if (ii == j && ii < L.n)
-                    val += g.s2;
-            } else if (ii == L.yrow) {
-                val = (j < L.n) ? y[j] : 0.0;
-            } else {
-                val = (ii == j) ? 1.0 : 0.0;
-            }
-            v[r] = val;
-        }
-        double2_t vv = {v[0], v[1]};
-        *reinterpret_cast<double2_t *>(A + i + (long)j * lda) = vv; // ntot, lda even
-    }
-}
-
-// ---------------------------------------------------------------------------
-// refined reciprocal square root: v_rsq_f64 seed + two Newton steps, and the
-// square root s = d r with one correction.  Relative error ~1 ulp; the pivot
-// chain is the critical path of the whole factorisation, so it avoids the
-// long div/sqrt library sequences.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void rsqrt_sqrt_f64(double d, double &r, double &s)
-{
-    double y = __builtin_amdgcn_rsq(d);
-    const double hd = 0.5 * d;
-    double t = __builtin_fma(-hd * y, y, 0.5);
-    y = __builtin_fma(y, t, y);
-    t = __builtin_fma(-hd * y, y, 0.5);
-    y = __builtin_fma(y, t, y);
-    double q = d * y;
-    const double e = __builtin_fma(-q, q, d);
-    q = __builtin_fma(0.5 * y, e, q);
-    r = y;
-    s = q;
-}
-
-// ---------------------------------------------------------------------------
-// 64x64 diagonal block: unblocked right-looking Cholesky by ONE wave.  Lane i
-// holds row i in 64 fp64 registers.  Per column: the pivot and the next
-// column's multiplier travel by v_readlane (short dependency chain), the other
-// multipliers l_k are broadcast through LDS (every lane reads the same
-// address), two per ds_read_b128.  Writes the lower triangle back and 1/L_jj
-// to dinv[64].  info[b] receives the 1-based global column of the first
-// non-positive pivot (first failure wins; 0 = ok).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void potf2_64_kernel(double *__restrict__ A, long lda,
-                                                      long astride, int j0,
-                                                      double *__restrict__ dinv, long dstride,
-                                                      int *__restrict__ info)
-{
-    __shared__ __attribute__((aligned(16))) double col[2][64];
-    // the panel is the critical path; under look-ahead it shares SIMDs with the
-    // trailing update's MFMA waves and should win instruction issue
-    __builtin_amdgcn_s_setprio(3);
-    const int b = blockIdx.z;
-    double *Ab = A + (long)b * astride + j0 + (long)j0 * lda;
-    const int lane = threadIdx.x;
-    double a[64];
-    {
-        const double *pr = Ab + lane;
-#pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            a[j] = *pr;
-            pr += lda;
-        }
-    }
-    int bad = 0;
-    double d = readlane_f64(a[0], 0);
-    double r, s;
-    double myr = 0.0; // lane j keeps 1 / L_jj
-    rsqrt_sqrt_f64(d, r, s);
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        if (!(d > 0.0) && bad == 0)
-            bad = j0 + j + 1;
-        const double l = (lane == j) ? s : a[j] * r;
-        a[j] = l;
-        myr = (lane == j) ? r : myr;
-        if (j < 63) {
-            double2_t lk[32];
-            if (j < 62) {
-                // broadcast reads of the column are issued first; the next
-                // pivot's readlane + rsqrt chain below runs under their latency
-                col[j & 1][lane] = l;
-                __syncthreads();
-                const double2_t *c2 = reinterpret_cast<const double2_t *>(col[j & 1]);
-#pragma unroll
-                for (int kk = (j + 2) >> 1; kk < 32; ++kk)
-                    lk[kk] = c2[kk];
-            }
-            a[j + 1] -= l * readlane_f64(l, j + 1);
-            d = readlane_f64(a[j + 1], j + 1);
-            rsqrt_sqrt_f64(d, r, s);
-            if (j < 62) {
-#pragma unroll
-                for (int kk = (j + 2) >> 1; kk < 32; ++kk) {
-                    if (2 * kk >= j + 2)
-                        a[2 * kk] -= l * lk[kk][0];
-                    a[2 * kk + 1] -= l * lk[kk][1];
-                }
-#pragma unroll
-                for (int k = j + 2; k < 64; ++k)
-                    PIN(a[k]);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    dinv[(long)b * dstride + lane] = myr;
-    // fresh per-lane pointer: without the opaque copy the compiler keeps the 64
-    // load addresses alive across the whole factorisation and spills
-    double *pw = Ab + lane;
-    asm volatile("" : "+v"(pw));
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        if (lane >= j)
-            *pw = a[j];
-        pw += lda;
-    }
-    if (lane == 0 && bad != 0 && info[b] == 0)
-        info[b] = bad;
-}
-
-// ---------------------------------------------------------------------------
-// 64x64 diagonal block by FOUR waves (one per SIMD).  Every wave holds all 64
-// rows (lane = row) and a quarter of the columns: wave w owns the columns
-// 16q + 4w + s (q, s = 0..3), i.e. the matrix is cut into sixteen 4-column
-// panels dealt round-robin to the waves.  Panel p is factored by its owner
-// (pivot chain as in potf2_64_kernel, the in-panel updates by v_readlane) and
-// published to a ring of three LDS slots; after ONE workgroup barrier per
-// panel every wave applies the rank-4 update to its own later columns.  The
-// owner of panel p+1 updates only that panel before starting its pivot chain
-// and catches up on its remaining columns one barrier later (the slot of panel
-// p stays valid that long), so the chain of rsqrt's -- the critical path of
-// the whole factorisation -- waits for 16 FMAs per panel instead of 64.
-// ---------------------------------------------------------------------------
-struct Potf2W {
-    double a[4][4]; // a[q][s] = column 16q + 4w + s of row `lane`
-    double myr;     // 1 / L_cc for the lane that is the pivot row of an owned column
-    int bad;
-};
-
-// rank-4 update of this wave's columns in group Q by the panel in `slot`
-template <int Q>
-__device__ __forceinline__ void potf2w_update_group(Potf2W &st, const double *slot,
-                                                    const double (&li)[4], int w)
-{
-    double2_t lk[4][2];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const double2_t *src = reinterpret_cast<const double2_t *>(slot + s * 64 + 16 * Q + 4 * w);
-        lk[s][0] = src[0];
-        lk[s][1] = src[1];
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        st.a[Q][0] -= li[s] * lk[s][0][0];
-        st.a[Q][1] -= li[s] * lk[s][0][1];
-        st.a[Q][2] -= li[s] * lk[s][1][0];
-        st.a[Q][3] -= li[s] * lk[s][1][1];
-    }
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc)
-        PIN(st.a[Q][cc]);
-}
-
-// factor panel P (columns 4P .. 4P+3, group QP = P>>2) held by this wave; publish
-template <int P>
-__device__ __forceinline__ void potf2w_factor(Potf2W &st, double *slot, int lane, int j0)
-{
-    constexpr int QP = P >> 2;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int c = 4 * P + s;
-        const double d = readlane_f64(st.a[QP][s], c);
-        if (!(d > 0.0) && st.bad == 0)
-            st.bad = j0 + c + 1;
-        double r, sq;
-        rsqrt_sqrt_f64(d, r, sq);
-        const double l = (lane == c) ? sq : st.a[QP][s] * r;
-        st.a[QP][s] = l;
-        st.myr = (lane == c) ? r : st.myr;
-#pragma unroll
-        for (int s2 = s + 1; s2 < 4; ++s2)
-            st.a[QP][s2] -= l * readlane_f64(l, 4 * P + s2);
-        slot[s * 64 + lane] = l;
-    }
-}
-
-template <int P>
-struct Potf2WSteps {
-    static __device__ __forceinline__ void run(Potf2W &st, double *ring, int w, int lane, int j0)
-    {
-        constexpr int QP = P >> 2, WP = P & 3;
-        constexpr int PN = P + 1, QN = PN >> 2, WN = PN & 3;
-        __syncthreads(); // panel P is published
-        const double *slot = ring + (P % 3) * 256;
-        if (P >= 1 && w == WP) {
-            // I factored panel P before touching my later groups with panel P-1
-            const double *prev = ring + ((P + 2) % 3) * 256;
-            double lp[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                lp[s] = prev[s * 64 + lane];
-            if (QP < 1) potf2w_update_group<1>(st, prev, lp, w);
-            if (QP < 2) potf2w_update_group<2>(st, prev, lp, w);
-            if (QP < 3) potf2w_update_group<3>(st, prev, lp, w);
-        }
-        double li[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            li[s] = slot[s * 64 + lane];
-        if (P < 15 && w == WN) {
-            // next owner: bring its panel up to date, then run the pivot chain
-            if (QN == 0) potf2w_update_group<0>(st, slot, li, w);
-            if (QN == 1) potf2w_update_group<1>(st, slot, li, w);
-            if (QN == 2) potf2w_update_group<2>(st, slot, li, w);
-            if (QN == 3) potf2w_update_group<3>(st, slot, li, w);
-            potf2w_factor<(P < 15 ? PN : 15)>(st, ring + (PN % 3) * 256, lane, j0);
-        } else {
-            // my columns of the panel's own group lie after it only if w > WP
-            if (w > WP) {
-                if (QP == 0) potf2w_update_group<0>(st, slot, li, w);
-                if (QP == 1) potf2w_update_group<1>(st, slot, li, w);
-                if (QP == 2) potf2w_update_group<2>(st, slot, li, w);
-                if (QP == 3) potf2w_update_group<3>(st, slot, li, w);
-            }
-            if (QP < 1) potf2w_update_group<1>(st, slot, li, w);
-            if (QP < 2) potf2w_update_group<2>(st, slot, li, w);
-            if (QP < 3) potf2w_update_group<3>(st, slot, li, w);
-        }
-        Potf2WSteps<P + 1>::run(st, ring, w, lane, j0);
-    }
-};
-template <>
-struct Potf2WSteps<16> {
-    static __device__ __forceinline__ void run(Potf2W &, double *, int, int, int) {}
-};
-
-// The factorisation proper, callable by any 256-thread workgroup: Ab points at
-// the 64x64 block (leading dimension lda), j0 is its global column (for the
-// failure report), dinv_b / info_b belong to this batch element.
-__device__ __forceinline__ void potf2_64x4_body(double *__restrict__ Ab, long lda, int j0,
-                                                double *__restrict__ dinv_b,
-                                                int *__restrict__ info_b, double *ring, int *sbad)
-{
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    Potf2W st;
-    st.myr = 0.0;
-    st.bad = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            st.a[q][s] = Ab[lane + (long)(16 * q + 4 * w + s) * lda];
-    if (w == 0)
-        potf2w_factor<0>(st, ring, lane, j0);
-    Potf2WSteps<0>::run(st, ring, w, lane, j0);
-    // write back the lower triangle of my columns, and my reciprocal pivots
-    {
-        double *pw = Ab + lane + (long)(4 * w) * lda;
-        asm volatile("" : "+v"(pw));
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                if (lane >= 16 * q + 4 * w + s)
-                    pw[(long)s * lda] = st.a[q][s];
-            pw += 16 * lda;
-        }
-    }
-    if (((lane >> 2) & 3) == w)
-        dinv_b[lane] = st.myr;
-    if (lane == 0)
-        sbad[w] = st.bad;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int first = 0;
-        for (int k = 0; k < 4; ++k)
-            if (sbad[k] != 0 && (first == 0 || sbad[k] < first))
-                first = sbad[k];
-        if (first != 0 && info_b[0] == 0)
-            info_b[0] = first;
-    }
-}
-
-__global__ __launch_bounds__(256) void potf2_64x4_kernel(double *__restrict__ A, long lda,
-                                                         long astride, int j0,
-                                                         double *__restrict__ dinv, long dstride,
-                                                         int *__restrict__ info)
-{
-    __shared__ __attribute__((aligned(16))) double ring[3 * 4 * 64];
-    __shared__ int sbad[4];
-    __builtin_amdgcn_s_setprio(3);
-    const int b = blockIdx.z;
-    potf2_64x4_body(A + (long)b * astride + j0 + (long)j0 * lda, lda, j0, dinv + (long)b * dstride,
-                    info + b, ring, sbad);
-}
-
-// ---------------------------------------------------------------------------
-// Panel solve, one row per lane, 64 columns in registers; one wave per block.
-//   TRANS = true : X <- X * L11^-T   (forward substitution; Cholesky panel,
-//                                     forward solves with rows = right-hand sides)
-//   TRANS = false: X <- X * L11^-1   (backward substitution; the L^T sweep)
-// X = rows of the panel (leading dimension ldx), L11 = 64x64 lower block
-// (leading dimension ldl) with reciprocal diagonal dinv[64].  L11 is staged
-// once into LDS (TRANS: as stored; else transposed) and its entries are read
-// back as wave-wide broadcasts, two per ds_read_b128.
-// ---------------------------------------------------------------------------
-template <bool TRANS>
-__global__ __launch_bounds__(64) void trsm_rows_kernel(double *__restrict__ X, long ldx,
-                                                       long xstride, int m,
-                                                       const double *__restrict__ Lm, long ldl,
-                                                       long lstride,
-                                                       const double *__restrict__ dinv,
-                                                       long dstride)
-{
-    // T[p][j]: multiplier of x_p in the update of x_j, rows of 64 doubles
-    __shared__ __attribute__((aligned(16))) double T[64 * 64];
-    __shared__ __attribute__((aligned(16))) double di[64];
-    __builtin_amdgcn_s_setprio(3);
-    const int b = blockIdx.z;
-    const int lane = threadIdx.x;
-    const int row = blockIdx.x * 64 + lane;
-    X += (long)b * xstride;
-    const double *L11 = Lm + (long)b * lstride;
-    if (TRANS) {
-        // x_j -= L11[j][p] x_p (j > p): T[p][j] = L11[j + p ldl], coalesced copy
-#pragma unroll 8
-        for (int p = 0; p < 64; ++p)
-            T[p * 64 + lane] = L11[lane + (long)p * ldl];
-    } else {
-        // x_j -= L11[p][j] x_p (j < p): T[p][j] = L11[p + j ldl]; lane = p keeps
-        // the global read coalesced, the LDS write is strided (once per block)
-#pragma unroll 8
-        for (int j = 0; j < 64; ++j)
-            T[lane * 64 + j] = L11[lane + (long)j * ldl];
-    }
-    di[lane] = dinv[(long)b * dstride + lane];
-    const bool ok = row < m;
-    double x[64];
-    {
-        const double *pr = X + (ok ? row : 0);
-#pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            x[j] = *pr;
-            pr += ldx;
-        }
-    }
-    __syncthreads();
-    // Row p of T is fetched one column step ahead of its use (T is static), so
-    // the LDS latency hides behind the previous step's FMAs.
-    double2_t cur[32], nxt[32];
-    if (TRANS) {
-        {
-            const double2_t *t2 = reinterpret_cast<const double2_t *>(T);
-#pragma unroll
-            for (int kk = 0; kk < 32; ++kk)
-                cur[kk] = t2[kk];
-        }
-#pragma unroll
-        for (int p = 0; p < 64; ++p) {
-            if (p < 63) {
-                const double2_t *t2 = reinterpret_cast<const double2_t *>(T + (p + 1) * 64);
-#pragma unroll
-                for (int kk = (p + 2) >> 1; kk < 32; ++kk)
-                    nxt[kk] = t2[kk];
-            }
-            const double xp = x[p] * di[p];
-            x[p] = xp;
-#pragma unroll
-            for (int kk = (p + 1) >> 1; kk < 32; ++kk) {
-                if (2 * kk >= p + 1)
-                    x[2 * kk] -= cur[kk][0] * xp;
-                x[2 * kk + 1] -= cur[kk][1] * xp;
-            }
-#pragma unroll
-            for (int j = p + 1; j < 64; ++j)
-                PIN(x[j]);
-#pragma unroll
-            for (int kk = (p + 2) >> 1; kk < 32; ++kk)
-                cur[kk] = nxt[kk];
-        }
-    } else {
-        {
-            const double2_t *t2 = reinterpret_cast<const double2_t *>(T + 63 * 64);
-#pragma unroll
-            for (int kk = 0; kk < 32; ++kk)
-                cur[kk] = t2[kk];
-        }
-#pragma unroll
-        for (int p = 63; p >= 0; --p) {
-            if (p > 0) {
-                const double2_t *t2 = reinterpret_cast<const double2_t *>(T + (p - 1) * 64);
-#pragma unroll
-                for (int kk = 0; 2 * kk < p - 1; ++kk)
-                    nxt[kk] = t2[kk];
-            }
-            const double xp = x[p] * di[p];
-            x[p] = xp;
-#pragma unroll
-            for (int kk = 0; 2 * kk < p; ++kk) {
-                x[2 * kk] -= cur[kk][0] * xp;
-                if (2 * kk + 1 < p)
-                    x[2 * kk + 1] -= cur[kk][1] * xp;
-            }
-#pragma unroll
-            for (int j = 0; j < p; ++j)
-                PIN(x[j]);
-#pragma unroll
-            for (int kk = 0; 2 * kk < p - 1; ++kk)
-                cur[kk] = nxt[kk];
-        }
-    }
-    if (ok) {
-        double *pw = X + row; // opaque copy: see potf2_64_kernel
-        asm volatile("" : "+v"(pw));
-#pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            *pw = x[j];
-            pw += ldx;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Panel solve, FOUR lanes per row (a wave = 16 rows): the latency-oriented
-// variant used when the panel is short (few rows per CU).  Lane l works on row
-// l>>2 and on the 16 columns {8kk + 2g, 8kk + 2g + 1}, g = l&3, kk = 0..7, so a
-// column step costs each lane at most 16 FMAs instead of 63; the solved entry
-// x_p is handed to the other three lanes of the quad by DPP quad_perm.  The
-// multipliers come from an LDS copy of L11 whose inapplicable entries (j <= p,
-// or j >= p for the backward form) are stored as zeros, so the update needs no
-// per-lane predicate; lanes with equal g read the same address (broadcast).
-// ---------------------------------------------------------------------------
-template <int G>
-__device__ __forceinline__ double quad_bcast_f64(double v)
-{
-    constexpr int ctrl = G | (G << 2) | (G << 4) | (G << 6); // quad_perm:[G,G,G,G]
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
-template <bool TRANS, int P>
-__device__ __forceinline__ void trsm_quad_step(double (&x)[8][2], const double *T, const double *di,
-                                               int g, double2_t (&cur)[8], double2_t (&nxt)[8])
-{
-    constexpr int KK = P >> 3, GP = (P >> 1) & 3, SL = P & 1;
-    constexpr int PN = TRANS ? P + 1 : P - 1; // next column step
-    if (PN >= 0 && PN < 64) {
-        const double2_t *t2 = reinterpret_cast<const double2_t *>(T + PN * 64);
-        if (TRANS) {
-#pragma unroll
-            for (int kk = (PN >> 3); kk < 8; ++kk)
-                nxt[kk] = t2[4 * kk + g];
-        } else {
-#pragma unroll
-            for (int kk = 0; kk <= (PN >> 3); ++kk)
-                nxt[kk] = t2[4 * kk + g];
-        }
-    }
-    const double mine = x[KK][SL] * di[P];
-    const double xp = quad_bcast_f64<GP>(mine);
-    x[KK][SL] = (g == GP) ? xp : x[KK][SL];
-    if (TRANS) {
-#pragma unroll
-        for (int kk = KK; kk < 8; ++kk) {
-            x[kk][0] -= cur[kk][0] * xp;
-            x[kk][1] -= cur[kk][1] * xp;
-        }
-#pragma unroll
-        for (int kk = KK; kk < 8; ++kk) {
-            PIN(x[kk][0]);
-            PIN(x[kk][1]);
-        }
-    } else {
-#pragma unroll
-        for (int kk = 0; kk <= KK; ++kk) {
-            x[kk][0] -= cur[kk][0] * xp;
-            x[kk][1] -= cur[kk][1] * xp;
-        }
-#pragma unroll
-        for (int kk = 0; kk <= KK; ++kk) {
-            PIN(x[kk][0]);
-            PIN(x[kk][1]);
-        }
-    }
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk)
-        cur[kk] = nxt[kk];
-}
-
-template <bool TRANS, int P>
-struct TrsmQuadSteps {
-    static __device__ __forceinline__ void run(double (&x)[8][2], const double *T, const double *di,
-                                               int g, double2_t (&cur)[8], double2_t (&nxt)[8])
-    {
-        trsm_quad_step<TRANS, TRANS ? P : 63 - P>(x, T, di, g, cur, nxt);
-        TrsmQuadSteps<TRANS, P + 1>::run(x, T, di, g, cur, nxt);
-    }
-};
-template <bool TRANS>
-struct TrsmQuadSteps<TRANS, 64> {
-    static __device__ __forceinline__ void run(double (&)[8][2], const double *, const double *, int,
-                                               double2_t (&)[8], double2_t (&)[8])
-    {
-    }
-};
-
-template <bool TRANS>
-__global__ __launch_bounds__(64) void trsm_quad_kernel(double *__restrict__ X, long ldx,
-                                                       long xstride, int m,
-                                                       const double *__restrict__ Lm, long ldl,
-                                                       long lstride,
-                                                       const double *__restrict__ dinv,
-                                                       long dstride)
-{
-    __shared__ __attribute__((aligned(16))) double T[64 * 64];
-    __shared__ __attribute__((aligned(16))) double di[64];
-    __builtin_amdgcn_s_setprio(3);
-    const int b = blockIdx.z;
-    const int lane = threadIdx.x;
-    const int g = lane & 3;
-    const int row = blockIdx.x * 16 + (lane >> 2);
-    X += (long)b * xstride;
-    const double *L11 = Lm + (long)b * lstride;
-    if (TRANS) {
-        // T[p][j] = L11[j][p] for j > p, else 0
-#pragma unroll 8
-        for (int p = 0; p < 64; ++p) {
-            const double v = L11[lane + (long)p * ldl];
-            T[p * 64 + lane] = (lane > p) ? v : 0.0;
-        }
-    } else {
-        // T[p][j] = L11[p][j] for j < p, else 0 (lane = p: coalesced global read)
-#pragma unroll 8
-        for (int j = 0; j < 64; ++j) {
-            const double v = L11[lane + (long)j * ldl];
-            T[lane * 64 + j] = (j < lane) ? v : 0.0;
-        }
-    }
-    di[lane] = dinv[(long)b * dstride + lane];
-    const bool ok = row < m;
-    double x[8][2];
-    {
-        const double *pr = X + (ok ? row : 0) + (long)(2 * g) * ldx;
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            x[kk][0] = pr[0];
-            x[kk][1] = pr[ldx];
-            pr += 8 * ldx;
-        }
-    }
-    __syncthreads();
-    double2_t cur[8], nxt[8];
-    {
-        const double2_t *t2 = reinterpret_cast<const double2_t *>(T + (TRANS ? 0 : 63) * 64);
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            cur[kk] = t2[4 * kk + g];
-            nxt[kk] = cur[kk];
-        }
-    }
-    TrsmQuadSteps<TRANS, 0>::run(x, T, di, g, cur, nxt);
-    if (ok) {
-        double *pw = X + row + (long)(2 * g) * ldx;
-        asm volatile("" : "+v"(pw));
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            pw[0] = x[kk][0];
-            pw[ldx] = x[kk][1];
-            pw += 8 * ldx;
-        }
-    }
-}
-
-// reciprocal diagonal of a resident factor: dinv[j] = 1 / L[j0+j, j0+j]
-__global__ void diag_recip_kernel(const double *__restrict__ Lm, long ldl, long lstride, int n,
-                                  double *__restrict__ dinv, long dstride)
-{
-    const int b = blockIdx.z;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n)
-        dinv[(long)b * dstride + j] = 1.0 / Lm[(long)b * lstride + j + (long)j * ldl];
-}
-
-// ---------------------------------------------------------------------------
-// C(m x n) -= P(m x k) * Q(n x k)^T on v_mfma_f64_16x16x4_f64.
-//
-// P element (i,kk) at P[i + kk*ldp].  Q element (j,kk) at Q[j*qsj + kk*qsk]:
-//   (qsj,qsk) = (1, ldq)  -> Q^T product (Cholesky panel / trailing update)
-//   (qsj,qsk) = (ldq, 1)  -> plain product with a k x n matrix (L^T sweep)
-// A workgroup is 4 waves in a 2 x 2 arrangement; each wave owns a
-// (16 TM) x (16 TN) tile built from TM x TN MFMA tiles and streams its A/B
-// fragments straight from global memory (L2-resident panel) into registers,
-// software-pipelined one k-step (4 columns) ahead.  The MFMA is issued as
-// D^T = Q_frag * P_frag^T so that the 16 lanes that share a D register row
-// cover 16 consecutive ROWS of C: the read-modify-write of C then moves whole
-// 128-byte lines (C is column-major).
-//   f64 16x16x4 operand map: lane l supplies A[l&15][l>>4] and B[l>>4][l&15];
-//   D register r of lane l is D[(l>>4) + 4 r][l & 15]   (probed on gfx950 by
-//   bq_probe_mfma_layout; tests/test_gpu_probe.py asserts it).
-// lower != 0: skip wave tiles that lie strictly above the diagonal of C
-// (C square, trailing update); m, n multiples of 16 TM / 16 TN are not
-// required, out-of-range wave tiles exit, but m and n must be multiples of 16
-// and k a multiple of 8.
-// ---------------------------------------------------------------------------
-// 1-D grid over the lower-triangular workgroup tiles of a square update:
-// t -> (bx, by), by <= bx, row by row, so no empty workgroups are launched (at
-// N=16384 the 2-D grid's early-exit workgroups cost 8 % of the trailing update)
-__device__ __forceinline__ void tri_decode(int t, int &bx, int &by)
-{
-    bx = (int)((__builtin_sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-    while ((bx + 1) * (bx + 2) / 2 <= t)
-        ++bx;
-    while (bx * (bx + 1) / 2 > t)
-        --bx;
-    by = t - bx * (bx + 1) / 2;
-}
-
-// one wave tile of C -= P Q^T (see gemm_sub_kernel); C, P, Q already point at the batch element
-template <int TM, int TN>
-__device__ __forceinline__ void gemm_sub_tile(double *__restrict__ C, long ldc,
-                                              const double *__restrict__ P, long ldp,
-                                              const double *__restrict__ Q, long qsj, long qsk,
-                                              int m, int n, int k, int lower, int row0, int col0,
-                                              int lane)
-{
-    const int l15 = lane & 15, l4 = lane >> 4;
-
-    // clamp fragment rows at the edge (m, n multiples of 16 but maybe not of
-    // the wave tile): out-of-range MFMA tiles are computed on clamped rows and
-    // dropped at the store.
-    const double *pp[TM];
-    const double *qq[TN];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        int r = row0 + tm * 16;
-        if (r >= m)
-            r = row0;
-        pp[tm] = P + r + l15 + (long)l4 * ldp;
-    }
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        int c = col0 + tn * 16;
-        if (c >= n)
-            c = col0;
-        qq[tn] = Q + (long)(c + l15) * qsj + (long)l4 * qsk;
-    }
-
-    double4_t acc[TM][TN];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
-    double pa[TM], qa[TN], pb[TM], qb[TN];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-        pa[tm] = pp[tm][0];
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-        qa[tn] = qq[tn][0];
-    const long pstep = 4 * ldp, qstep = 4 * qsk;
-    const int ksteps = k >> 2; // even (k is a multiple of 8): the body below has no branch
-    for (int ks = 0; ks < ksteps; ks += 2) {
-        // fragments of step ks+1 are requested before the MFMAs of step ks issue,
-        // those of step ks+2 before the MFMAs of step ks+1.  The scheduling
-        // barriers keep that order: without them the scheduler sinks each load
-        // group down to its first use and the prefetch distance collapses to zero.
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-            pb[tm] = pp[tm][(long)(ks + 1) * pstep];
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-            qb[tn] = qq[tn][(long)(ks + 1) * qstep];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                acc[tm][tn] =
-                    __builtin_amdgcn_mfma_f64_16x16x4f64(qa[tn], pa[tm], acc[tm][tn], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        const long o2 = (ks + 2 < ksteps) ? (long)(ks + 2) : (long)ks; // clamped, value unused
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-            pa[tm] = pp[tm][o2 * pstep];
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-            qa[tn] = qq[tn][o2 * qstep];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                acc[tm][tn] =
-                    __builtin_amdgcn_mfma_f64_16x16x4f64(qb[tn], pb[tm], acc[tm][tn], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // D^T tile: D[jj][ii], jj = l4 + 4 r (column of C), ii = l15 (row of C)
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        const int r = row0 + tm * 16;
-        if (r >= m)
-            continue;
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int c = col0 + tn * 16;
-            if (c >= n)
-                continue;
-            if (lower && c >= r + 16)
-                continue;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                double *dst = C + (r + l15) + (long)(c + l4 + 4 * rr) * ldc;
-                *dst -= acc[tm][tn][rr];
-            }
-        }
-    }
-}
-
-// Fused diagonal factor: when fuse_j0 >= 0 the launch also factors the leading 64x64
-// block of C (the next diagonal block of the Cholesky) right after updating it.
-// Workgroup 0 owns every workgroup tile that intersects that block, updates them,
-// and runs potf2_64x4_body on the result; the other workgroups of the block exit.
-// This removes one dependent launch (and the block's trip through L2) per 64 columns.
-template <int TM, int TN>
-__global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C, long ldc,
-                                                          long cstride, const double *__restrict__ P,
-                                                          long ldp, long pstride,
-                                                          const double *__restrict__ Q, long qsj,
-                                                          long qsk, long qstride, int m, int n,
-                                                          int k, int lower, int fuse_j0,
-                                                          double *__restrict__ dinv, long dstride,
-                                                          int *__restrict__ info)
-{
-    __shared__ __attribute__((aligned(16))) double ring[3 * 4 * 64];
-    __shared__ int sbad[4];
-    const int b = blockIdx.z;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (lower == 2)
-        tri_decode(blockIdx.x, bx, by);
-    C += (long)b * cstride;
-    P += (long)b * pstride;
-    Q += (long)b * qstride;
-    constexpr int WT = 32 * TM; // rows (and, TM == TN, columns) of a workgroup tile
-    if (fuse_j0 >= 0 && bx * WT < 64 && by * (32 * TN) < 64) {
-        if (bx != 0 || by != 0)
-            return; // inside the diagonal block: workgroup 0 does it
-        constexpr int NS = (WT >= 64) ? 1 : 64 / WT;
-        for (int sx = 0; sx < NS; ++sx)
-            for (int sy = 0; sy <= sx; ++sy) {
-                const int row0 = (sx * 2 + (wave & 1)) * (TM * 16);
-                const int col0 = (sy * 2 + (wave >> 1)) * (TN * 16);
-                if (row0 < m && col0 < n && !(lower && col0 >= row0 + TM * 16))
-                    gemm_sub_tile<TM, TN>(C, ldc, P, ldp, Q, qsj, qsk, m, n, k, lower, row0, col0,
-                                          lane);
-            }
-        __syncthreads(); // the updated block is visible to the whole workgroup
-        potf2_64x4_body(C, ldc, fuse_j0, dinv + (long)b * dstride, info + b, ring, sbad);
-        return;
-    }
-    const int row0 = (bx * 2 + (wave & 1)) * (TM * 16);
-    const int col0 = (by * 2 + (wave >> 1)) * (TN * 16);
-    if (row0 >= m || col0 >= n)
-        return;
-    if (lower && col0 >= row0 + TM * 16)
-        return;
-    gemm_sub_tile<TM, TN>(C, ldc, P, ldp, Q, qsj, qsk, m, n, k, lower, row0, col0, lane);
-}
-
-// ---------------------------------------------------------------------------
-// The same product for k == 64 exactly (the trailing / panel update of small
-// systems, outer block 64): all 16 k-steps of fragments are requested up front
-// and the MFMAs drain them as they land, so a tile costs one memory round trip
-// instead of sixteen.  TM, TN <= 2.
-// ---------------------------------------------------------------------------
-template <int TM, int TN>
-__device__ __forceinline__ void gemm_k64_tile(double *__restrict__ C, long ldc,
-                                              const double *__restrict__ P, long ldp,
-                                              const double *__restrict__ Q, long qsj, long qsk,
-                                              int m, int n, int lower, int row0, int col0, int lane)
-{
-    const int l15 = lane & 15, l4 = lane >> 4;
-    double pa[16][TM], qa[16][TN];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        int r = row0 + tm * 16;
-        if (r >= m)
-            r = row0;
-        const double *pp = P + r + l15 + (long)l4 * ldp;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks)
-            pa[ks][tm] = pp[(long)ks * 4 * ldp];
-    }
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        int c = col0 + tn * 16;
-        if (c >= n)
-            c = col0;
-        const double *qq = Q + (long)(c + l15) * qsj + (long)l4 * qsk;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks)
-            qa[ks][tn] = qq[(long)ks * 4 * qsk];
-    }
-    // C is read while the fragments are in flight
-    double cold[TM][TN][4];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                int r = row0 + tm * 16, c = col0 + tn * 16;
-                if (r >= m) r = row0;
-                if (c >= n) c = col0;
-                cold[tm][tn][rr] = C[(r + l15) + (long)(c + l4 + 4 * rr) * ldc];
-            }
-    // every load above is issued before the first MFMA (the scheduler otherwise
-    // interleaves them to save registers and serialises the round trips)
-    __builtin_amdgcn_sched_barrier(0);
-    double4_t acc[TM][TN];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[ks][tn], pa[ks][tm],
-                                                                   acc[tm][tn], 0, 0, 0);
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        const int r = row0 + tm * 16;
-        if (r >= m)
-            continue;
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int c = col0 + tn * 16;
-            if (c >= n)
-                continue;
-            if (lower && c >= r + 16)
-                continue;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-                C[(r + l15) + (long)(c + l4 + 4 * rr) * ldc] = cold[tm][tn][rr] - acc[tm][tn][rr];
-        }
-    }
-}
-
-template <int TM, int TN>
-__global__ __launch_bounds__(256) void gemm_k64_kernel(double *__restrict__ C, long ldc,
-                                                       long cstride, const double *__restrict__ P,
-                                                       long ldp, long pstride,
-                                                       const double *__restrict__ Q, long qsj,
-                                                       long qsk, long qstride, int m, int n,
-                                                       int lower, int fuse_j0,
-                                                       double *__restrict__ dinv, long dstride,
-                                                       int *__restrict__ info)
-{
-    __shared__ __attribute__((aligned(16))) double ring[3 * 4 * 64];
-    __shared__ int sbad[4];
-    const int b = blockIdx.z;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (lower == 2)
-        tri_decode(blockIdx.x, bx, by);
-    C += (long)b * cstride;
-    P += (long)b * pstride;
-    Q += (long)b * qstride;
-    constexpr int WT = 32 * TM;
-    if (fuse_j0 >= 0 && bx * WT < 64 && by * (32 * TN) < 64) { // see gemm_sub_kernel
-        if (bx != 0 || by != 0)
-            return;
-        constexpr int NS = (WT >= 64) ? 1 : 64 / WT;
-        for (int sx = 0; sx < NS; ++sx)
-            for (int sy = 0; sy <= sx; ++sy) {
-                const int row0 = (sx * 2 + (wave & 1)) * (TM * 16);
-                const int col0 = (sy * 2 + (wave >> 1)) * (TN * 16);
-                if (row0 < m && col0 < n && !(lower && col0 >= row0 + TM * 16))
-                    gemm_k64_tile<TM, TN>(C, ldc, P, ldp, Q, qsj, qsk, m, n, lower, row0, col0,
-                                          lane);
-            }
-        __syncthreads();
-        potf2_64x4_body(C, ldc, fuse_j0, dinv + (long)b * dstride, info + b, ring, sbad);
-        return;
-    }
-    const int row0 = (bx * 2 + (wave & 1)) * (TM * 16);
-    const int col0 = (by * 2 + (wave >> 1)) * (TN * 16);
-    if (row0 >= m || col0 >= n)
-        return;
-    if (lower && col0 >= row0 + TM * 16)
-        return;
-    gemm_k64_tile<TM, TN>(C, ldc, P, ldp, Q, qsj, qsk, m, n, lower, row0, col0, lane);
-}
-
-// ---------------------------------------------------------------------------
-// Read-out after the bordered elimination (one block per problem):
-//   logdet = 2 sum_{i<n} log L_ii,  qf = -S[yrow,yrow] = y' Kxx^-1 y,
-//   logml  = -qf/2 - logdet/2 - n/2 log 2 pi,
-//   mean_i = -S[yrow, i],  var_i = S[i,i]   (S = Schur complement at npad)
-// scal[b*4 + {0,1,2}] = logml, logdet, qf.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict__ A, long lda,
-                                                       long astride, Layout L,
-                                                       double *__restrict__ scal,
-                                                       double *__restrict__ mean,
-                                                       double *__restrict__ var, long mstride)
-{
-    const int b = blockIdx.z;
-    A += (long)b * astride;
-    const int t = threadIdx.x;
-    double s = 0.0;
-    for (int i = t; i < L.n; i += 256)
-        s += log(A[i + (long)i * lda]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        s += __shfl_down(s, off, 64);
-    __shared__ double part[4];
-    if ((t & 63) == 0)
-        part[t >> 6] = s;
-    __syncthreads();
-    if (t == 0) {
-        const double logdet = 2.0 * (part[0] + part[1] + part[2] + part[3]);
-        double qf = 0.0, logml = 0.0;
-        if (L.yrow >= 0) {
-            qf = -A[L.yrow + (long)L.yrow * lda];
-            logml = -0.5 * qf - 0.5 * logdet - 0.5 * (double)L.n * 1.8378770664093453; // log 2pi
-        }
-        scal[b * 4 + 0] = logml;
-        scal[b * 4 + 1] = logdet;
-        scal[b * 4 + 2] = qf;
-    }
-    for (int i = t; i < L.M; i += 256) {
-        const long c = L.npad + i;
-        if (var)
-            var[(long)b * mstride + i] = A[c + c * lda];
-        if (mean && L.yrow >= 0)
-            mean[(long)b * mstride + i] = -A[L.yrow + c * lda];
-    }
-}
-
-// per-row reductions of a solved border V (m x n, ld = ldv), z (n):
-//   mean_i = sum_j V[i,j] z[j],   var_i = k0 - sum_j V[i,j]^2
-__global__ __launch_bounds__(256) void rowdot_kernel(const double *__restrict__ V, long ldv, int m,
-                                                     int n, const double *__restrict__ z,
-                                                     double k0, double *__restrict__ mean,
-                                                     double *__restrict__ var)
-{
-    // block = 64 rows x 4 column slices
-    const int t = threadIdx.x;
-    const int row = blockIdx.x * 64 + (t & 63);
-    const int sl = t >> 6;
-    double sm = 0.0, sv = 0.0;
-    if (row < m)
-        for (int j = sl; j < n; j += 4) {
-            const double v = V[row + (long)j * ldv];
-            sm += v * (z ? z[j] : 0.0);
-            sv += v * v;
-        }
-    __shared__ double pm[4][64], pv[4][64];
-    pm[sl][t & 63] = sm;
-    pv[sl][t & 63] = sv;
-    __syncthreads();
-    if (sl == 0 && row < m) {
-        const int r = t & 63;
-        if (mean)
-            mean[row] = (pm[0][r] + pm[1][r]) + (pm[2][r] + pm[3][r]);
-        if (var)
-            var[row] = k0 - ((pv[0][r] + pv[1][r]) + (pv[2][r] + pv[3][r]));
-    }
-}
-
-// mean_i = sum_j k(xo_i, x_j) alpha_j : fused cross-Gram x GEMV, one wave per
-// 64 outputs?  No: one block of 256 threads per output point slice would
-// starve; use one wave per output point, lanes stride over j.
-template <int D>
-__global__ __launch_bounds__(256) void predict_mean_kernel(const double *__restrict__ xo, int M,
-                                                           const double *__restrict__ x, int n,
-                                                           const double *__restrict__ alpha,
-                                                           GaussParams g, double *__restrict__ mean)
-{
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + wave;
-    if (i >= M)
-        return;
-    double p[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k)
-        p[k] = xo[k + (long)i * D];
-    double s = 0.0;
-    for (int j = lane; j < n; j += 64) {
-        double q[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k)
-            q[k] = x[k + (long)j * D];
-        s += exp_gauss(gauss_q<D>(p, q, g)) * alpha[j];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        s += __shfl_down(s, off, 64);
-    if (lane == 0)
-        mean[i] = g.c * s;
-}
-
-// dst(rows x cols, ld ldd) <- src(rows x cols, ld lds); optional transpose
-__global__ void copy2d_kernel(double *__restrict__ dst, long ldd, const double *__restrict__ src,
-                              long lds, int rows, int cols, int transpose_src)
-{
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int j0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
-    if (i >= rows)
-        return;
-    for (int j = j0; j < j0 + 4 && j < cols; ++j)
-        dst[i + (long)j * ldd] = transpose_src ? src[j + (long)i * lds] : src[i + (long)j * lds];
-}
-
-// A <- identity on the padding square [n, ntot) and zero in the padding
-// rows/cols of the lower triangle (used by the linalg drop-ins)
-__global__ void pad_identity_kernel(double *__restrict__ A, long lda, int n, int ntot)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int j = blockIdx.y;
-    if (i >= ntot || j >= ntot)
-        return;
-    if (i >= n || j >= n)
-        A[i + (long)j * lda] = (i == j) ? 1.0 : 0.0;
-}
-
-// 2 sum log diag, one block
-__global__ __launch_bounds__(256) void logdet_kernel(const double *__restrict__ A, long lda, int n,
-                                                     double *__restrict__ out)
-{
-    const int t = threadIdx.x;
-    double s = 0.0;
-    for (int i = t; i < n; i += 256)
-        s += log(A[i + (long)i * lda]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        s += __shfl_down(s, off, 64);
-    __shared__ double part[4];
-    if ((t & 63) == 0)
-        part[t >> 6] = s;
-    __syncthreads();
-    if (t == 0)
-        out[0] = 2.0 * (part[0] + part[1] + part[2] + part[3]);
-}
-
-// ---------------------------------------------------------------------------
-// hardware probes
-// ---------------------------------------------------------------------------
-// relative error of the raw v_rsq_f64 seed, of one and of two Newton steps, against
-// the correctly rounded 1/sqrt; out[3*i + k]
-__global__ void probe_rsq_kernel(const double *x, double *out, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
-        return;
-    const double d = x[i];
-    const double ref = 1.0 / sqrt(d);
-    double y = __builtin_amdgcn_rsq(d);
-    out[3 * i] = fabs(y - ref) / ref;
-    const double hd = 0.5 * d;
-    double t = __builtin_fma(-hd * y, y, 0.5);
-    y = __builtin_fma(y, t, y);
-    out[3 * i + 1] = fabs(y - ref) / ref;
-    t = __builtin_fma(-hd * y, y, 0.5);
-    y = __builtin_fma(y, t, y);
-    out[3 * i + 2] = fabs(y - ref) / ref;
-}
-
-__global__ void probe_empty_kernel(double *out)
-{
-    if (out == nullptr && threadIdx.x == 9999)
-        out[0] = 0.0;
-}
-
-__global__ __launch_bounds__(256) void probe_mfma_kernel(double *out, int iters)
-{
-    double4_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
-    const double a = 1.0 + threadIdx.x * 1e-9, bb = 1.0 - threadIdx.x * 1e-9;
-    for (int i = 0; i < iters; ++i) {
-        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c1, 0, 0, 0);
-        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c2, 0, 0, 0);
-        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c3, 0, 0, 0);
-    }
-    c0 += c1 + c2 + c3;
-    if (c0[0] == 123.456)
-        out[0] = c0[1];
-}
-
-__global__ __launch_bounds__(256) void probe_fma_kernel(double *out, int iters)
-{
-    double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5,
-           a6 = a0 + 6, a7 = a0 + 7;
-    const double m = 0.999999, c = 1e-9;
-    for (int i = 0; i < iters; ++i) {
-        a0 = a0 * m + c; a1 = a1 * m + c; a2 = a2 * m + c; a3 = a3 * m + c;
-        a4 = a4 * m + c; a5 = a5 * m + c; a6 = a6 * m + c; a7 = a7 * m + c;
-    }
-    const double s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
-    if (s == 123.456)
-        out[0] = s;
-}
-
-__global__ __launch_bounds__(256) void probe_write_kernel(double2_t *dst, size_t n2)
-{
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * 256;
-    const double2_t v = {1.0, 2.0};
-    for (; i < n2; i += stride)
-        dst[i] = v;
-}
-
-__global__ __launch_bounds__(256) void probe_copy_kernel(double2_t *dst, const double2_t *src,
-                                                         size_t n2)
-{
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (; i < n2; i += stride)
-        dst[i] = src[i];
-}
-
-// D = A B with A[i][k] = i (row tag), B[k][j] = [k==0] * 1 ... we want each D
-// element to carry row*16+col: use A[i][k] = (k==0) ? i*16 : (k==1 ? 1 : 0),
-// B[k][j] = (k==0) ? 1 : (k==1 ? j : 0)  ->  D[i][j] = 16 i + j.
-__global__ void probe_layout_kernel(double *out)
-{
-    const int l = threadIdx.x;
-    const int i = l & 15, k = l >> 4;
-    const double a = (k == 0) ? 16.0 * i : (k == 1 ? 1.0 : 0.0);
-    const double bb = (k == 0) ? 1.0 : (k == 1 ? (double)(l & 15) : 0.0);
-    double4_t c = {0, 0, 0, 0};
-    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c, 0, 0, 0);
-    for (int r = 0; r < 4; ++r)
-        out[l * 4 + r] = c[r];
-}
-
-// ===========================================================================
-// Closed-form Gaussian-kernel integrals (gauss_c.pyx) and the BQ moments that
-// consume them (bq_c.pyx:157-213,264-355).  Each result is
-//     scale * exp( log N(z | 0, C) + per-point terms ),
-// with z a D-vector built from one or two points.  The host supplies the
-// inverse Cholesky factor of the small D x D covariance (D <= 16), so the
-// Mahalanobis term is || Linv z ||^2 with no division on the device.
-// ===========================================================================
-template <int D>
-struct GaussForm {
-    double mu[D];        // subtracted from the point(s) to form z
-    double linv[D * D];  // row-major lower-triangular inverse Cholesky factor
-    double logc;         // -(D log 2pi + log|C|) / 2
-};
-
-template <int D>
-__device__ __forceinline__ double gauss_form_eval(const GaussForm<D> &f, const double (&z)[D])
-{
-    double maha = 0.0;
-#pragma unroll
-    for (int r = 0; r < D; ++r) {
-        double y = 0.0;
-#pragma unroll
-        for (int c = 0; c <= r; ++c)
-            y += f.linv[r * D + c] * z[c];
-        maha += y * y;
-    }
-    return f.logc - 0.5 * maha;
-}
-
-// out_i = scale * exp(add + log N(x_i - mu | 0, C)); also, if alpha != null,
-// accumulates sum_i out_i alpha_i into acc[0] (Z_mean) -- one block per 256 points
-template <int D>
-__global__ __launch_bounds__(256) void int_K_kernel(const double *__restrict__ x, int n,
-                                                    GaussForm<D> f, double scale, double add,
-                                                    double *__restrict__ out,
-                                                    const double *__restrict__ alpha,
-                                                    double *__restrict__ acc)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    double v = 0.0;
-    if (i < n) {
-        double z[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k)
-            z[k] = x[k + (long)i * D] - f.mu[k];
-        v = scale * exp(add + gauss_form_eval<D>(f, z));
-        if (out)
-            out[i] = v;
-        if (alpha)
-            v *= alpha[i];
-    }
-    if (acc) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-            v += __shfl_down(v, off, 64);
-        __shared__ double part[4];
-        if ((threadIdx.x & 63) == 0)
-            part[threadIdx.x >> 6] = v;
-        __syncthreads();
-        if (threadIdx.x == 0)
-            acc[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
-    }
-}
-
-// out_ij = scale * exp(log N([x1_i - mu; x2_j - mu] | 0, C2)), n1 x n2 column-major.
-// With alpha (length n2) and beta (length n1): beta_i = sum_j out_ij alpha_j is
-// accumulated instead of (or besides) storing the matrix; one block = 64 rows,
-// its four waves split the columns.
-template <int D>
-__global__ __launch_bounds__(256) void int_K1_K2_kernel(const double *__restrict__ x1, int n1,
-                                                        const double *__restrict__ x2, int n2,
-                                                        GaussForm<2 * D> f, double scale,
-                                                        double *__restrict__ out,
-                                                        const double *__restrict__ alpha,
-                                                        double *__restrict__ beta)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + lane;
-    double z[2 * D];
-    const bool ok = i < n1;
-#pragma unroll
-    for (int k = 0; k < D; ++k)
-        z[k] = ok ? x1[k + (long)i * D] - f.mu[k] : 0.0;
-    double acc = 0.0;
-    for (int j = wave; j < n2; j += 4) {
-#pragma unroll
-        for (int k = 0; k < D; ++k)
-            z[D + k] = x2[k + (long)j * D] - f.mu[D + k];
-        const double v = scale * exp(gauss_form_eval<2 * D>(f, z));
-        if (out && ok)
-            out[i + (long)j * n1] = v;
-        if (alpha)
-            acc += v * alpha[j];
-    }
-    if (beta) {
-        __shared__ double part[4][64];
-        part[wave][lane] = acc;
-        __syncthreads();
-        if (wave == 0 && ok)
-            beta[i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-    }
-}
-
-// out_ij = scale * exp(n1_i + n1_j + log N(b_i - b_j | 0, C)), n x n; with alpha the
-// bilinear form sum_ij alpha_i alpha_j out_ij goes to acc[block] instead.
-template <int D>
-__global__ __launch_bounds__(256) void int_int_K1_K2_K1_kernel(const double *__restrict__ bpts,
-                                                               const double *__restrict__ n1v,
-                                                               int n, GaussForm<D> f, double scale,
-                                                               double *__restrict__ out,
-                                                               const double *__restrict__ alpha,
-                                                               double *__restrict__ acc)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + lane;
-    const bool ok = i < n;
-    double bi[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k)
-        bi[k] = ok ? bpts[k + (long)i * D] : 0.0;
-    const double ni = ok ? n1v[i] : 0.0;
-    const double ai = (alpha && ok) ? alpha[i] : 0.0;
-    double sum = 0.0;
-    const int j0 = blockIdx.y * 256;
-    const int j1 = (j0 + 256 < n) ? j0 + 256 : n;
-    for (int j = j0 + wave; j < j1; j += 4) {
-        double z[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k)
-            z[k] = bi[k] - bpts[k + (long)j * D];
-        const double v = scale * exp(ni + n1v[j] + gauss_form_eval<D>(f, z));
-        if (out && ok)
-            out[i + (long)j * n] = v;
-        if (alpha)
-            sum += ai * v * alpha[j];
-    }
-    if (acc) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-            sum += __shfl_down(sum, off, 64);
-        __shared__ double part[4];
-        if (lane == 0)
-            part[wave] = sum;
-        __syncthreads();
-        if (threadIdx.x == 0)
-            acc[blockIdx.x + (long)blockIdx.y * gridDim.x] = (part[0] + part[1]) + (part[2] + part[3]);
-    }
-}
-
-// b_i = G x_i (D x D, row-major G), n1_i = log N(x_i - mu | 0, C1)
-template <int D>
-__global__ __launch_bounds__(256) void iikk_prepare_kernel(const double *__restrict__ x, int n,
-                                                           GaussForm<D> f1, GaussForm<D> g,
-                                                           double *__restrict__ bpts,
-                                                           double *__restrict__ n1v)
-{
-    // g.linv carries the full D x D matrix G (row-major), g.mu / g.logc unused
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n)
-        return;
-    double xi[D], z[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        xi[k] = x[k + (long)i * D];
-        z[k] = xi[k] - f1.mu[k];
-    }
-    n1v[i] = gauss_form_eval<D>(f1, z);
-#pragma unroll
-    for (int r = 0; r < D; ++r) {
-        double s = 0.0;
-#pragma unroll
-        for (int c = 0; c < D; ++c)
-            s += g.linv[r * D + c] * xi[c];
-        bpts[r + (long)i * D] = s;
-    }
-}
-
-// out[0] = sum_k v[k]  (k < n), one block; out[1] = sum_k u[k] v[k] if u
-__global__ __launch_bounds__(256) void reduce_sum_kernel(const double *__restrict__ v,
-                                                         const double *__restrict__ u, int n,
-                                                         double *__restrict__ out)
-{
-    const int t = threadIdx.x;
-    double s = 0.0;
-    for (int k = t; k < n; k += 256)
-        s += u ? u[k] * v[k] : v[k];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        s += __shfl_down(s, off, 64);
-    __shared__ double part[4];
-    if ((t & 63) == 0)
-        part[t >> 6] = s;
-    __syncthreads();
-    if (t == 0)
-        out[0] = (part[0] + part[1]) + (part[2] + part[3]);
-}
-
-// ===========================================================================
-// Batched expected-squared-mean systems (bq.py:447-527, bq_c.pyx:425-535).
-// Batch element a is the Gram of the nsc points x_sc plus the candidate x_a[a]
-// (no noise term: gp.Kxoxo), with the reference's jitter on the diagonal --
-// jit1[a] on the candidates within `thresh` of x_a[a], jit2[a] on the new point
-// (bq_c.pyx:127-140) -- bordered by two rows: int K(x_sca) p(x) dx and [l_sc, 0].
-// After eliminating the npad columns, A_a and A_sc . l_sc are read off the panel
-// and the Schur complement (esm_finalize_kernel); no back substitution.
-// ===========================================================================
-struct EsmLayout {
-    int ns, nsc, npad, ntot; // points [0, nsc] (nsc+1 of them), border rows npad, npad+1
-};
-
-__global__ __launch_bounds__(256) void assemble_esm_kernel(const double *__restrict__ x_sc,
-                                                           const double *__restrict__ x_a,
-                                                           const double *__restrict__ intk_sc,
-                                                           const double *__restrict__ intk_a,
-                                                           const double *__restrict__ l_sc,
-                                                           const double *__restrict__ jit1,
-                                                           const double *__restrict__ jit2,
-                                                           double thresh, GaussParams g,
-                                                           double *__restrict__ A, long lda,
-                                                           long astride, EsmLayout L)
-{
-    const int b = blockIdx.z;
-    const int t = threadIdx.x;
-    const int ib = blockIdx.x * 128, jb = blockIdx.y * 64;
-    if (jb > ib + 127)
-        return;
-    A += (long)b * astride;
-    const double xa = x_a[b];
-    const int n1 = L.nsc + 1;
-    const int i = ib + (t & 63) * 2;
-    const int jbase = jb + (t >> 6) * 16;
-    if (i >= L.ntot)
-        return;
-    double xi[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int ii = i + r;
-        xi[r] = ii < L.nsc ? x_sc[ii] : xa;
-    }
-    for (int jj = 0; jj < 16; ++jj) {
-        const int j = jbase + jj;
-        if (j >= L.ntot)
-            break;
-        const double xj = j < L.nsc ? x_sc[j] : xa;
-        double v[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int ii = i + r;
-            double val;
-            if (ii < n1 && j < n1) {
-                const double tdiff = xi[r] - xj;
-                val = g.c * exp_gauss((tdiff * tdiff) * g.nh[0]);
-                if (ii == j) {
-                    if (ii == L.nsc)
-                        val += jit2[b];
-                    else if (ii >= L.ns && fabs(xi[r] - xa) < thresh)
-                        val += jit1[b];
-                }
-            } else if (ii == L.npad) {
-                val = j < L.nsc ? intk_sc[j] : (j == L.nsc ? intk_a[b] : 0.0);
-            } else if (ii == L.npad + 1) {
-                val = j < L.nsc ? l_sc[j] : 0.0;
-            } else {
-                val = (ii == j) ? 1.0 : 0.0;
-            }
-            v[r] = val;
-        }
-        double2_t vv = {v[0], v[1]};
-        *reinterpret_cast<double2_t *>(A + i + (long)j * lda) = vv;
-    }
-}
-
-// out[2b] = A_a = (K^-1 intK)[last], out[2b+1] = A_sc . l_sc
-__global__ void esm_finalize_kernel(const double *__restrict__ A, long lda, long astride,
-                                    EsmLayout L, int batch, double *__restrict__ out)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= batch)
-        return;
-    const double *Ab = A + (long)b * astride;
-    const double z_last = Ab[L.npad + (long)L.nsc * lda];
-    const double l_last = Ab[L.nsc + (long)L.nsc * lda];
-    // A = L^-T z: the last component is z_last / L_nn
-    out[2 * b] = z_last / l_last;
-    // (L^-1 [l_sc, 0]) . z  sits, negated, in the Schur complement at (npad+1, npad)
-    out[2 * b + 1] = -Ab[(L.npad + 1) + (long)L.npad * lda];
-}
+#include "common.h"
+#include "gram.h"    // gram_sym_kernel, gram_cross_kernel, assemble_kernel
+#include "potf2.h"   // potf2_64_kernel, potf2_64x4_kernel (+ body, fusable into gemm)
+#include "trsm.h"    // trsm_rows_kernel, trsm_quad_kernel, diag_recip_kernel
+#include "gemm.h"    // gemm_sub_kernel, gemm_k64_kernel
+#include "reduce.h"  // finalize_kernel, rowdot_kernel, predict_mean_kernel, logdet_kernel, ...
+#include "probe.h"   // probe_* kernels
+#include "moments.h" // int_K*, iikk, esm kernels

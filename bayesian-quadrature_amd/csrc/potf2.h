@@ -1,0 +1,290 @@
+// potf2.h -- 64x64 diagonal Cholesky blocks (one-wave and four-wave variants)
+// Part of the libbqhip.so kernel set; included through kernels.h.
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// refined reciprocal square root: v_rsq_f64 seed + two Newton steps, and the
+// square root s = d r with one correction.  Relative error ~1 ulp; the pivot
+// chain is the critical path of the whole factorisation, so it avoids the
+// long div/sqrt library sequences.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void rsqrt_sqrt_f64(double d, double &r, double &s)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    const double hd = 0.5 * d;
+    double t = __builtin_fma(-hd * y, y, 0.5);
+    y = __builtin_fma(y, t, y);
+    t = __builtin_fma(-hd * y, y, 0.5);
+    y = __builtin_fma(y, t, y);
+    double q = d * y;
+    const double e = __builtin_fma(-q, q, d);
+    q = __builtin_fma(0.5 * y, e, q);
+    r = y;
+    s = q;
+}
+
+// ---------------------------------------------------------------------------
+// 64x64 diagonal block: unblocked right-looking Cholesky by ONE wave.  Lane i
+// holds row i in 64 fp64 registers.  Per column: the pivot and the next
+// column's multiplier travel by v_readlane (short dependency chain), the other
+// multipliers l_k are broadcast through LDS (every lane reads the same
+// address), two per ds_read_b128.  Writes the lower triangle back and 1/L_jj
+// to dinv[64].  info[b] receives the 1-based global column of the first
+// non-positive pivot (first failure wins; 0 = ok).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void potf2_64_kernel(double *__restrict__ A, long lda,
+                                                      long astride, int j0,
+                                                      double *__restrict__ dinv, long dstride,
+                                                      int *__restrict__ info)
+{
+    __shared__ __attribute__((aligned(16))) double col[2][64];
+    // the panel is the critical path; under look-ahead it shares SIMDs with the
+    // trailing update's MFMA waves and should win instruction issue
+    __builtin_amdgcn_s_setprio(3);
+    const int b = blockIdx.z;
+    double *Ab = A + (long)b * astride + j0 + (long)j0 * lda;
+    const int lane = threadIdx.x;
+    double a[64];
+    {
+        const double *pr = Ab + lane;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            a[j] = *pr;
+            pr += lda;
+        }
+    }
+    int bad = 0;
+    double d = readlane_f64(a[0], 0);
+    double r, s;
+    double myr = 0.0; // lane j keeps 1 / L_jj
+    rsqrt_sqrt_f64(d, r, s);
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        if (!(d > 0.0) && bad == 0)
+            bad = j0 + j + 1;
+        const double l = (lane == j) ? s : a[j] * r;
+        a[j] = l;
+        myr = (lane == j) ? r : myr;
+        if (j < 63) {
+            double2_t lk[32];
+            if (j < 62) {
+                // broadcast reads of the column are issued first; the next
+                // pivot's readlane + rsqrt chain below runs under their latency
+                col[j & 1][lane] = l;
+                __syncthreads();
+                const double2_t *c2 = reinterpret_cast<const double2_t *>(col[j & 1]);
+#pragma unroll
+                for (int kk = (j + 2) >> 1; kk < 32; ++kk)
+                    lk[kk] = c2[kk];
+            }
+            a[j + 1] -= l * readlane_f64(l, j + 1);
+            d = readlane_f64(a[j + 1], j + 1);
+            rsqrt_sqrt_f64(d, r, s);
+            if (j < 62) {
+#pragma unroll
+                for (int kk = (j + 2) >> 1; kk < 32; ++kk) {
+                    if (2 * kk >= j + 2)
+                        a[2 * kk] -= l * lk[kk][0];
+                    a[2 * kk + 1] -= l * lk[kk][1];
+                }
+#pragma unroll
+                for (int k = j + 2; k < 64; ++k)
+                    PIN(a[k]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    dinv[(long)b * dstride + lane] = myr;
+    // fresh per-lane pointer: without the opaque copy the compiler keeps the 64
+    // load addresses alive across the whole factorisation and spills
+    double *pw = Ab + lane;
+    asm volatile("" : "+v"(pw));
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        if (lane >= j)
+            *pw = a[j];
+        pw += lda;
+    }
+    if (lane == 0 && bad != 0 && info[b] == 0)
+        info[b] = bad;
+}
+
+// ---------------------------------------------------------------------------
+// 64x64 diagonal block by FOUR waves (one per SIMD).  Every wave holds all 64
+// rows (lane = row) and a quarter of the columns: wave w owns the columns
+// 16q + 4w + s (q, s = 0..3), i.e. the matrix is cut into sixteen 4-column
+// panels dealt round-robin to the waves.  Panel p is factored by its owner
+// (pivot chain as in potf2_64_kernel, the in-panel updates by v_readlane) and
+// published to a ring of three LDS slots; after ONE workgroup barrier per
+// panel every wave applies the rank-4 update to its own later columns.  The
+// owner of panel p+1 updates only that panel before starting its pivot chain
+// and catches up on its remaining columns one barrier later (the slot of panel
+// p stays valid that long), so the chain of rsqrt's -- the critical path of
+// the whole factorisation -- waits for 16 FMAs per panel instead of 64.
+// ---------------------------------------------------------------------------
+struct Potf2W {
+    double a[4][4]; // a[q][s] = column 16q + 4w + s of row `lane`
+    double myr;     // 1 / L_cc for the lane that is the pivot row of an owned column
+    int bad;
+};
+
+// rank-4 update of this wave's columns in group Q by the panel in `slot`
+template <int Q>
+__device__ __forceinline__ void potf2w_update_group(Potf2W &st, const double *slot,
+                                                    const double (&li)[4], int w)
+{
+    double2_t lk[4][2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const double2_t *src = reinterpret_cast<const double2_t *>(slot + s * 64 + 16 * Q + 4 * w);
+        lk[s][0] = src[0];
+        lk[s][1] = src[1];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        st.a[Q][0] -= li[s] * lk[s][0][0];
+        st.a[Q][1] -= li[s] * lk[s][0][1];
+        st.a[Q][2] -= li[s] * lk[s][1][0];
+        st.a[Q][3] -= li[s] * lk[s][1][1];
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+        PIN(st.a[Q][cc]);
+}
+
+// factor panel P (columns 4P .. 4P+3, group QP = P>>2) held by this wave; publish
+template <int P>
+__device__ __forceinline__ void potf2w_factor(Potf2W &st, double *slot, int lane, int j0)
+{
+    constexpr int QP = P >> 2;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int c = 4 * P + s;
+        const double d = readlane_f64(st.a[QP][s], c);
+        if (!(d > 0.0) && st.bad == 0)
+            st.bad = j0 + c + 1;
+        double r, sq;
+        rsqrt_sqrt_f64(d, r, sq);
+        const double l = (lane == c) ? sq : st.a[QP][s] * r;
+        st.a[QP][s] = l;
+        st.myr = (lane == c) ? r : st.myr;
+#pragma unroll
+        for (int s2 = s + 1; s2 < 4; ++s2)
+            st.a[QP][s2] -= l * readlane_f64(l, 4 * P + s2);
+        slot[s * 64 + lane] = l;
+    }
+}
+
+template <int P>
+struct Potf2WSteps {
+    static __device__ __forceinline__ void run(Potf2W &st, double *ring, int w, int lane, int j0)
+    {
+        constexpr int QP = P >> 2, WP = P & 3;
+        constexpr int PN = P + 1, QN = PN >> 2, WN = PN & 3;
+        __syncthreads(); // panel P is published
+        const double *slot = ring + (P % 3) * 256;
+        if (P >= 1 && w == WP) {
+            // I factored panel P before touching my later groups with panel P-1
+            const double *prev = ring + ((P + 2) % 3) * 256;
+            double lp[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                lp[s] = prev[s * 64 + lane];
+            if (QP < 1) potf2w_update_group<1>(st, prev, lp, w);
+            if (QP < 2) potf2w_update_group<2>(st, prev, lp, w);
+            if (QP < 3) potf2w_update_group<3>(st, prev, lp, w);
+        }
+        double li[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            li[s] = slot[s * 64 + lane];
+        if (P < 15 && w == WN) {
+            // next owner: bring its panel up to date, then run the pivot chain
+            if (QN == 0) potf2w_update_group<0>(st, slot, li, w);
+            if (QN == 1) potf2w_update_group<1>(st, slot, li, w);
+            if (QN == 2) potf2w_update_group<2>(st, slot, li, w);
+            if (QN == 3) potf2w_update_group<3>(st, slot, li, w);
+            potf2w_factor<(P < 15 ? PN : 15)>(st, ring + (PN % 3) * 256, lane, j0);
+        } else {
+            // my columns of the panel's own group lie after it only if w > WP
+            if (w > WP) {
+                if (QP == 0) potf2w_update_group<0>(st, slot, li, w);
+                if (QP == 1) potf2w_update_group<1>(st, slot, li, w);
+                if (QP == 2) potf2w_update_group<2>(st, slot, li, w);
+                if (QP == 3) potf2w_update_group<3>(st, slot, li, w);
+            }
+            if (QP < 1) potf2w_update_group<1>(st, slot, li, w);
+            if (QP < 2) potf2w_update_group<2>(st, slot, li, w);
+            if (QP < 3) potf2w_update_group<3>(st, slot, li, w);
+        }
+        Potf2WSteps<P + 1>::run(st, ring, w, lane, j0);
+    }
+};
+template <>
+struct Potf2WSteps<16> {
+    static __device__ __forceinline__ void run(Potf2W &, double *, int, int, int) {}
+};
+
+// The factorisation proper, callable by any 256-thread workgroup: Ab points at
+// the 64x64 block (leading dimension lda), j0 is its global column (for the
+// failure report), dinv_b / info_b belong to this batch element.
+__device__ __forceinline__ void potf2_64x4_body(double *__restrict__ Ab, long lda, int j0,
+                                                double *__restrict__ dinv_b,
+                                                int *__restrict__ info_b, double *ring, int *sbad)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    Potf2W st;
+    st.myr = 0.0;
+    st.bad = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            st.a[q][s] = Ab[lane + (long)(16 * q + 4 * w + s) * lda];
+    if (w == 0)
+        potf2w_factor<0>(st, ring, lane, j0);
+    Potf2WSteps<0>::run(st, ring, w, lane, j0);
+    // write back the lower triangle of my columns, and my reciprocal pivots
+    {
+        double *pw = Ab + lane + (long)(4 * w) * lda;
+        asm volatile("" : "+v"(pw));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (lane >= 16 * q + 4 * w + s)
+                    pw[(long)s * lda] = st.a[q][s];
+            pw += 16 * lda;
+        }
+    }
+    if (((lane >> 2) & 3) == w)
+        dinv_b[lane] = st.myr;
+    if (lane == 0)
+        sbad[w] = st.bad;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int first = 0;
+        for (int k = 0; k < 4; ++k)
+            if (sbad[k] != 0 && (first == 0 || sbad[k] < first))
+                first = sbad[k];
+        if (first != 0 && info_b[0] == 0)
+            info_b[0] = first;
+    }
+}
+
+__global__ __launch_bounds__(256) void potf2_64x4_kernel(double *__restrict__ A, long lda,
+                                                         long astride, int j0,
+                                                         double *__restrict__ dinv, long dstride,
+                                                         int *__restrict__ info)
+{
+    __shared__ __attribute__((aligned(16))) double ring[3 * 4 * 64];
+    __shared__ int sbad[4];
+    __builtin_amdgcn_s_setprio(3);
+    const int b = blockIdx.z;
+    potf2_64x4_body(A + (long)b * astride + j0 + (long)j0 * lda, lda, j0, dinv + (long)b * dstride,
+                    info + b, ring, sbad);
+}

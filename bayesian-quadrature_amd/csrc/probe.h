@@ -1,0 +1,95 @@
+// probe.h -- hardware probes (MFMA / FMA rate, HBM bandwidth, MFMA layout, rsq accuracy)
+// Part of the libbqhip.so kernel set; included through kernels.h.
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// hardware probes
+// ---------------------------------------------------------------------------
+// relative error of the raw v_rsq_f64 seed, of one and of two Newton steps, against
+// the correctly rounded 1/sqrt; out[3*i + k]
+__global__ void probe_rsq_kernel(const double *x, double *out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const double d = x[i];
+    const double ref = 1.0 / sqrt(d);
+    double y = __builtin_amdgcn_rsq(d);
+    out[3 * i] = fabs(y - ref) / ref;
+    const double hd = 0.5 * d;
+    double t = __builtin_fma(-hd * y, y, 0.5);
+    y = __builtin_fma(y, t, y);
+    out[3 * i + 1] = fabs(y - ref) / ref;
+    t = __builtin_fma(-hd * y, y, 0.5);
+    y = __builtin_fma(y, t, y);
+    out[3 * i + 2] = fabs(y - ref) / ref;
+}
+
+__global__ void probe_empty_kernel(double *out)
+{
+    if (out == nullptr && threadIdx.x == 9999)
+        out[0] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void probe_mfma_kernel(double *out, int iters)
+{
+    double4_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    const double a = 1.0 + threadIdx.x * 1e-9, bb = 1.0 - threadIdx.x * 1e-9;
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c3, 0, 0, 0);
+    }
+    c0 += c1 + c2 + c3;
+    if (c0[0] == 123.456)
+        out[0] = c0[1];
+}
+
+__global__ __launch_bounds__(256) void probe_fma_kernel(double *out, int iters)
+{
+    double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5,
+           a6 = a0 + 6, a7 = a0 + 7;
+    const double m = 0.999999, c = 1e-9;
+    for (int i = 0; i < iters; ++i) {
+        a0 = a0 * m + c; a1 = a1 * m + c; a2 = a2 * m + c; a3 = a3 * m + c;
+        a4 = a4 * m + c; a5 = a5 * m + c; a6 = a6 * m + c; a7 = a7 * m + c;
+    }
+    const double s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    if (s == 123.456)
+        out[0] = s;
+}
+
+__global__ __launch_bounds__(256) void probe_write_kernel(double2_t *dst, size_t n2)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    const double2_t v = {1.0, 2.0};
+    for (; i < n2; i += stride)
+        dst[i] = v;
+}
+
+__global__ __launch_bounds__(256) void probe_copy_kernel(double2_t *dst, const double2_t *src,
+                                                         size_t n2)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n2; i += stride)
+        dst[i] = src[i];
+}
+
+// D = A B with A[i][k] = i (row tag), B[k][j] = [k==0] * 1 ... we want each D
+// element to carry row*16+col: use A[i][k] = (k==0) ? i*16 : (k==1 ? 1 : 0),
+// B[k][j] = (k==0) ? 1 : (k==1 ? j : 0)  ->  D[i][j] = 16 i + j.
+__global__ void probe_layout_kernel(double *out)
+{
+    const int l = threadIdx.x;
+    const int i = l & 15, k = l >> 4;
+    const double a = (k == 0) ? 16.0 * i : (k == 1 ? 1.0 : 0.0);
+    const double bb = (k == 0) ? 1.0 : (k == 1 ? (double)(l & 15) : 0.0);
+    double4_t c = {0, 0, 0, 0};
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c, 0, 0, 0);
+    for (int r = 0; r < 4; ++r)
+        out[l * 4 + r] = c[r];
+}

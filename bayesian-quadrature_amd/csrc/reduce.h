@@ -1,0 +1,156 @@
+// reduce.h -- read-out, reductions, fused prediction, small utility kernels
+// Part of the libbqhip.so kernel set; included through kernels.h.
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// Read-out after the bordered elimination (one block per problem):
+//   logdet = 2 sum_{i<n} log L_ii,  qf = -S[yrow,yrow] = y' Kxx^-1 y,
+//   logml  = -qf/2 - logdet/2 - n/2 log 2 pi,
+//   mean_i = -S[yrow, i],  var_i = S[i,i]   (S = Schur complement at npad)
+// scal[b*4 + {0,1,2}] = logml, logdet, qf.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict__ A, long lda,
+                                                       long astride, Layout L,
+                                                       double *__restrict__ scal,
+                                                       double *__restrict__ mean,
+                                                       double *__restrict__ var, long mstride)
+{
+    const int b = blockIdx.z;
+    A += (long)b * astride;
+    const int t = threadIdx.x;
+    double s = 0.0;
+    for (int i = t; i < L.n; i += 256)
+        s += log(A[i + (long)i * lda]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        s += __shfl_down(s, off, 64);
+    __shared__ double part[4];
+    if ((t & 63) == 0)
+        part[t >> 6] = s;
+    __syncthreads();
+    if (t == 0) {
+        const double logdet = 2.0 * (part[0] + part[1] + part[2] + part[3]);
+        double qf = 0.0, logml = 0.0;
+        if (L.yrow >= 0) {
+            qf = -A[L.yrow + (long)L.yrow * lda];
+            logml = -0.5 * qf - 0.5 * logdet - 0.5 * (double)L.n * 1.8378770664093453; // log 2pi
+        }
+        scal[b * 4 + 0] = logml;
+        scal[b * 4 + 1] = logdet;
+        scal[b * 4 + 2] = qf;
+    }
+    for (int i = t; i < L.M; i += 256) {
+        const long c = L.npad + i;
+        if (var)
+            var[(long)b * mstride + i] = A[c + c * lda];
+        if (mean && L.yrow >= 0)
+            mean[(long)b * mstride + i] = -A[L.yrow + c * lda];
+    }
+}
+
+// per-row reductions of a solved border V (m x n, ld = ldv), z (n):
+//   mean_i = sum_j V[i,j] z[j],   var_i = k0 - sum_j V[i,j]^2
+__global__ __launch_bounds__(256) void rowdot_kernel(const double *__restrict__ V, long ldv, int m,
+                                                     int n, const double *__restrict__ z,
+                                                     double k0, double *__restrict__ mean,
+                                                     double *__restrict__ var)
+{
+    // block = 64 rows x 4 column slices
+    const int t = threadIdx.x;
+    const int row = blockIdx.x * 64 + (t & 63);
+    const int sl = t >> 6;
+    double sm = 0.0, sv = 0.0;
+    if (row < m)
+        for (int j = sl; j < n; j += 4) {
+            const double v = V[row + (long)j * ldv];
+            sm += v * (z ? z[j] : 0.0);
+            sv += v * v;
+        }
+    __shared__ double pm[4][64], pv[4][64];
+    pm[sl][t & 63] = sm;
+    pv[sl][t & 63] = sv;
+    __syncthreads();
+    if (sl == 0 && row < m) {
+        const int r = t & 63;
+        if (mean)
+            mean[row] = (pm[0][r] + pm[1][r]) + (pm[2][r] + pm[3][r]);
+        if (var)
+            var[row] = k0 - ((pv[0][r] + pv[1][r]) + (pv[2][r] + pv[3][r]));
+    }
+}
+
+// mean_i = sum_j k(xo_i, x_j) alpha_j : fused cross-Gram x GEMV, one wave per
+// 64 outputs?  No: one block of 256 threads per output point slice would
+// starve; use one wave per output point, lanes stride over j.
+template <int D>
+__global__ __launch_bounds__(256) void predict_mean_kernel(const double *__restrict__ xo, int M,
+                                                           const double *__restrict__ x, int n,
+                                                           const double *__restrict__ alpha,
+                                                           GaussParams g, double *__restrict__ mean)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= M)
+        return;
+    double p[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+        p[k] = xo[k + (long)i * D];
+    double s = 0.0;
+    for (int j = lane; j < n; j += 64) {
+        double q[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            q[k] = x[k + (long)j * D];
+        s += exp_gauss(gauss_q<D>(p, q, g)) * alpha[j];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        s += __shfl_down(s, off, 64);
+    if (lane == 0)
+        mean[i] = g.c * s;
+}
+
+// dst(rows x cols, ld ldd) <- src(rows x cols, ld lds); optional transpose
+__global__ void copy2d_kernel(double *__restrict__ dst, long ldd, const double *__restrict__ src,
+                              long lds, int rows, int cols, int transpose_src)
+{
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
+    if (i >= rows)
+        return;
+    for (int j = j0; j < j0 + 4 && j < cols; ++j)
+        dst[i + (long)j * ldd] = transpose_src ? src[j + (long)i * lds] : src[i + (long)j * lds];
+}
+
+// A <- identity on the padding square [n, ntot) and zero in the padding
+// rows/cols of the lower triangle (used by the linalg drop-ins)
+__global__ void pad_identity_kernel(double *__restrict__ A, long lda, int n, int ntot)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= ntot || j >= ntot)
+        return;
+    if (i >= n || j >= n)
+        A[i + (long)j * lda] = (i == j) ? 1.0 : 0.0;
+}
+
+// 2 sum log diag, one block
+__global__ __launch_bounds__(256) void logdet_kernel(const double *__restrict__ A, long lda, int n,
+                                                     double *__restrict__ out)
+{
+    const int t = threadIdx.x;
+    double s = 0.0;
+    for (int i = t; i < n; i += 256)
+        s += log(A[i + (long)i * lda]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        s += __shfl_down(s, off, 64);
+    __shared__ double part[4];
+    if ((t & 63) == 0)
+        part[t >> 6] = s;
+    __syncthreads();
+    if (t == 0)
+        out[0] = 2.0 * (part[0] + part[1] + part[2] + part[3]);
+}

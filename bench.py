@@ -324,6 +324,15 @@ def extras(eng, nb_override):
         eng.free(xd)
         eng.free(Kd)
     out.update(batched_configs(eng))
+    # the same C2 problem through the host-buffer entry point (allocation, PCIe both
+    # ways, synchronisation inside every call): never the headline `value`
+    c2 = wl.c2()
+    eng.fit_predict(c2["x"], c2["y"], c2["h"], c2["w"], c2["s"], c2["xo"])
+    t0 = time.perf_counter()
+    for _ in range(10):
+        eng.fit_predict(c2["x"], c2["y"], c2["h"], c2["w"], c2["s"], c2["xo"])
+    out["c2_host_buffer_call"] = {"ms_per_call": (time.perf_counter() - t0) / 10 * 1e3,
+                                  "note": "bq_fit_predict: plan creation + H2D + run + D2H per call"}
     return out
 
 

@@ -481,3 +481,25 @@ def test_bq_expected_moments_gpu_vs_double(engine, oracle):
     assert np.allclose(d[3], g[3], rtol=1e-8, atol=1e-9 * d[0] ** 2)
     assert np.allclose(d[4], g[4], rtol=1e-9, atol=1e-13)
     assert np.allclose(d[5], g[5], rtol=1e-6, atol=1e-13)
+
+
+def test_large_fit_properties(engine):
+    """N = 8192 (wide outer block, look-ahead) through the GP object path: the factor,
+    z, alpha and the log-ML must satisfy their defining identities."""
+    n = 8192
+    c = wl.c4(n)
+    rs = np.random.RandomState(4)
+    y = wl.norm_logpdf(c["x"]) + 0.01 * rs.randn(n)
+    fit = engine.gp_fit(c["x"], y, c["h"], c["w"], c["s"])
+    L, z, alpha = fit.L(), fit.z(), fit.alpha()
+    K = fit.K()
+    assert _resid(K, L, rs, nvec=2) < 1e-14 * n
+    assert np.linalg.norm(L.dot(z) - y) / np.linalg.norm(y) < 1e-12
+    assert np.linalg.norm(K.dot(alpha) - y) / np.linalg.norm(y) < 1e-10
+    ref = -0.5 * z.dot(z) - np.log(np.diag(L)).sum() - 0.5 * n * np.log(2 * np.pi)
+    assert abs(fit.logml - ref) <= 1e-12 * abs(ref)
+    # posterior at the samples reproduces y up to the noise level; variance is tiny there
+    m, v, _ = fit.predict(c["x"][::64])
+    assert np.max(np.abs(m - y[::64])) < 1e-3
+    assert (v > -1e-9).all() and v.max() < 1e-3 * fit.K()[0, 0]
+    fit.close()
