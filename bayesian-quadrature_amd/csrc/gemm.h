@@ -120,12 +120,134 @@ __device__ __forceinline__ void gemm_sub_tile(double *__restrict__ C, long ldc,
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same wave tile on v_mfma_f64_4x4x4_4b_f64.  On gfx950 the 16x16x4 form sustains
+// only ~48 TFLOP/s (62 % of the 78.6 peak: its MFMA_BUSY is 64 cycles but it cannot be
+// issued back to back), the four-block 4x4x4 form ~70 (tools/probe_mfma.py).  Operand
+// map, probed on the box (tools/probe_mfma444.py): A lane = i + 4 blk + 16 k,
+// B lane = j + 4 blk + 16 k, D lane = j + 4 blk + 16 i  (D_blk = A_blk B_blk, 4x4x4 each).
+//
+// Both operands are the ordinary 16 x 4 fragments (64 distinct values, one load each):
+// block blk of the B operand holds rows 4 blk .. 4 blk + 3 of the P fragment, block blk
+// of the A operand columns 4 blk .. 4 blk + 3 of the Q fragment.  Rotating the Q
+// fragment by s quads (DPP row_ror:4s) makes block blk meet column quad (blk - s) mod 4,
+// so four MFMAs (s = 0..3) cover a 16 x 16 tile of C:
+//   acc[tm][tn][s], lane l -> C[r + l%16, c + 4 (((l/4)%4 - s) mod 4) + l/16]
+// i.e. an accumulator register still covers whole 128-byte lines of C.  Per k-step of
+// 4 a (16 TM) x (16 TN) wave tile takes TM + TN fragment loads, 3 TN rotations and
+// 4 TM TN MFMAs.  (Feeding the four-block form with replicated 4-column fragments
+// instead needs 2.5x the load instructions and is bound by the L1: 36 TFLOP/s; one
+// rotation of each operand instead of three of Q measures the same, with 32-byte
+// store runs.)  Q must be unit-stride in its row index (qsj == 1) and m, n multiples
+// of the wave tile (true for every padded system here).
+// ---------------------------------------------------------------------------
+template <int S>
+__device__ __forceinline__ double row_ror_quads(double v)
+{
+    if (S == 0)
+        return v;
+    constexpr int ctrl = 0x120 + 4 * S; // row_ror:4S: lane l reads lane (l - 4S) mod 16 of its row
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    // every lane is written (full row and bank masks), so no "old" value is needed:
+    // mov_dpp avoids the zero-initialising v_mov that update_dpp(0, ...) costs
+    lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void gemm444_tile(double *__restrict__ C, long ldc,
+                                             const double *__restrict__ P, long ldp,
+                                             const double *__restrict__ Q, long ldq, int k,
+                                             int lower, int row0, int col0, int lane)
+{
+    const int l15 = lane & 15, l4 = lane >> 4, blk = (lane >> 2) & 3;
+    const double *pp = P + row0 + l15 + (long)l4 * ldp;
+    const double *qq = Q + col0 + l15 + (long)l4 * ldq;
+
+    double acc[TM][TN][4];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc[tm][tn][s] = 0.0;
+
+    double pa[TM], qa[TN], pb[TM], qb[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+        pa[tm] = pp[16 * tm];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+        qa[tn] = qq[16 * tn];
+    const long pstep = 4 * ldp, qstep = 4 * ldq;
+    const int ksteps = k >> 2; // even
+
+#define BQ_444_STEP(PF, QF)                                                                        \
+    _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)                                              \
+    {                                                                                              \
+        const double q0 = QF[tn];                                                                  \
+        const double q1 = row_ror_quads<1>(q0), q2 = row_ror_quads<2>(q0),                         \
+                     q3 = row_ror_quads<3>(q0);                                                    \
+        _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                          \
+        {                                                                                          \
+            acc[tm][tn][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(q0, PF[tm], acc[tm][tn][0], 0, 0, 0); \
+            acc[tm][tn][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(q1, PF[tm], acc[tm][tn][1], 0, 0, 0); \
+            acc[tm][tn][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(q2, PF[tm], acc[tm][tn][2], 0, 0, 0); \
+            acc[tm][tn][3] = __builtin_amdgcn_mfma_f64_4x4x4f64(q3, PF[tm], acc[tm][tn][3], 0, 0, 0); \
+        }                                                                                          \
+    }
+
+    for (int ks = 0; ks < ksteps; ks += 2) {
+        const double *p1 = pp + (long)(ks + 1) * pstep, *q1p = qq + (long)(ks + 1) * qstep;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+            pb[tm] = p1[16 * tm];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+            qb[tn] = q1p[16 * tn];
+        __builtin_amdgcn_sched_barrier(0);
+        BQ_444_STEP(pa, qa)
+        __builtin_amdgcn_sched_barrier(0);
+        const long o2 = (ks + 2 < ksteps) ? (long)(ks + 2) : (long)ks; // clamped, value unused
+        const double *p2 = pp + o2 * pstep, *q2p = qq + o2 * qstep;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+            pa[tm] = p2[16 * tm];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+            qa[tn] = q2p[16 * tn];
+        __builtin_amdgcn_sched_barrier(0);
+        BQ_444_STEP(pb, qb)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef BQ_444_STEP
+
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int r = row0 + tm * 16;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int c = col0 + tn * 16;
+            if (lower && c >= r + 16)
+                continue;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int cq = (blk - s) & 3;
+                double *dst = C + (r + l15) + (long)(c + 4 * cq + l4) * ldc;
+                *dst -= acc[tm][tn][s];
+            }
+        }
+    }
+}
+
 // Fused diagonal factor: when fuse_j0 >= 0 the launch also factors the leading 64x64
 // block of C (the next diagonal block of the Cholesky) right after updating it.
 // Workgroup 0 owns every workgroup tile that intersects that block, updates them,
 // and runs potf2_64x4_body on the result; the other workgroups of the block exit.
 // This removes one dependent launch (and the block's trip through L2) per 64 columns.
-template <int TM, int TN>
+template <int TM, int TN, int MF> // MF = 0: v_mfma_f64_16x16x4_f64, 1: v_mfma_f64_4x4x4_4b_f64
 __global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C, long ldc,
                                                           long cstride, const double *__restrict__ P,
                                                           long ldp, long pstride,
@@ -154,9 +276,13 @@ __global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C
             for (int sy = 0; sy <= sx; ++sy) {
                 const int row0 = (sx * 2 + (wave & 1)) * (TM * 16);
                 const int col0 = (sy * 2 + (wave >> 1)) * (TN * 16);
-                if (row0 < m && col0 < n && !(lower && col0 >= row0 + TM * 16))
-                    gemm_sub_tile<TM, TN>(C, ldc, P, ldp, Q, qsj, qsk, m, n, k, lower, row0, col0,
-                                          lane);
+                if (row0 < m && col0 < n && !(lower && col0 >= row0 + TM * 16)) {
+                    if (MF == 1)
+                        gemm444_tile<TM, TN>(C, ldc, P, ldp, Q, qsk, k, lower, row0, col0, lane);
+                    else
+                        gemm_sub_tile<TM, TN>(C, ldc, P, ldp, Q, qsj, qsk, m, n, k, lower, row0,
+                                              col0, lane);
+                }
             }
         __syncthreads(); // the updated block is visible to the whole workgroup
         potf2_64x4_body(C, ldc, fuse_j0, dinv + (long)b * dstride, info + b, ring, sbad);
@@ -168,7 +294,10 @@ __global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C
         return;
     if (lower && col0 >= row0 + TM * 16)
         return;
-    gemm_sub_tile<TM, TN>(C, ldc, P, ldp, Q, qsj, qsk, m, n, k, lower, row0, col0, lane);
+    if (MF == 1)
+        gemm444_tile<TM, TN>(C, ldc, P, ldp, Q, qsk, k, lower, row0, col0, lane);
+    else
+        gemm_sub_tile<TM, TN>(C, ldc, P, ldp, Q, qsj, qsk, m, n, k, lower, row0, col0, lane);
 }
 
 // ---------------------------------------------------------------------------

@@ -26,6 +26,61 @@ __global__ void probe_rsq_kernel(const double *x, double *out, int n)
     out[3 * i + 2] = fabs(y - ref) / ref;
 }
 
+// MFMA issue study: NACC independent accumulators per wave, 16x16x4 (KIND 0) or the
+// four-block 4x4x4 form (KIND 1); waves per SIMD are set by the grid.
+template <int KIND, int NACC>
+__global__ __launch_bounds__(256) void probe_mfma_var_kernel(double *out, int iters)
+{
+    const double a = 1.0 + threadIdx.x * 1e-9, bb = 1.0 - threadIdx.x * 1e-9;
+    if (KIND == 0) {
+        double4_t c[NACC];
+#pragma unroll
+        for (int k = 0; k < NACC; ++k)
+            c[k] = (double4_t){0, 0, 0, 0};
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int k = 0; k < NACC; ++k)
+                c[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c[k], 0, 0, 0);
+        }
+        double4_t s = c[0];
+#pragma unroll
+        for (int k = 1; k < NACC; ++k)
+            s += c[k];
+        if (s[0] == 123.456)
+            out[0] = s[1];
+    } else {
+        double c[NACC];
+#pragma unroll
+        for (int k = 0; k < NACC; ++k)
+            c[k] = 0.0;
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int k = 0; k < NACC; ++k)
+                c[k] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bb, c[k], 0, 0, 0);
+        }
+        double s = c[0];
+#pragma unroll
+        for (int k = 1; k < NACC; ++k)
+            s += c[k];
+        if (s == 123.456)
+            out[0] = s;
+    }
+}
+
+// Operand map of v_mfma_f64_4x4x4_4b_f64: block (la, lb) of the grid sets A = 1 in lane la
+// only and B = 1 in lane lb only; out[la*64 + lb] = the lane whose D becomes 1 (or -1).
+__global__ void probe_layout444_kernel(int *out)
+{
+    const int la = blockIdx.x, lb = blockIdx.y, l = threadIdx.x;
+    const double a = (l == la) ? 1.0 : 0.0, bb = (l == lb) ? 1.0 : 0.0;
+    const double d = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bb, 0.0, 0, 0, 0);
+    if (l == 0)
+        out[la * 64 + lb] = -1;
+    __syncthreads();
+    if (d != 0.0)
+        out[la * 64 + lb] = l;
+}
+
 __global__ void probe_empty_kernel(double *out)
 {
     if (out == nullptr && threadIdx.x == 9999)
