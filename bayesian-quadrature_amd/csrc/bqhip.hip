@@ -78,6 +78,7 @@ struct bq_ctx {
     hipEvent_t ev_panel = nullptr, ev_next = nullptr, ev_fork = nullptr;
     int lookahead = 1;
     int potf2_waves = 4; // 4: potf2_64x4_kernel, 1: potf2_64_kernel (BQ_POTF2_WAVES)
+    int gemm_lds = 1;    // LDS-staged 128x128 trailing update (BQ_GEMM_LDS)
     int mfma444 = 1;     // trailing / panel updates on v_mfma_f64_4x4x4_4b_f64 (BQ_MFMA444)
     int fuse = 1;        // diagonal factor fused into the launch that last updates it (BQ_FUSE)
     int gram_nt = 0;     // non-temporal stores in the Gram kernel (BQ_GRAM_NT)
@@ -336,7 +337,11 @@ int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const dou
                                mode, fuse_j0, dinv, dstride, info);                                \
     } while (0)
     if (tiles(128) >= cu) {
-        BQ_GEMM_SUB(4, 4, 128);
+        if (c->gemm_lds && f444 && fuse_j0 < 0 && (k % 8) == 0)
+            hipLaunchKernelGGL(gemm_lds_kernel, grid_for(128), dim3(256), 0, c->cur, C, ldc,
+                               cstride, P, ldp, pstride, Q, qsk, qstride, m, n, k, mode);
+        else
+            BQ_GEMM_SUB(4, 4, 128);
     } else if (tiles(64) >= cu / 2) {
         if (k == 64)
             hipLaunchKernelGGL((gemm_k64_kernel<2, 2>), grid_for(64), dim3(256), 0, c->cur, C, ldc,
@@ -609,6 +614,8 @@ static int ctx_init(bq_ctx *c, int device)
     HIPCHK(c, hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, hi));
     if (const char *e = std::getenv("BQ_LOOKAHEAD"))
         c->lookahead = std::atoi(e);
+    if (const char *e = std::getenv("BQ_GEMM_LDS"))
+        c->gemm_lds = std::atoi(e);
     if (const char *e = std::getenv("BQ_MFMA444"))
         c->mfma444 = std::atoi(e);
     if (const char *e = std::getenv("BQ_FUSE"))
@@ -1798,6 +1805,22 @@ extern "C" int bq_probe_mfma_variant(bq_ctx *c, int kind, int nacc, int blocks_p
     HIPCHK(c, hipSetDevice(c->device));
     DevBuf o;
     HIPCHK(c, o.alloc(64));
+    if (kind >= 2) { // the GEMM inner step, kind 2: no rotations, 3: with rotations
+        const int it = 512, blocks = c->cus * blocks_per_cu;
+        float ms = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            BQCHK(bq_timer_start(c));
+            if (kind == 2)
+                hipLaunchKernelGGL(probe_mfma_step_kernel<0>, dim3(blocks), dim3(256), 0,
+                                   c->stream, o.d(), it);
+            else
+                hipLaunchKernelGGL(probe_mfma_step_kernel<1>, dim3(blocks), dim3(256), 0,
+                                   c->stream, o.d(), it);
+            BQCHK(bq_timer_stop_ms(c, &ms));
+        }
+        *tflops = (double)blocks * 4 * (double)it * 64 * 512.0 / (ms * 1e-3) / 1e12;
+        return BQ_OK;
+    }
     const int iters = 8192 / nacc, blocks = c->cus * blocks_per_cu;
     auto launch = [&](int it) {
 #define PV(K_, N_)                                                                                 \
@@ -1832,16 +1855,25 @@ extern "C" int bq_probe_mfma_variant(bq_ctx *c, int kind, int nacc, int blocks_p
     return BQ_OK;
 }
 
-extern "C" int bq_probe_mfma444_layout(bq_ctx *c, int32_t *out4096)
+extern "C" int bq_probe_mfma444_layout(bq_ctx *c, int cbsz, int abid, int32_t *out8192)
 {
-    if (!c || !out4096)
+    if (!c || !out8192)
         return BQ_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     DevBuf o;
-    HIPCHK(c, o.alloc(4096 * sizeof(int)));
-    hipLaunchKernelGGL(probe_layout444_kernel, dim3(64, 64), dim3(64), 0, c->stream, o.i());
+    HIPCHK(c, o.alloc(8192 * sizeof(int)));
+#define PL(C_, A_)                                                                                 \
+    hipLaunchKernelGGL((probe_layout444_kernel<C_, A_>), dim3(64, 64), dim3(64), 0, c->stream, o.i())
+    if (cbsz == 0) PL(0, 0);
+    else if (cbsz == 1 && abid == 0) PL(1, 0);
+    else if (cbsz == 1) PL(1, 1);
+    else if (abid == 0) PL(2, 0);
+    else if (abid == 1) PL(2, 1);
+    else if (abid == 2) PL(2, 2);
+    else PL(2, 3);
+#undef PL
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(out4096, o.p, 4096 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out8192, o.p, 8192 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return BQ_OK;
 }

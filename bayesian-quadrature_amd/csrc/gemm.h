@@ -428,3 +428,154 @@ __global__ __launch_bounds__(256) void gemm_k64_kernel(double *__restrict__ C, l
         return;
     gemm_k64_tile<TM, TN>(C, ldc, P, ldp, Q, qsj, qsk, m, n, lower, row0, col0, lane);
 }
+
+// ---------------------------------------------------------------------------
+// Trailing update, LDS-staged: C(m x n) -= P Q^T, workgroup tile 128 x 128, wave tile
+// 64 x 64, v_mfma_f64_4x4x4_4b_f64.  The register-streaming kernel above reads every
+// fragment from global memory in two waves and spends VALU issue slots on the quad
+// rotations; at the four-block MFMA's rate that is what it is bound by (measured 52 of
+// the ~65 TFLOP/s the same loop reaches without memory).  Here a workgroup stages
+// 8 k-columns of its P and Q row blocks in LDS once (16-byte global loads issued a
+// chunk ahead, ds_write_b128 after the barrier -- the async-stage split), and every
+// wave reads its fragments from LDS: 4 P fragments and, instead of rotating, the 16
+// pre-rotated views of its 4 Q fragments -- a rotated view is just another address
+// pattern of the same 16 doubles, conflict-free like the plain one (k rows are
+// padded to 1152 bytes so that the two k rows of a half-wave use disjoint banks).
+// The inner loop has no VALU work at all.
+// Requires qsj == 1, m and n multiples of 64, k a multiple of 8.
+// ---------------------------------------------------------------------------
+#define BQ_LDS_KC 8                  // k columns per chunk
+#define BQ_LDS_ROW (128 * 8 + 128)   // bytes per staged k row (128 doubles + pad)
+
+__global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C, long ldc,
+                                                          long cstride, const double *__restrict__ P,
+                                                          long ldp, long pstride,
+                                                          const double *__restrict__ Q, long ldq,
+                                                          long qstride, int m, int n, int k,
+                                                          int lower)
+{
+    // [buffer][P / Q][k row][128 doubles + pad]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * BQ_LDS_KC * BQ_LDS_ROW];
+    const int b = blockIdx.z;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (lower == 2)
+        tri_decode(blockIdx.x, bx, by);
+    C += (long)b * cstride;
+    P += (long)b * pstride;
+    Q += (long)b * qstride;
+    const int R0 = bx * 128, C0 = by * 128;
+    const int wr = (wave & 1) * 64, wc = (wave >> 1) * 64; // this wave's 64 x 64 sub-tile
+    const int row0 = R0 + wr, col0 = C0 + wc;
+    const bool active = row0 < m && col0 < n && !(lower && col0 >= row0 + 64);
+
+    // staging map: 2 x (8 k columns x 64 pairs of rows) per operand over 256 threads
+    const int pair = t & 63, kq = t >> 6; // k columns kq and kq + 4
+    const int prow = min(R0 + 2 * pair, m - 2), qrow = min(C0 + 2 * pair, n - 2);
+    const double *gp = P + prow + (long)kq * ldp;
+    const double *gq = Q + qrow + (long)kq * ldq;
+    unsigned char *sP = smem, *sQ = smem + BQ_LDS_KC * BQ_LDS_ROW;
+    constexpr int BUF = 2 * BQ_LDS_KC * BQ_LDS_ROW;
+    const int soff = kq * BQ_LDS_ROW + pair * 16;
+
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // fragment read offsets inside a chunk: k row l4 (+4 for the second k-step)
+    const int pfrag = l4 * BQ_LDS_ROW + (wr + l15) * 8;
+    int qfrag[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) // view rotated by s quads: lane reads column (l15 - 4 s) mod 16
+        qfrag[s] = l4 * BQ_LDS_ROW + (wc + ((l15 - 4 * s) & 15)) * 8;
+
+    double acc[4][4][4];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc[tm][tn][s] = 0.0;
+
+    double2_t stP[2], stQ[2];
+    const int nchunk = k / BQ_LDS_KC;
+    // prologue: chunk 0 -> LDS buffer 0
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        stP[j] = *reinterpret_cast<const double2_t *>(gp + (long)(4 * j) * ldp);
+        stQ[j] = *reinterpret_cast<const double2_t *>(gq + (long)(4 * j) * ldq);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        *reinterpret_cast<double2_t *>(sP + soff + 4 * j * BQ_LDS_ROW) = stP[j];
+        *reinterpret_cast<double2_t *>(sQ + soff + 4 * j * BQ_LDS_ROW) = stQ[j];
+    }
+    __syncthreads();
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int cur = (ch & 1) * BUF;
+        // (1) global loads of the next chunk, in flight during this chunk's MFMAs
+        const bool more = ch + 1 < nchunk;
+        if (more) {
+            const long ko = (long)(ch + 1) * BQ_LDS_KC;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                stP[j] = *reinterpret_cast<const double2_t *>(gp + (ko + 4 * j) * ldp);
+                stQ[j] = *reinterpret_cast<const double2_t *>(gq + (ko + 4 * j) * ldq);
+            }
+        }
+        // (2) the chunk's two k-steps from LDS
+        if (active) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const unsigned char *bp = sP + cur + st * 4 * BQ_LDS_ROW;
+                const unsigned char *bq = sQ + cur + st * 4 * BQ_LDS_ROW;
+                double pf[4], qf[4][4];
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    pf[tm] = *reinterpret_cast<const double *>(bp + pfrag + tm * 128);
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        qf[tn][s] = *reinterpret_cast<const double *>(bq + qfrag[s] + tn * 128);
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            acc[tm][tn][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(
+                                qf[tn][s], pf[tm], acc[tm][tn][s], 0, 0, 0);
+            }
+        }
+        // (3) next chunk into the other buffer; (4) one barrier per chunk
+        if (more) {
+            const int nxt = ((ch + 1) & 1) * BUF;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                *reinterpret_cast<double2_t *>(sP + nxt + soff + 4 * j * BQ_LDS_ROW) = stP[j];
+                *reinterpret_cast<double2_t *>(sQ + nxt + soff + 4 * j * BQ_LDS_ROW) = stQ[j];
+            }
+        }
+        __syncthreads();
+    }
+
+    if (!active)
+        return;
+    const int blk = (lane >> 2) & 3;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+        const int r = row0 + tm * 16;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int c = col0 + tn * 16;
+            if (lower && c >= r + 16)
+                continue;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int cq = (blk - s) & 3;
+                double *dst = C + (r + l15) + (long)(c + 4 * cq + l4) * ldc;
+                *dst -= acc[tm][tn][s];
+            }
+        }
+    }
+}

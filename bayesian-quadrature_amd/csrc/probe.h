@@ -2,6 +2,7 @@
 // Part of the libbqhip.so kernel set; included through kernels.h.
 #pragma once
 #include "common.h"
+#include "gemm.h" // row_ror_quads
 
 // ---------------------------------------------------------------------------
 // hardware probes
@@ -67,18 +68,68 @@ __global__ __launch_bounds__(256) void probe_mfma_var_kernel(double *out, int it
     }
 }
 
+// The GEMM inner step without memory: 4 P-fragments x 4 Q-fragments, 64 four-block MFMAs
+// per step, with (ROT = 1) or without (ROT = 0) the three DPP quad rotations per Q fragment.
+template <int ROT>
+__global__ __launch_bounds__(256, 2) void probe_mfma_step_kernel(double *out, int iters)
+{
+    double acc[4][4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc[a][b][s] = 0.0;
+    double pf[4], qf[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        pf[a] = 1.0 + threadIdx.x * 1e-9 + a;
+        qf[a] = 1.0 - threadIdx.x * 1e-9 - a;
+    }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            qf[tn] += 1e-12; // keeps the rotations inside the loop
+            const double q0 = qf[tn];
+            const double q1 = ROT ? row_ror_quads<1>(q0) : q0;
+            const double q2 = ROT ? row_ror_quads<2>(q0) : q0;
+            const double q3 = ROT ? row_ror_quads<3>(q0) : q0;
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+                acc[tm][tn][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(q0, pf[tm], acc[tm][tn][0], 0, 0, 0);
+                acc[tm][tn][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(q1, pf[tm], acc[tm][tn][1], 0, 0, 0);
+                acc[tm][tn][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(q2, pf[tm], acc[tm][tn][2], 0, 0, 0);
+                acc[tm][tn][3] = __builtin_amdgcn_mfma_f64_4x4x4f64(q3, pf[tm], acc[tm][tn][3], 0, 0, 0);
+            }
+        }
+    }
+    double sum = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                sum += acc[a][b][s];
+    if (sum == 123.456)
+        out[0] = sum;
+}
+
 // Operand map of v_mfma_f64_4x4x4_4b_f64: block (la, lb) of the grid sets A = 1 in lane la
 // only and B = 1 in lane lb only; out[la*64 + lb] = the lane whose D becomes 1 (or -1).
+template <int CBSZ, int ABID>
 __global__ void probe_layout444_kernel(int *out)
 {
     const int la = blockIdx.x, lb = blockIdx.y, l = threadIdx.x;
     const double a = (l == la) ? 1.0 : 0.0, bb = (l == lb) ? 1.0 : 0.0;
-    const double d = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bb, 0.0, 0, 0, 0);
-    if (l == 0)
-        out[la * 64 + lb] = -1;
-    __syncthreads();
-    if (d != 0.0)
-        out[la * 64 + lb] = l;
+    const double d = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bb, 0.0, CBSZ, ABID, 0);
+    // several D lanes may light up when the A block is broadcast: record a bit mask
+    const unsigned long long m = __ballot(d != 0.0);
+    if (l == 0) {
+        out[2 * (la * 64 + lb)] = (int)(m & 0xffffffffu);
+        out[2 * (la * 64 + lb) + 1] = (int)(m >> 32);
+    }
 }
 
 __global__ void probe_empty_kernel(double *out)

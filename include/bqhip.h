@@ -234,9 +234,10 @@ int bq_probe_hbm(bq_ctx *ctx, size_t bytes, double *write_gbs, double *copy_gbs)
 /* MFMA issue study: kind 0 = v_mfma_f64_16x16x4_f64, 1 = v_mfma_f64_4x4x4_4b_f64; nacc
  * independent accumulators per wave (1,2,4,8); blocks_per_cu = waves per SIMD */
 int bq_probe_mfma_variant(bq_ctx *ctx, int kind, int nacc, int blocks_per_cu, double *tflops);
-/* operand map of v_mfma_f64_4x4x4_4b_f64: out[la*64 + lb] = lane of the D element fed by
- * A lane la and B lane lb, or -1 */
-int bq_probe_mfma444_layout(bq_ctx *ctx, int32_t *out4096);
+/* operand map of v_mfma_f64_4x4x4_4b_f64 under the CBSZ / ABID broadcast controls:
+ * out[2*(la*64 + lb) + {0,1}] = low / high half of the 64-bit mask of D lanes fed by A lane la
+ * and B lane lb */
+int bq_probe_mfma444_layout(bq_ctx *ctx, int cbsz, int abid, int32_t *out8192);
 /* relative error of v_rsq_f64 raw / after one / after two Newton steps at x[0..n):
  * err3[3*i + {0,1,2}] */
 int bq_probe_rsq(bq_ctx *ctx, const double *x, int64_t n, double *err3);

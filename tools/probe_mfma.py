@@ -12,3 +12,10 @@ for kind, name in ((0, "16x16x4"), (1, "4x4x4_4b")):
             e._check(e._lib.bq_probe_mfma_variant(e._ctx, kind, nacc, bpc, C.cast(C.byref(v), L._dp)))
             row.append(round(v.value, 1))
         print(name, "nacc", nacc, "waves/SIMD 1,2,4,8:", row)
+for kind, name in ((2, "gemm step, no rotation"), (3, "gemm step, 3 DPP rotations per Q fragment")):
+    row = []
+    for bpc in (1, 2):
+        v = C.c_double()
+        e._check(e._lib.bq_probe_mfma_variant(e._ctx, kind, 4, bpc, C.cast(C.byref(v), L._dp)))
+        row.append(round(v.value, 1))
+    print(name, "waves/SIMD 1,2:", row)

@@ -1,14 +1,26 @@
-"""Derives the lane maps of v_mfma_f64_4x4x4_4b_f64 from the hardware."""
+"""Derives the lane maps of v_mfma_f64_4x4x4_4b_f64 from the hardware, with and without
+the CBSZ / ABID A-operand broadcast."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bayesian_quadrature_amd import Engine, _lib as L
 e = Engine(0)
-out = np.empty(4096, dtype=np.int32)
-e._check(e._lib.bq_probe_mfma444_layout(e._ctx, out.ctypes.data_as(L._i32p)))
-T = out.reshape(64, 64)   # T[la, lb] = D lane or -1
-print("pairs that contribute:", int((T >= 0).sum()), "(expect 4 blocks x 4 k x 4 i x 4 j = 256)")
-# group A lanes by which B lanes they pair with (same block and same k)
-for la in range(64):
-    lbs = np.nonzero(T[la] >= 0)[0]
-    print("A lane %2d pairs with B lanes %s -> D lanes %s" % (la, lbs.tolist(), T[la, lbs].tolist()))
+
+
+def table(cbsz, abid):
+    out = np.empty(8192, dtype=np.int32)
+    e._check(e._lib.bq_probe_mfma444_layout(e._ctx, cbsz, abid, out.ctypes.data_as(L._i32p)))
+    o = out.astype(np.int64).reshape(64, 64, 2)
+    return (o[..., 0] & 0xffffffff) | ((o[..., 1] & 0xffffffff) << 32)
+
+
+for cbsz, abid in ((0, 0), (2, 0), (2, 1), (2, 3), (1, 0), (1, 1)):
+    T = table(cbsz, abid)
+    pairs = [(la, lb, [l for l in range(64) if (int(T[la, lb]) >> l) & 1]) for la in range(64)
+             for lb in range(64) if T[la, lb]]
+    print("cbsz", cbsz, "abid", abid, ": contributing (A lane, B lane) pairs:", len(pairs))
+    # which A lanes are used at all, and an example of the D lanes per pair
+    used = sorted(set(p[0] for p in pairs))
+    print("   A lanes used:", used)
+    for la, lb, dl in pairs[:6]:
+        print("   A %2d x B %2d -> D %s" % (la, lb, dl))
