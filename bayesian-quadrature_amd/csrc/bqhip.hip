@@ -78,7 +78,7 @@ struct bq_ctx {
     hipEvent_t ev_panel = nullptr, ev_next = nullptr, ev_fork = nullptr;
     int lookahead = 1;
     int potf2_waves = 4; // 4: potf2_64x4_kernel, 1: potf2_64_kernel (BQ_POTF2_WAVES)
-    int gemm_lds = 1;    // LDS-staged 128x128 trailing update (BQ_GEMM_LDS)
+    int gemm_lds = 0;    // LDS-staged 128x128 trailing update (BQ_GEMM_LDS)
     int mfma444 = 1;     // trailing / panel updates on v_mfma_f64_4x4x4_4b_f64 (BQ_MFMA444)
     int fuse = 1;        // diagonal factor fused into the launch that last updates it (BQ_FUSE)
     int gram_nt = 0;     // non-temporal stores in the Gram kernel (BQ_GRAM_NT)

@@ -37,6 +37,11 @@ PEAK_HBM_GBS = 8000.0
 PEAK_FP64_TFLOPS = 78.6
 
 
+# the 128x128-tile trailing-update kernel as rocprofv3 names it (4x4 MFMA tiles per wave,
+# v_mfma_f64_4x4x4 variant)
+TRAILING_KERNEL = "gemm_sub_kernel<4, 4, 1>"
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary
     (profiles/*_pmc_traffic.json, made by tools/pmc_summary.py from separate
@@ -299,10 +304,10 @@ def extras(eng, nb_override):
                 "class_ms_sequential": {k: v["ms"] for k, v in prof.items()},
                 "class_ms_lookahead": {k: v["ms"] for k, v in prof_la.items()},
                 "class_launches_sequential": {k: v["launches"] for k, v in prof.items()}}
-            traffic, src = pmc_traffic("gemm_sub_kernel<4, 4>")
+            traffic, src = pmc_traffic(TRAILING_KERNEL)
             ach = sy["work"] / (sy["ms"] * 1e-3) / 1e12
             out["trailing_update_n16384"] = {
-                "kernel": "gemm_sub_kernel<4, 4>", "bound": "mfma", "achieved": ach,
+                "kernel": TRAILING_KERNEL, "bound": "mfma", "achieved": ach,
                 "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_TFLOPS,
                 "traffic": traffic, "traffic_source": src,
                 "algorithmic_flops_per_launch": sy["work"] / max(1, sy["launches"]),
@@ -359,6 +364,8 @@ def batched_configs(eng):
                                "failed": int((status != 0).sum()),
                                "potrf_tflops_lower_bound": flops / (ms * 1e-3) / 1e12}
     c3 = wl.c3()
+    # one untimed chunk first: the first call pays the 100 x 128 MiB workspace allocation
+    eng.logml_grid(c3["x"], c3["y"], c3["h"][:100], c3["w"][:100], c3["s"], chunk=100)
     t0 = time.perf_counter()
     lm = eng.logml_grid(c3["x"], c3["y"], c3["h"], c3["w"], c3["s"], chunk=100)
     wall = time.perf_counter() - t0

@@ -42,7 +42,7 @@ def main():
             out["kernels"][r.short]["calls_in_trace"] = int(r.Calls)
     with open(os.path.join(root, "profiles", "%s_pmc_traffic.json" % tag), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
-    print(json.dumps(out["kernels"].get("gemm_sub_kernel<4, 4>"), indent=1))
+    print(json.dumps(out["kernels"].get("gemm_sub_kernel<4, 4, 1>"), indent=1))
     print(json.dumps(out["kernels"].get("gram_sym_kernel<2>"), indent=1))
 
 
