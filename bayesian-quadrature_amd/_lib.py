@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbqhip.so")
+# BQHIP_LIBRARY: developer override used to A/B experimental builds of the same C ABI
+LIB_PATH = os.environ.get("BQHIP_LIBRARY") or os.path.join(_HERE, "libbqhip.so")
 
 BQ_OK, BQ_ERR_NOT_PD, BQ_ERR_BAD_ARG, BQ_ERR_HIP, BQ_ERR_NOMEM = 0, 1, 2, 3, 4
 BQ_MAX_DIM = 8
@@ -35,6 +36,7 @@ SIGNATURES = {
                                  C.POINTER(C.c_int)]),
     "bq_set_block": (C.c_int, [_vp, C.c_int]),
     "bq_set_lookahead": (C.c_int, [_vp, C.c_int]),
+    "bq_ctx_trim": (C.c_int, [_vp]),
     "bq_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "bq_dev_free": (C.c_int, [_vp, _vp]),
     "bq_upload": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),

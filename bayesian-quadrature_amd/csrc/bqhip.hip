@@ -78,7 +78,8 @@ struct bq_ctx {
     hipEvent_t ev_panel = nullptr, ev_next = nullptr, ev_fork = nullptr;
     int lookahead = 1;
     int potf2_waves = 4; // 4: potf2_64x4_kernel, 1: potf2_64_kernel (BQ_POTF2_WAVES)
-    int gemm_lds = 0;    // LDS-staged 128x128 trailing update (BQ_GEMM_LDS)
+    int gemm_lds = 1;    // LDS-staged 128x128 trailing update (BQ_GEMM_LDS)
+    int tile_order = 0;  // 2: XCD-aware super-tile order of the triangular tile list (BQ_TILE_ORDER)
     int mfma444 = 1;     // trailing / panel updates on v_mfma_f64_4x4x4_4b_f64 (BQ_MFMA444)
     int fuse = 1;        // diagonal factor fused into the launch that last updates it (BQ_FUSE)
     int gram_nt = 0;     // non-temporal stores in the Gram kernel (BQ_GRAM_NT)
@@ -86,6 +87,7 @@ struct bq_ctx {
     bool own_stream = false;
     int cus = 256;
     int nb_override = 0;
+    bq_plan *plan_cache = nullptr; // workspace of the last batched call, kept for the next one
     char err[512] = {0};
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool prof = false;
@@ -294,6 +296,19 @@ int launch_assemble(bq_ctx *c, int d, const double *pts, long pstride, const dou
 // C(m x n) -= P(m x k) Q(n x k)^T; tile shape from the amount of parallelism
 // fuse_j0 >= 0: also factor the leading 64x64 block of C (global column fuse_j0) in the
 // same launch (see gemm_sub_kernel); dinv / info as for launch_potf2
+// whether C(m x n) -= P Q^T with unit-stride Q rows goes to the LDS-staged 128 x 128 kernel:
+// enough workgroup tiles to fill the chip, whole 64 x 64 wave tiles, k in chunks of 32.
+// Such an update never carries the fused diagonal factor (the factor would ride on the
+// register-streaming kernel, which is slower by more than a potf2 launch costs).
+static bool gemm_uses_lds(const bq_ctx *c, int m, int n, int k, int lower, int batch)
+{
+    long a = (long)((m + 127) / 128) * ((n + 127) / 128) * batch;
+    if (lower)
+        a = a / 2 + 1;
+    return c->gemm_lds && c->mfma444 && a >= c->cus && (m % 64) == 0 && (n % 64) == 0 &&
+           (k % 32) == 0;
+}
+
 int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const double *P, long ldp,
                 long pstride, const double *Q, long qsj, long qsk, long qstride, int m, int n,
                 int k, int lower, int batch, int fuse_j0 = -1, double *dinv = nullptr,
@@ -337,11 +352,19 @@ int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const dou
                                mode, fuse_j0, dinv, dstride, info);                                \
     } while (0)
     if (tiles(128) >= cu) {
-        if (c->gemm_lds && f444 && fuse_j0 < 0 && (k % 8) == 0)
-            hipLaunchKernelGGL(gemm_lds_kernel, grid_for(128), dim3(256), 0, c->cur, C, ldc,
-                               cstride, P, ldp, pstride, Q, qsk, qstride, m, n, k, mode);
-        else
+        if (f444 && fuse_j0 < 0 && gemm_uses_lds(c, m, n, k, lower, batch)) {
+            dim3 g = grid_for(128);
+            const int order = tri ? c->tile_order : 0;
+            if (order == 2) { // super-tile list of the triangle rounded up to 8 tiles a side
+                const unsigned ts = ((unsigned)((m + 127) / 128) + 7) / 8;
+                g.x = 32 * ts * ts + 4 * ts;
+            }
+            hipLaunchKernelGGL(gemm_lds_kernel, g, dim3(256), BQ_LDS_BYTES, c->cur,
+                               C, ldc, cstride, P, ldp, pstride, Q, qsk, qstride, m, n, k, mode,
+                               order);
+        } else {
             BQ_GEMM_SUB(4, 4, 128);
+        }
     } else if (tiles(64) >= cu / 2) {
         if (k == 64)
             hipLaunchKernelGGL((gemm_k64_kernel<2, 2>), grid_for(64), dim3(256), 0, c->cur, C, ldc,
@@ -462,7 +485,10 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
             if (r0 < ntot) {
                 const double *P = A + r0 + (long)K0 * lda;
                 // the trailing update also factors the next diagonal block if there is one
-                const int fj = (c->fuse && r0 < ncols) ? r0 : -1;
+                const int fj = (c->fuse && r0 < ncols &&
+                                !gemm_uses_lds(c, ntot - r0, ntot - r0, KB, 1, batch))
+                                   ? r0
+                                   : -1;
                 BQCHK(launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda,
                                   astride, P, 1, lda, astride, ntot - r0, ntot - r0, KB, 1, batch,
                                   fj, dinv, 64, info));
@@ -612,10 +638,15 @@ static int ctx_init(bq_ctx *c, int device)
     int lo = 0, hi = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIPCHK(c, hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, hi));
+    // the LDS-staged trailing update uses 72 KiB of dynamic LDS per workgroup
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lds_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, BQ_LDS_BYTES));
     if (const char *e = std::getenv("BQ_LOOKAHEAD"))
         c->lookahead = std::atoi(e);
     if (const char *e = std::getenv("BQ_GEMM_LDS"))
         c->gemm_lds = std::atoi(e);
+    if (const char *e = std::getenv("BQ_TILE_ORDER"))
+        c->tile_order = std::atoi(e);
     if (const char *e = std::getenv("BQ_MFMA444"))
         c->mfma444 = std::atoi(e);
     if (const char *e = std::getenv("BQ_FUSE"))
@@ -680,6 +711,10 @@ extern "C" void bq_ctx_destroy(bq_ctx *c)
         return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->plan_cache) {
+        bq_plan_destroy(c, c->plan_cache);
+        c->plan_cache = nullptr;
+    }
     for (auto &e : c->prof_events) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -1171,6 +1206,48 @@ extern "C" void bq_plan_destroy(bq_ctx *c, bq_plan *p)
     delete p;
 }
 
+namespace {
+
+// The batched host entry points (bq_batch_fit_predict, bq_gp_logml_grid) keep their plan --
+// up to half of the free HBM -- in the context between calls: a hyper-parameter loop calls
+// them again and again with the same shapes, and allocating and releasing tens of GB per
+// call costs milliseconds every time and, now and then, hundreds (observed on the C3 grid:
+// 230 ms typical, 0.5 - 1.6 s spikes).  bq_ctx_trim() releases it.
+int plan_acquire(bq_ctx *c, int64_t nprob, int64_t d, int64_t n, int64_t M, bq_plan **out)
+{
+    bq_plan *p = c->plan_cache;
+    c->plan_cache = nullptr;
+    if (p && p->nprob == nprob && p->d == d && p->n == n && p->M == M) {
+        *out = p;
+        return BQ_OK;
+    }
+    if (p)
+        bq_plan_destroy(c, p);
+    return bq_plan_create(c, nprob, d, n, M, out);
+}
+
+void plan_release(bq_ctx *c, bq_plan *p)
+{
+    if (!p)
+        return;
+    if (c->plan_cache)
+        bq_plan_destroy(c, c->plan_cache);
+    c->plan_cache = p;
+}
+
+} // namespace
+
+extern "C" int bq_ctx_trim(bq_ctx *c)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    if (c->plan_cache) {
+        bq_plan_destroy(c, c->plan_cache);
+        c->plan_cache = nullptr;
+    }
+    return BQ_OK;
+}
+
 extern "C" int bq_plan_bytes(bq_plan *p, size_t *bytes)
 {
     if (!p || !bytes)
@@ -1335,8 +1412,9 @@ extern "C" int bq_batch_fit_predict(bq_ctx *c, int64_t nprob, const double *x, c
     HIPCHK(c, hipMemGetInfo(&freeb, &totalb));
     int64_t chunk = std::max<int64_t>(1, (int64_t)((freeb / 2) / per));
     chunk = std::min<int64_t>(chunk, nprob);
-    bq_plan *p = nullptr;
-    BQCHK(bq_plan_create(c, chunk, d, n, M, &p));
+    bq_plan *p = nullptr, *big = nullptr;
+    BQCHK(plan_acquire(c, chunk, d, n, M, &p));
+    big = p;
     std::vector<double> hh((size_t)chunk, h), ss((size_t)chunk, s), ww((size_t)chunk * d);
     for (int64_t b = 0; b < chunk; ++b)
         for (int64_t k = 0; k < d; ++k)
@@ -1344,8 +1422,7 @@ extern "C" int bq_batch_fit_predict(bq_ctx *c, int64_t nprob, const double *x, c
     int st = BQ_OK;
     for (int64_t p0 = 0; p0 < nprob && st == BQ_OK; p0 += chunk) {
         const int64_t nb = std::min(chunk, nprob - p0);
-        if (nb != chunk) { // last, smaller chunk: a fresh plan of the right size
-            bq_plan_destroy(c, p);
+        if (nb != chunk) { // last, smaller chunk: a temporary plan of the right size
             p = nullptr;
             st = bq_plan_create(c, nb, d, n, M, &p);
             if (st != BQ_OK)
@@ -1361,7 +1438,9 @@ extern "C" int bq_batch_fit_predict(bq_ctx *c, int64_t nprob, const double *x, c
                                  var ? var + (size_t)p0 * M : nullptr,
                                  logml ? logml + p0 : nullptr, status ? status + p0 : nullptr);
     }
-    bq_plan_destroy(c, p);
+    if (p != big)
+        bq_plan_destroy(c, p);
+    plan_release(c, big);
     return st;
 }
 
@@ -1392,8 +1471,9 @@ extern "C" int bq_gp_logml_grid(bq_ctx *c, const double *x, const double *y, int
         chunk = std::max<int64_t>(1, (int64_t)((freeb / 2) / per));
     }
     chunk = std::min<int64_t>(chunk, G);
-    bq_plan *p = nullptr;
-    BQCHK(bq_plan_create(c, chunk, d, n, 0, &p));
+    bq_plan *p = nullptr, *big = nullptr;
+    BQCHK(plan_acquire(c, chunk, d, n, 0, &p));
+    big = p;
     // the data are shared: replicate x, y once for the chunk
     std::vector<double> xr((size_t)chunk * d * n), yr((size_t)chunk * n), ss((size_t)chunk, s);
     for (int64_t b = 0; b < chunk; ++b) {
@@ -1403,8 +1483,7 @@ extern "C" int bq_gp_logml_grid(bq_ctx *c, const double *x, const double *y, int
     int st = BQ_OK;
     for (int64_t g0 = 0; g0 < G && st == BQ_OK; g0 += chunk) {
         const int64_t nb = std::min(chunk, G - g0);
-        if (nb != chunk) {
-            bq_plan_destroy(c, p);
+        if (nb != chunk) { // last, smaller chunk: a temporary plan of the right size
             p = nullptr;
             st = bq_plan_create(c, nb, d, n, 0, &p);
             if (st != BQ_OK)
@@ -1417,7 +1496,9 @@ extern "C" int bq_gp_logml_grid(bq_ctx *c, const double *x, const double *y, int
         if (st == BQ_OK)
             st = bq_plan_results(c, p, nullptr, nullptr, out + g0, nullptr);
     }
-    bq_plan_destroy(c, p);
+    if (p != big)
+        bq_plan_destroy(c, p);
+    plan_release(c, big);
     return st;
 }
 

@@ -16,6 +16,37 @@ __device__ __forceinline__ void tri_decode(int t, int &bx, int &by)
     by = t - bx * (bx + 1) / 2;
 }
 
+// XCD-aware order of the lower-triangular workgroup-tile list.  Hardware sends workgroup id
+// to XCD id % 8, and every XCD has its own L2.  Row by row, the 64 workgroups resident on
+// one XCD hold ~5 different P row blocks and ~60 different Q row blocks: about half of
+// their operand chunks miss L2 (TCC_MISS, PMC) and cross the fabric.  Here the tile
+// triangle is cut into 8 x 8 super-tiles (diagonal ones hold 36 tiles), listed super-tile
+// by super-tile, and inside every run of 512 workgroup ids XCD x takes list entries
+// [64 x, 64 x + 64): its 64 resident workgroups share 8 P and 8 Q row blocks.
+// Returns false for ids that fall outside the triangle (the triangle side is rounded up to
+// a multiple of 8 tiles; those workgroups exit at once).
+__device__ __forceinline__ bool supertile_decode(int id, int nid, int tn, int &bx, int &by)
+{
+    // the last, partial run of 512 ids keeps the list order
+    const int u = id < (nid & ~511) ? (id & ~511) + ((id & 7) << 6) + ((id >> 3) & 63) : id;
+    int sx = (int)((__builtin_sqrt(16.0 + 128.0 * u) - 4.0) * (1.0 / 64.0));
+    while (32 * (sx + 1) * (sx + 1) + 4 * (sx + 1) <= u)
+        ++sx;
+    while (32 * sx * sx + 4 * sx > u)
+        --sx;
+    const int rem = u - (32 * sx * sx + 4 * sx);
+    if (rem < 64 * sx) {
+        bx = 8 * sx + ((rem & 63) >> 3);
+        by = 8 * (rem >> 6) + (rem & 7);
+    } else {
+        int ix, iy;
+        tri_decode(rem - 64 * sx, ix, iy);
+        bx = 8 * sx + ix;
+        by = 8 * sx + iy;
+    }
+    return bx < tn;
+}
+
 // one wave tile of C -= P Q^T (see gemm_sub_kernel); C, P, Q already point at the batch element
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_sub_tile(double *__restrict__ C, long ldc,
@@ -99,25 +130,33 @@ __device__ __forceinline__ void gemm_sub_tile(double *__restrict__ C, long ldc,
     }
 
     // D^T tile: D[jj][ii], jj = l4 + 4 r (column of C), ii = l15 (row of C)
+    // Two passes, all loads before any store: written as `*dst -= acc` the compiler must
+    // assume the store of one element aliases the load of the next and serialises 64
+    // memory round trips per lane (measured: 14 % of the trailing update).
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        const int r = row0 + tm * 16;
-        if (r >= m)
-            continue;
+    for (int pass = 0; pass < 2; ++pass)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int c = col0 + tn * 16;
-            if (c >= n)
-                continue;
-            if (lower && c >= r + 16)
+        for (int tm = 0; tm < TM; ++tm) {
+            const int r = row0 + tm * 16;
+            if (r >= m)
                 continue;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                double *dst = C + (r + l15) + (long)(c + l4 + 4 * rr) * ldc;
-                *dst -= acc[tm][tn][rr];
+            for (int tn = 0; tn < TN; ++tn) {
+                const int c = col0 + tn * 16;
+                if (c >= n)
+                    continue;
+                if (lower && c >= r + 16)
+                    continue;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    double *dst = C + (r + l15) + (long)(c + l4 + 4 * rr) * ldc;
+                    if (pass == 0)
+                        acc[tm][tn][rr] = *dst - acc[tm][tn][rr];
+                    else
+                        *dst = acc[tm][tn][rr];
+                }
             }
         }
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -155,24 +194,81 @@ __device__ __forceinline__ double row_ror_quads(double v)
     return __hiloint2double(hi, lo);
 }
 
+// C tile access of a (16 TM) x (16 TN) wave tile held as acc[TM][TN][4] in the rotated-quad
+// layout (gemm444_tile / gemm_lds_kernel).  Written as `*dst -= acc` at the end of the
+// kernel, the compiler must assume that the store of one element aliases the load of the
+// next and serialises 64 memory round trips per lane (measured: 14 % of the N=16384
+// trailing update).  Instead the accumulators START as -C (every load in flight at once,
+// straight into the accumulator registers, overlapping the first operand fetch; blocks
+// above the diagonal are read and dropped so there is no branch between the loads), the
+// MFMAs add P Q^T, and the epilogue only stores -acc = C - P Q^T.
+// Addresses: wave-uniform tile origin (SGPR base) + four 32-bit per-lane offsets, one per
+// rotation + immediates -- no per-element 64-bit address arithmetic.
+template <int TM, int TN> struct Tile444 {
+    char *tile;
+    long tnstep;
+    unsigned voff[4];
+    int row0, col0;
+    __device__ __forceinline__ Tile444(double *C, long ldc, int row0_, int col0_, int lane)
+    {
+        const int l15 = lane & 15, l4 = lane >> 4, blk = (lane >> 2) & 3;
+        row0 = __builtin_amdgcn_readfirstlane(row0_);
+        col0 = __builtin_amdgcn_readfirstlane(col0_);
+        tile = reinterpret_cast<char *>(C + row0 + (long)col0 * ldc);
+        tnstep = 16 * ldc * (long)sizeof(double);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            voff[s] = (unsigned)((l15 + (long)(l4 + 4 * ((blk - s) & 3)) * ldc) * (long)sizeof(double));
+    }
+    __device__ __forceinline__ double *at(int tm, int tn, int s) const
+    {
+        return reinterpret_cast<double *>((tile + (tn * tnstep + tm * 128)) + voff[s]);
+    }
+    __device__ __forceinline__ void load_neg(double (&acc)[TM][TN][4]) const
+    {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc[tm][tn][s] = *at(tm, tn, s);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc[tm][tn][s] = -acc[tm][tn][s];
+    }
+    __device__ __forceinline__ void store_neg(const double (&acc)[TM][TN][4], int lower) const
+    {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                if (lower && col0 + tn * 16 >= row0 + tm * 16 + 16)
+                    continue;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    *at(tm, tn, s) = -acc[tm][tn][s];
+            }
+    }
+};
+
 template <int TM, int TN>
 __device__ __forceinline__ void gemm444_tile(double *__restrict__ C, long ldc,
                                              const double *__restrict__ P, long ldp,
                                              const double *__restrict__ Q, long ldq, int k,
                                              int lower, int row0, int col0, int lane)
 {
-    const int l15 = lane & 15, l4 = lane >> 4, blk = (lane >> 2) & 3;
+    const int l15 = lane & 15, l4 = lane >> 4;
     const double *pp = P + row0 + l15 + (long)l4 * ldp;
     const double *qq = Q + col0 + l15 + (long)l4 * ldq;
 
     double acc[TM][TN][4];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                acc[tm][tn][s] = 0.0;
+    const Tile444<TM, TN> ct(C, ldc, row0, col0, lane);
+    ct.load_neg(acc);
 
     double pa[TM], qa[TN], pb[TM], qb[TN];
 #pragma unroll
@@ -184,12 +280,14 @@ __device__ __forceinline__ void gemm444_tile(double *__restrict__ C, long ldc,
     const long pstep = 4 * ldp, qstep = 4 * ldq;
     const int ksteps = k >> 2; // even
 
+#define BQ_444_ROT                                                                                 \
+    const double q1 = row_ror_quads<1>(q0), q2 = row_ror_quads<2>(q0), q3 = row_ror_quads<3>(q0);
+#define BQ_444_KOFF(ks) (long)(ks)
 #define BQ_444_STEP(PF, QF)                                                                        \
     _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)                                              \
     {                                                                                              \
         const double q0 = QF[tn];                                                                  \
-        const double q1 = row_ror_quads<1>(q0), q2 = row_ror_quads<2>(q0),                         \
-                     q3 = row_ror_quads<3>(q0);                                                    \
+        BQ_444_ROT                                                                                 \
         _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                          \
         {                                                                                          \
             acc[tm][tn][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(q0, PF[tm], acc[tm][tn][0], 0, 0, 0); \
@@ -200,7 +298,7 @@ __device__ __forceinline__ void gemm444_tile(double *__restrict__ C, long ldc,
     }
 
     for (int ks = 0; ks < ksteps; ks += 2) {
-        const double *p1 = pp + (long)(ks + 1) * pstep, *q1p = qq + (long)(ks + 1) * qstep;
+        const double *p1 = pp + BQ_444_KOFF(ks + 1) * pstep, *q1p = qq + BQ_444_KOFF(ks + 1) * qstep;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
             pb[tm] = p1[16 * tm];
@@ -210,7 +308,7 @@ __device__ __forceinline__ void gemm444_tile(double *__restrict__ C, long ldc,
         __builtin_amdgcn_sched_barrier(0);
         BQ_444_STEP(pa, qa)
         __builtin_amdgcn_sched_barrier(0);
-        const long o2 = (ks + 2 < ksteps) ? (long)(ks + 2) : (long)ks; // clamped, value unused
+        const long o2 = BQ_444_KOFF((ks + 2 < ksteps) ? (ks + 2) : ks); // clamped, value unused
         const double *p2 = pp + o2 * pstep, *q2p = qq + o2 * qstep;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -223,23 +321,10 @@ __device__ __forceinline__ void gemm444_tile(double *__restrict__ C, long ldc,
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef BQ_444_STEP
+#undef BQ_444_ROT
+#undef BQ_444_KOFF
 
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        const int r = row0 + tm * 16;
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int c = col0 + tn * 16;
-            if (lower && c >= r + 16)
-                continue;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int cq = (blk - s) & 3;
-                double *dst = C + (r + l15) + (long)(c + 4 * cq + l4) * ldc;
-                *dst -= acc[tm][tn][s];
-            }
-        }
-    }
+    ct.store_neg(acc, lower);
 }
 
 // Fused diagonal factor: when fuse_j0 >= 0 the launch also factors the leading 64x64
@@ -259,6 +344,10 @@ __global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C
 {
     __shared__ __attribute__((aligned(16))) double ring[3 * 4 * 64];
     __shared__ int sbad[4];
+    // the small-tile forms are the panel's own updates: on the look-ahead stream they share
+    // CUs with the bulk trailing update and sit on the critical path, so they issue first
+    if (TM < 4)
+        __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int bx = blockIdx.x, by = blockIdx.y;
@@ -395,6 +484,7 @@ __global__ __launch_bounds__(256) void gemm_k64_kernel(double *__restrict__ C, l
 {
     __shared__ __attribute__((aligned(16))) double ring[3 * 4 * 64];
     __shared__ int sbad[4];
+    __builtin_amdgcn_s_setprio(3); // panel-internal update: see gemm_sub_kernel
     const int b = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int bx = blockIdx.x, by = blockIdx.y;
@@ -433,34 +523,48 @@ __global__ __launch_bounds__(256) void gemm_k64_kernel(double *__restrict__ C, l
 // Trailing update, LDS-staged: C(m x n) -= P Q^T, workgroup tile 128 x 128, wave tile
 // 64 x 64, v_mfma_f64_4x4x4_4b_f64.  The register-streaming kernel above reads every
 // fragment from global memory in two waves and spends VALU issue slots on the quad
-// rotations; at the four-block MFMA's rate that is what it is bound by (measured 52 of
-// the ~65 TFLOP/s the same loop reaches without memory).  Here a workgroup stages
-// 8 k-columns of its P and Q row blocks in LDS once (16-byte global loads issued a
-// chunk ahead, ds_write_b128 after the barrier -- the async-stage split), and every
-// wave reads its fragments from LDS: 4 P fragments and, instead of rotating, the 16
-// pre-rotated views of its 4 Q fragments -- a rotated view is just another address
-// pattern of the same 16 doubles, conflict-free like the plain one (k rows are
-// padded to 1152 bytes so that the two k rows of a half-wave use disjoint banks).
-// The inner loop has no VALU work at all.
-// Requires qsj == 1, m and n multiples of 64, k a multiple of 8.
+// rotations and on 64-bit load addresses (0.57 VALU instructions per MFMA, PMC); VALU
+// and the f64 MFMA do not co-execute, so that is what it is bound by.  Here a
+// workgroup stages 16 k-columns of its P and Q row blocks in LDS with LDS-DMA
+// (global_load_lds_dwordx4: one wave instruction moves one k row of 128 doubles, no
+// staging registers, no ds_write), a chunk ahead of the MFMAs, and every wave reads its
+// fragments from LDS with immediate offsets: 4 P fragments and, instead of rotating, the
+// 16 pre-rotated views of its 4 Q fragments -- a rotated view is just another address
+// pattern of the same 16 doubles.  Fragments of k-step s+1 are read while the MFMAs of
+// k-step s run.  The inner loop has no VALU work at all.
+// LDS: 2 buffers x (16 P rows + 16 Q rows) x 1152 B = 72 KiB per workgroup, two
+// workgroups per CU.  One barrier per chunk (256 MFMAs per wave).
+// Requires qsj == 1, m and n multiples of 64, k a multiple of 32.
 // ---------------------------------------------------------------------------
-#define BQ_LDS_KC 8                  // k columns per chunk
+#define BQ_LDS_KC 16                 // k columns per chunk
 #define BQ_LDS_ROW (128 * 8 + 128)   // bytes per staged k row (128 doubles + pad)
+#define BQ_LDS_STAGE (2 * BQ_LDS_KC * BQ_LDS_ROW)
+#define BQ_LDS_BYTES (2 * BQ_LDS_STAGE)
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void global_cvoid_t;
 
 __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C, long ldc,
                                                           long cstride, const double *__restrict__ P,
                                                           long ldp, long pstride,
                                                           const double *__restrict__ Q, long ldq,
                                                           long qstride, int m, int n, int k,
-                                                          int lower)
+                                                          int lower, int order)
 {
-    // [buffer][P / Q][k row][128 doubles + pad]
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * BQ_LDS_KC * BQ_LDS_ROW];
+    // [buffer][P rows 0..15 | Q rows 16..31][128 doubles + pad]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.z;
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6); // scalar: LDS-DMA bases stay in SGPRs
     int bx = blockIdx.x, by = blockIdx.y;
-    if (lower == 2)
-        tri_decode(blockIdx.x, bx, by);
+    if (lower == 2) {
+        if (order == 2) {
+            if (!supertile_decode(blockIdx.x, gridDim.x, (m + 127) >> 7, bx, by))
+                return;
+        } else {
+            tri_decode(blockIdx.x, bx, by);
+        }
+    }
     C += (long)b * cstride;
     P += (long)b * pstride;
     Q += (long)b * qstride;
@@ -469,113 +573,84 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C
     const int row0 = R0 + wr, col0 = C0 + wc;
     const bool active = row0 < m && col0 < n && !(lower && col0 >= row0 + 64);
 
-    // staging map: 2 x (8 k columns x 64 pairs of rows) per operand over 256 threads
-    const int pair = t & 63, kq = t >> 6; // k columns kq and kq + 4
-    const int prow = min(R0 + 2 * pair, m - 2), qrow = min(C0 + 2 * pair, n - 2);
-    const double *gp = P + prow + (long)kq * ldp;
-    const double *gq = Q + qrow + (long)kq * ldq;
-    unsigned char *sP = smem, *sQ = smem + BQ_LDS_KC * BQ_LDS_ROW;
-    constexpr int BUF = 2 * BQ_LDS_KC * BQ_LDS_ROW;
-    const int soff = kq * BQ_LDS_ROW + pair * 16;
+    // staging: a chunk is 32 k rows (16 of P, 16 of Q); wave w moves rows 8w .. 8w+7, one
+    // LDS-DMA per row, lane i carrying rows 2i, 2i+1 of the operand's 128-row block
+    // (clamped at the matrix edge: the clamped rows feed accumulators that are not stored)
+    const bool stq = wave >= 2;
+    const long sld = stq ? ldq : ldp;
+    const double *gsrc = stq ? Q + min(C0 + 2 * lane, n - 2) + (long)(8 * (wave - 2)) * ldq
+                             : P + min(R0 + 2 * lane, m - 2) + (long)(8 * wave) * ldp;
+    const int srow = wave * 8 * BQ_LDS_ROW; // wave-uniform LDS offset of this wave's first row
 
     const int l15 = lane & 15, l4 = lane >> 4;
-    // fragment read offsets inside a chunk: k row l4 (+4 for the second k-step)
-    const int pfrag = l4 * BQ_LDS_ROW + (wr + l15) * 8;
-    int qfrag[4];
+    // fragment read offsets inside a stage buffer: k row l4 of a k-step
+    const unsigned char *pview = smem + l4 * BQ_LDS_ROW + (wr + l15) * 8;
+    const unsigned char *qview[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) // view rotated by s quads: lane reads column (l15 - 4 s) mod 16
-        qfrag[s] = l4 * BQ_LDS_ROW + (wc + ((l15 - 4 * s) & 15)) * 8;
+        qview[s] = smem + (BQ_LDS_KC + l4) * BQ_LDS_ROW + (wc + ((l15 - 4 * s) & 15)) * 8;
 
     double acc[4][4][4];
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                acc[tm][tn][s] = 0.0;
 
-    double2_t stP[2], stQ[2];
-    const int nchunk = k / BQ_LDS_KC;
-    // prologue: chunk 0 -> LDS buffer 0
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        stP[j] = *reinterpret_cast<const double2_t *>(gp + (long)(4 * j) * ldp);
-        stQ[j] = *reinterpret_cast<const double2_t *>(gq + (long)(4 * j) * ldq);
+#define BQ_LDS_FILL(BUF_, CH_)                                                                     \
+    {                                                                                              \
+        const double *g_ = gsrc + (long)(CH_) * BQ_LDS_KC * sld;                                   \
+        _Pragma("unroll") for (int r = 0; r < 8; ++r) __builtin_amdgcn_global_load_lds(            \
+            (global_cvoid_t *)(g_ + (long)r * sld),                                                \
+            (lds_void_t *)(smem + (BUF_) * BQ_LDS_STAGE + srow + r * BQ_LDS_ROW), 16, 0, 0);       \
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        *reinterpret_cast<double2_t *>(sP + soff + 4 * j * BQ_LDS_ROW) = stP[j];
-        *reinterpret_cast<double2_t *>(sQ + soff + 4 * j * BQ_LDS_ROW) = stQ[j];
+    // one chunk from buffer BUF_: (1) every wave's LDS-DMA of this chunk has landed and
+    // every wave is done with the other buffer; (2) LDS-DMA of the next chunk into it;
+    // (3) 16 sub-steps (k-step st, column block tn) of 16 MFMAs; the 4 rotated Q views of
+    // sub-step j+1 (and the 4 P fragments of the next k-step) are read during sub-step j
+#define BQ_LDS_READ_P(BUF_, ST_, PF)                                                               \
+    _Pragma("unroll") for (int tm = 0; tm < 4; ++tm) PF[tm] = *reinterpret_cast<const double *>(   \
+        pview + (BUF_) * BQ_LDS_STAGE + (ST_) * 4 * BQ_LDS_ROW + tm * 128);
+#define BQ_LDS_READ_Q(BUF_, ST_, TN_, QF)                                                          \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) QF[s] = *reinterpret_cast<const double *>(       \
+        qview[s] + (BUF_) * BQ_LDS_STAGE + (ST_) * 4 * BQ_LDS_ROW + (TN_) * 128);
+#define BQ_LDS_CHUNK(BUF_, CH_)                                                                    \
+    {                                                                                              \
+        __syncthreads();                                                                           \
+        if ((CH_) + 1 < nchunk)                                                                    \
+            BQ_LDS_FILL(1 - (BUF_), (CH_) + 1)                                                     \
+        if (active) {                                                                              \
+            BQ_LDS_READ_P(BUF_, 0, pf[0])                                                          \
+            BQ_LDS_READ_Q(BUF_, 0, 0, qf[0])                                                       \
+            _Pragma("unroll") for (int j = 0; j < 16; ++j)                                         \
+            {                                                                                      \
+                const int st = j >> 2, tn = j & 3;                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                 \
+                if (j < 15)                                                                        \
+                    BQ_LDS_READ_Q(BUF_, (j + 1) >> 2, (j + 1) & 3, qf[(j + 1) & 1])                \
+                if (tn == 3 && j < 15)                                                             \
+                    BQ_LDS_READ_P(BUF_, st + 1, pf[(st + 1) & 1])                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                 \
+                _Pragma("unroll") for (int tm = 0; tm < 4; ++tm)                                   \
+                    _Pragma("unroll") for (int s = 0; s < 4; ++s) acc[tm][tn][s] =                 \
+                        __builtin_amdgcn_mfma_f64_4x4x4f64(qf[j & 1][s], pf[st & 1][tm],           \
+                                                           acc[tm][tn][s], 0, 0, 0);               \
+            }                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }                                                                                          \
     }
-    __syncthreads();
 
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const int cur = (ch & 1) * BUF;
-        // (1) global loads of the next chunk, in flight during this chunk's MFMAs
-        const bool more = ch + 1 < nchunk;
-        if (more) {
-            const long ko = (long)(ch + 1) * BQ_LDS_KC;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                stP[j] = *reinterpret_cast<const double2_t *>(gp + (ko + 4 * j) * ldp);
-                stQ[j] = *reinterpret_cast<const double2_t *>(gq + (ko + 4 * j) * ldq);
-            }
-        }
-        // (2) the chunk's two k-steps from LDS
-        if (active) {
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                const unsigned char *bp = sP + cur + st * 4 * BQ_LDS_ROW;
-                const unsigned char *bq = sQ + cur + st * 4 * BQ_LDS_ROW;
-                double pf[4], qf[4][4];
-#pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
-                    pf[tm] = *reinterpret_cast<const double *>(bp + pfrag + tm * 128);
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        qf[tn][s] = *reinterpret_cast<const double *>(bq + qfrag[s] + tn * 128);
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-                    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            acc[tm][tn][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(
-                                qf[tn][s], pf[tm], acc[tm][tn][s], 0, 0, 0);
-            }
-        }
-        // (3) next chunk into the other buffer; (4) one barrier per chunk
-        if (more) {
-            const int nxt = ((ch + 1) & 1) * BUF;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                *reinterpret_cast<double2_t *>(sP + nxt + soff + 4 * j * BQ_LDS_ROW) = stP[j];
-                *reinterpret_cast<double2_t *>(sQ + nxt + soff + 4 * j * BQ_LDS_ROW) = stQ[j];
-            }
-        }
-        __syncthreads();
+    double pf[2][4], qf[2][4];
+    const int nchunk = k / BQ_LDS_KC; // even
+    BQ_LDS_FILL(0, 0)
+    const Tile444<4, 4> ct(C, ldc, row0, col0, lane);
+    if (active)
+        ct.load_neg(acc);
+    for (int ch = 0; ch < nchunk; ch += 2) {
+        BQ_LDS_CHUNK(0, ch)
+        BQ_LDS_CHUNK(1, ch + 1)
     }
+#undef BQ_LDS_READ_P
+#undef BQ_LDS_READ_Q
+#undef BQ_LDS_CHUNK
+#undef BQ_LDS_FILL
 
     if (!active)
         return;
-    const int blk = (lane >> 2) & 3;
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-        const int r = row0 + tm * 16;
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            const int c = col0 + tn * 16;
-            if (lower && c >= r + 16)
-                continue;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int cq = (blk - s) & 3;
-                double *dst = C + (r + l15) + (long)(c + 4 * cq + l4) * ldc;
-                *dst -= acc[tm][tn][s];
-            }
-        }
-    }
+    ct.store_neg(acc, lower);
 }

@@ -96,7 +96,12 @@ class Engine(object):
     def set_lookahead(self, on):
         self._check(self._lib.bq_set_lookahead(self._ctx, 1 if on else 0))
 
+    def trim(self):
+        """Release the workspace the batched calls keep between calls."""
+        self._check(self._lib.bq_ctx_trim(self._ctx))
+
     # -- raw device memory -------------------------------------------------
+
     def alloc(self, nbytes):
         p = C.c_void_p()
         self._check(self._lib.bq_dev_alloc(self._ctx, int(nbytes), C.byref(p)))

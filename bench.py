@@ -37,9 +37,9 @@ PEAK_HBM_GBS = 8000.0
 PEAK_FP64_TFLOPS = 78.6
 
 
-# the 128x128-tile trailing-update kernel as rocprofv3 names it (4x4 MFMA tiles per wave,
-# v_mfma_f64_4x4x4 variant)
-TRAILING_KERNEL = "gemm_sub_kernel<4, 4, 1>"
+# the 128x128-tile LDS-staged trailing-update kernel as rocprofv3 names it
+# (v_mfma_f64_4x4x4_4b_f64, four 64x64 wave tiles)
+TRAILING_KERNEL = "gemm_lds_kernel"
 
 
 def pmc_traffic(kernel):
@@ -366,10 +366,14 @@ def batched_configs(eng):
     c3 = wl.c3()
     # one untimed chunk first: the first call pays the 100 x 128 MiB workspace allocation
     eng.logml_grid(c3["x"], c3["y"], c3["h"][:100], c3["w"][:100], c3["s"], chunk=100)
-    t0 = time.perf_counter()
-    lm = eng.logml_grid(c3["x"], c3["y"], c3["h"], c3["w"], c3["s"], chunk=100)
-    wall = time.perf_counter() - t0
-    out["c3_grid_400x4096"] = {"wall_ms": wall * 1e3, "ms_per_point": wall * 1e3 / len(lm),
+    walls = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        lm = eng.logml_grid(c3["x"], c3["y"], c3["h"], c3["w"], c3["s"], chunk=100)
+        walls.append(time.perf_counter() - t0)
+    wall = min(walls)
+    out["c3_grid_400x4096"] = {"wall_ms": wall * 1e3, "wall_ms_all": [w * 1e3 for w in walls],
+                               "ms_per_point": wall * 1e3 / len(lm),
                                "n_minus_inf": int(np.isinf(lm).sum()),
                                "potrf_tflops_lower_bound": len(lm) * (4096 ** 3 / 3.0) / wall / 1e12,
                                "note": "host wall clock incl. the upload of the 400 parameter "

@@ -63,6 +63,10 @@ int bq_set_block(bq_ctx *ctx, int nb);
 /* look-ahead of one panel on a second, high-priority stream (default on; the
  * environment variable BQ_LOOKAHEAD=0 also disables it) */
 int bq_set_lookahead(bq_ctx *ctx, int on);
+/* bq_batch_fit_predict and bq_gp_logml_grid keep their device workspace (up to half of
+ * the free HBM) in the context between calls, so that a hyper-parameter loop
+ * (bq.py:536-550) does not allocate and release it on every evaluation; this releases it */
+int bq_ctx_trim(bq_ctx *ctx);
 
 /* ---- device memory -------------------------------------------------- */
 int bq_dev_alloc(bq_ctx *ctx, size_t bytes, void **dptr);

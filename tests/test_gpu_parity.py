@@ -249,6 +249,25 @@ def test_batch_fit_predict(engine, oracle):
         assert abs(logml[i] - lmo) <= RTOL * abs(lmo)
 
 
+def test_batched_workspace_is_reused_and_trimmed(engine):
+    """The batched entry points keep their workspace in the context: the same call again
+    (same shapes, other hyper-parameters), a call of another shape, and a call after
+    trim() all give the results of a fresh evaluation."""
+    c = wl.c3(side=16, gh=3, gw=3)
+    a = engine.logml_grid(c["x"], c["y"], c["h"], c["w"], c["s"], chunk=4)
+    b = engine.logml_grid(c["x"], c["y"], c["h"][::-1], c["w"][::-1], c["s"], chunk=4)
+    assert np.array_equal(a, b[::-1])
+    c5 = wl.c5([3, 4, 5], n=200, m=33)
+    m1 = engine.batch_fit_predict(c5["x"], c5["y"], c5["h"], c5["w"] * 10, c5["s"], c5["xo"])
+    a2 = engine.logml_grid(c["x"], c["y"], c["h"], c["w"], c["s"], chunk=4)
+    assert np.array_equal(a, a2)
+    engine.trim()
+    m2 = engine.batch_fit_predict(c5["x"], c5["y"], c5["h"], c5["w"] * 10, c5["s"], c5["xo"])
+    for u, v in zip(m1, m2):
+        assert np.array_equal(u, v)
+    engine.trim()
+
+
 def test_plan_rerun_is_deterministic(engine):
     c = wl.c5([0, 1, 2], n=300, m=40)
     plan = engine.plan(3, 1, 300, 40)

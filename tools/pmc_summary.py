@@ -18,7 +18,7 @@ import pandas as pd
 def main():
     trace, pw, pf, tag = sys.argv[1:5]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    stats = glob.glob(os.path.join(trace, "*", "*_kernel_stats.csv"))[0]
+    stats = glob.glob(os.path.join(trace, "**", "*_kernel_stats.csv"), recursive=True)[0]
     shutil.copy(stats, os.path.join(root, "profiles", "%s_roofline_kernel_stats.csv" % tag))
     st = pd.read_csv(stats)
     out = {"_source": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate passes) of "
@@ -26,7 +26,7 @@ def main():
                       "fetch is RAW (no x2 wide-load correction: the GEMM loads 8 B/lane)",
            "kernels": {}}
     for path, name in ((pw, "WRITE_SIZE"), (pf, "FETCH_SIZE")):
-        f = glob.glob(os.path.join(path, "*", "*_counter_collection.csv"))[0]
+        f = glob.glob(os.path.join(path, "**", "*_counter_collection.csv"), recursive=True)[0]
         t = pd.read_csv(f)
         t = t[t.Counter_Name == name]
         t["short"] = t.Kernel_Name.str.extract(r"(\w+_kernel(?:<[^>]*>)?)")
@@ -42,7 +42,7 @@ def main():
             out["kernels"][r.short]["calls_in_trace"] = int(r.Calls)
     with open(os.path.join(root, "profiles", "%s_pmc_traffic.json" % tag), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
-    print(json.dumps(out["kernels"].get("gemm_sub_kernel<4, 4, 1>"), indent=1))
+    print(json.dumps(out["kernels"].get("gemm_lds_kernel"), indent=1))
     print(json.dumps(out["kernels"].get("gram_sym_kernel<2>"), indent=1))
 
 
