@@ -343,6 +343,14 @@ class Engine(object):
         self._check(self._lib.bq_probe_mfma_f64(self._ctx, C.cast(C.byref(v), _dp)))
         return float(v.value)
 
+    def probe_mfma_variant(self, kind, nacc=8, waves_per_simd=2):
+        """TFLOP/s of back-to-back independent MFMAs: kind 0 = v_mfma_f64_16x16x4_f64,
+        1 = v_mfma_f64_4x4x4_4b_f64."""
+        v = C.c_double()
+        self._check(self._lib.bq_probe_mfma_variant(self._ctx, int(kind), int(nacc),
+                                                    int(waves_per_simd), C.cast(C.byref(v), _dp)))
+        return v.value
+
     def probe_fma_f64(self):
         v = C.c_double()
         self._check(self._lib.bq_probe_fma_f64(self._ctx, C.cast(C.byref(v), _dp)))

@@ -455,6 +455,7 @@ def main():
         if dist.world == 1:
             try:
                 line["probes"] = {"mfma_f64_tflops": eng.probe_mfma_f64(),
+                                  "mfma_f64_4x4x4_4b_tflops": eng.probe_mfma_variant(1, 8, 2),
                                   "fma_f64_tflops": eng.probe_fma_f64()}
                 wgb, cgb = eng.probe_hbm(1 << 30)
                 line["probes"].update({"hbm_write_gbs": wgb, "hbm_copy_gbs": cgb})
