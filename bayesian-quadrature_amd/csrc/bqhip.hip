@@ -78,6 +78,7 @@ struct bq_ctx {
     hipEvent_t ev_panel = nullptr, ev_next = nullptr, ev_fork = nullptr;
     int lookahead = 1;
     int potf2_waves = 4; // 4: potf2_64x4_kernel, 1: potf2_64_kernel (BQ_POTF2_WAVES)
+    int trsm_blk = 1;    // MFMA panel solve from 16x16 block inverses (BQ_TRSM_BLK)
     int gemm_lds = 1;    // LDS-staged 128x128 trailing update (BQ_GEMM_LDS)
     int tile_order = 0;  // 2: XCD-aware super-tile order of the triangular tile list (BQ_TILE_ORDER)
     int mfma444 = 1;     // trailing / panel updates on v_mfma_f64_4x4x4_4b_f64 (BQ_MFMA444)
@@ -417,6 +418,20 @@ int launch_trsm(bq_ctx *c, double *X, long ldx, long xstride, int m, const doubl
     return BQ_OK;
 }
 
+// the MFMA panel solve (trsm_blk_kernel): needs the block inverses potf2_64x4_body leaves
+// behind the 64 reciprocal pivots
+int launch_trsm_blk(bq_ctx *c, double *X, long ldx, long xstride, int m, const double *L11,
+                    long ldl, long lstride, const double *dinv, long dstride, int batch)
+{
+    if (m <= 0)
+        return BQ_OK;
+    Bracket br(c, BQ_K_TRSM, 64.0 * 64 * (double)m * batch);
+    hipLaunchKernelGGL(trsm_blk_kernel, dim3((m + 63) / 64, 1, batch), dim3(256), 0, c->cur, X, ldx,
+                       xstride, m, L11, ldl, lstride, dinv, dstride);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
 int auto_nb(const bq_ctx *c, int ntot, int batch)
 {
     if (c->nb_override > 0)
@@ -446,20 +461,24 @@ int enqueue_panel(bq_ctx *c, double *A, long lda, long astride, int batch, int n
             const int fj = c->fuse ? j0 : -1;
             BQCHK(launch_gemm(c, BQ_K_GEMM, Ajj, lda, astride, A + j0 + (long)K0 * lda, lda,
                               astride, A + j0 + (long)K0 * lda, 1, lda, astride, ntot - j0, 64,
-                              j0 - K0, 0, batch, fj, dinv, 64, info));
+                              j0 - K0, 0, batch, fj, dinv, BQ_DINV_STRIDE, info));
             if (fj < 0)
-                BQCHK(launch_potf2(c, A, lda, astride, j0, dinv, 64, info, batch));
+                BQCHK(launch_potf2(c, A, lda, astride, j0, dinv, BQ_DINV_STRIDE, info, batch));
         } else if (!diag_done) {
-            BQCHK(launch_potf2(c, A, lda, astride, j0, dinv, 64, info, batch));
+            BQCHK(launch_potf2(c, A, lda, astride, j0, dinv, BQ_DINV_STRIDE, info, batch));
         }
-        BQCHK(launch_trsm<true>(c, Ajj + 64, lda, astride, ntot - j0 - 64, Ajj, lda, astride, dinv,
-                                64, batch));
+        if (c->trsm_blk && c->potf2_waves == 4)
+            BQCHK(launch_trsm_blk(c, Ajj + 64, lda, astride, ntot - j0 - 64, Ajj, lda, astride,
+                                  dinv, BQ_DINV_STRIDE, batch));
+        else
+            BQCHK(launch_trsm<true>(c, Ajj + 64, lda, astride, ntot - j0 - 64, Ajj, lda, astride,
+                                    dinv, BQ_DINV_STRIDE, batch));
     }
     return BQ_OK;
 }
 
 // Eliminate the first ncols columns (multiple of 64) of the ntot x ntot lower
-// matrix (ntot multiple of 64), batched.  dinv: 64 doubles per problem.
+// matrix (ntot multiple of 64), batched.  dinv: BQ_DINV_STRIDE doubles per problem.
 //
 // With more than one outer block and a wide block the factorisation runs with a
 // look-ahead of one panel on two streams.  The main stream carries only the bulk
@@ -491,7 +510,7 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
                                    : -1;
                 BQCHK(launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda,
                                   astride, P, 1, lda, astride, ntot - r0, ntot - r0, KB, 1, batch,
-                                  fj, dinv, 64, info));
+                                  fj, dinv, BQ_DINV_STRIDE, info));
                 diag_done = fj >= 0;
             }
         }
@@ -526,7 +545,8 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
             c->cur = c->aux;
             const int fj = c->fuse ? r0 : -1;
             st = launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda, astride,
-                             P, 1, lda, astride, ntot - r0, nw, KB, 1, batch, fj, dinv, 64, info);
+                             P, 1, lda, astride, ntot - r0, nw, KB, 1, batch, fj, dinv,
+                             BQ_DINV_STRIDE, info);
             if (st == BQ_OK)
                 st = enqueue_panel(c, A, lda, astride, batch, ntot, r0, nw, dinv, info, fj >= 0);
             c->cur = c->stream;
@@ -643,6 +663,8 @@ static int ctx_init(bq_ctx *c, int device)
                                   hipFuncAttributeMaxDynamicSharedMemorySize, BQ_LDS_BYTES));
     if (const char *e = std::getenv("BQ_LOOKAHEAD"))
         c->lookahead = std::atoi(e);
+    if (const char *e = std::getenv("BQ_TRSM_BLK"))
+        c->trsm_blk = std::atoi(e);
     if (const char *e = std::getenv("BQ_GEMM_LDS"))
         c->gemm_lds = std::atoi(e);
     if (const char *e = std::getenv("BQ_TILE_ORDER"))
@@ -928,9 +950,9 @@ extern "C" int bq_cho_factor(bq_ctx *c, const double *C, double *L, int64_t n, i
     int ntot;
     long lda;
     BQCHK(upload_padded(c, C, (int)n, A, ntot, lda));
-    HIPCHK(c, ws.alloc(64 * sizeof(double) + 64));
+    HIPCHK(c, ws.alloc(BQ_DINV_STRIDE * sizeof(double) + 64));
     double *dinv = ws.d();
-    int *info = reinterpret_cast<int *>(ws.d() + 64);
+    int *info = reinterpret_cast<int *>(ws.d() + BQ_DINV_STRIDE);
     HIPCHK(c, hipMemsetAsync(info, 0, sizeof(int), c->stream));
     BQCHK(enqueue_potrf_partial(c, A.d(), lda, 0, 1, ntot, ntot, dinv, info));
     int hinfo = 0;
@@ -1107,7 +1129,7 @@ extern "C" int bq_potrf_dev(bq_ctx *c, double *A_dev, int64_t n, int64_t lda, in
     if (!A_dev || !info_dev || n <= 0 || (n & 63) || lda < n || (lda & 1))
         return fail(c, BQ_ERR_BAD_ARG, "potrf_dev: n must be a positive multiple of 64, lda even");
     if (!c->dinv64.p)
-        HIPCHK(c, c->dinv64.alloc(64 * sizeof(double)));
+        HIPCHK(c, c->dinv64.alloc(BQ_DINV_STRIDE * sizeof(double)));
     HIPCHK(c, hipMemsetAsync(info_dev, 0, sizeof(int32_t), c->stream));
     return enqueue_potrf_partial(c, A_dev, lda, 0, 1, (int)n, (int)n, c->dinv64.d(), info_dev);
 }
@@ -1174,7 +1196,7 @@ extern "C" int bq_plan_create(bq_ctx *c, int64_t nprob, int64_t d, int64_t n, in
     A(p->pts, sizeof(double) * (size_t)d * p->L.ntot * nprob);
     A(p->y, sizeof(double) * (size_t)p->L.npad * nprob);
     A(p->gp, sizeof(GaussParams) * (size_t)nprob);
-    A(p->dinv, sizeof(double) * 64 * (size_t)nprob);
+    A(p->dinv, sizeof(double) * BQ_DINV_STRIDE * (size_t)nprob);
     A(p->info, sizeof(int) * (size_t)nprob);
     A(p->scal, sizeof(double) * 4 * (size_t)nprob);
     A(p->mean, sizeof(double) * (size_t)std::max<int64_t>(M, 1) * nprob);
@@ -1331,14 +1353,14 @@ extern "C" int bq_plan_run(bq_ctx *c, bq_plan *p)
         return plan_enqueue(c, p);
     // settings that change the launch sequence invalidate the captured graph
     if (p->graph_state == 1 && (p->graph_nb != c->nb_override || p->graph_la != c->lookahead ||
-                                p->graph_pw != c->potf2_waves * 4 + c->fuse * 2 + c->mfma444)) {
+                                p->graph_pw != c->potf2_waves * 16 + c->trsm_blk * 8 + c->gemm_lds * 4 + c->fuse * 2 + c->mfma444)) {
         plan_drop_graph(p);
         p->graph_state = 0;
     }
     if (p->graph_state == 0) {
         p->graph_nb = c->nb_override;
         p->graph_la = c->lookahead;
-        p->graph_pw = c->potf2_waves * 4 + c->fuse * 2 + c->mfma444;
+        p->graph_pw = c->potf2_waves * 16 + c->trsm_blk * 8 + c->gemm_lds * 4 + c->fuse * 2 + c->mfma444;
         p->graph_state = -1;
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
             const int st = plan_enqueue(c, p);
@@ -1515,7 +1537,7 @@ struct bq_fit {
     DevBuf pts;   // d x ntot
     DevBuf y;     // npad
     DevBuf gp;    // GaussParams
-    DevBuf dinv;  // npad reciprocal diagonal (+64 scratch for the factorisation)
+    DevBuf dinv;  // npad reciprocal diagonal (+ BQ_DINV_STRIDE scratch for the factorisation)
     DevBuf misc;  // info (int) + scal[4]
     DevBuf alpha; // npad, valid if have_alpha
     bool have_alpha = false;
@@ -1612,7 +1634,7 @@ extern "C" int bq_gp_fit(bq_ctx *c, const double *x, const double *y, int64_t d,
     A(f->pts, sizeof(double) * (size_t)d * f->L.ntot);
     A(f->y, sizeof(double) * (size_t)f->npad);
     A(f->gp, sizeof(GaussParams));
-    A(f->dinv, sizeof(double) * ((size_t)f->npad + 64));
+    A(f->dinv, sizeof(double) * ((size_t)f->npad + BQ_DINV_STRIDE));
     A(f->misc, sizeof(double) * 8);
     A(f->alpha, sizeof(double) * (size_t)f->npad);
     if (e != hipSuccess) {

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C
                                                           double *__restrict__ dinv, long dstride,
                                                           int *__restrict__ info)
 {
-    __shared__ __attribute__((aligned(16))) double ring[3 * 4 * 64];
+    __shared__ __attribute__((aligned(16))) double ring[4 * 4 * 64 + 64]; // three panel slots; then the four 16x16 blocks + 64 pivots
     __shared__ int sbad[4];
     // the small-tile forms are the panel's own updates: on the look-ahead stream they share
     // CUs with the bulk trailing update and sit on the critical path, so they issue first
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void gemm_k64_kernel(double *__restrict__ C, l
                                                        double *__restrict__ dinv, long dstride,
                                                        int *__restrict__ info)
 {
-    __shared__ __attribute__((aligned(16))) double ring[3 * 4 * 64];
+    __shared__ __attribute__((aligned(16))) double ring[4 * 4 * 64 + 64]; // three panel slots; then the four 16x16 blocks + 64 pivots
     __shared__ int sbad[4];
     __builtin_amdgcn_s_setprio(3); // panel-internal update: see gemm_sub_kernel
     const int b = blockIdx.z;

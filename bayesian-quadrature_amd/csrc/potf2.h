@@ -274,6 +274,43 @@ __device__ __forceinline__ void potf2_64x4_body(double *__restrict__ Ab, long ld
         if (first != 0 && info_b[0] == 0)
             info_b[0] = first;
     }
+    // W_b = L_bb^-1 of the four 16 x 16 diagonal sub-blocks, for the MFMA panel solve
+    // (trsm_blk_kernel).  Every wave drops its columns of the four blocks (and its
+    // reciprocal pivots) into LDS straight from registers -- the ring is free now --, then
+    // wave w inverts block w: lane j < 16 runs the forward substitution of unit column j,
+    // every L entry a broadcast LDS read, four partial sums per row.  About a microsecond,
+    // instead of 64 dependent column steps in every workgroup of the panel solve.
+    {
+        // blk[b][i + 16 k] = L[16 b + i][16 b + k]; my columns: k = 4 w + s of every block
+        const int bq = lane >> 4, i16 = lane & 15;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int sc = 0; sc < 4; ++sc)
+                if (bq == q)
+                    ring[256 * q + i16 + 16 * (4 * w + sc)] = st.a[q][sc];
+        double *rd = ring + 1024; // 64 reciprocal pivots
+        if (((lane >> 2) & 3) == w)
+            rd[lane] = st.myr;
+        __syncthreads();
+        if (lane < 16) {
+            const double *blk = ring + 256 * w;
+            double wc[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                double sacc[4] = {(i == lane) ? 1.0 : 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < i; ++k)
+                    sacc[k & 3] -= blk[i + 16 * k] * wc[k];
+                // rows above the column's own are exactly zero (all partial sums are)
+                wc[i] = ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) * rd[16 * w + i];
+            }
+            double *Wb = dinv_b + 64 + 256 * w + 16 * lane;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                Wb[i] = wc[i];
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void potf2_64x4_kernel(double *__restrict__ A, long lda,
@@ -281,7 +318,7 @@ __global__ __launch_bounds__(256) void potf2_64x4_kernel(double *__restrict__ A,
                                                          double *__restrict__ dinv, long dstride,
                                                          int *__restrict__ info)
 {
-    __shared__ __attribute__((aligned(16))) double ring[3 * 4 * 64];
+    __shared__ __attribute__((aligned(16))) double ring[4 * 4 * 64 + 64]; // three panel slots; then the four 16x16 blocks + 64 pivots
     __shared__ int sbad[4];
     __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.z;

@@ -282,6 +282,75 @@ __global__ __launch_bounds__(64) void trsm_quad_kernel(double *__restrict__ X, l
     }
 }
 
+// ---------------------------------------------------------------------------
+// Panel solve on the matrix cores: X (m x 64) <- X L11^-T in four 16-column block steps,
+//   X_c = (A_c - sum_{b<c} X_b L_cb^T) W_cc^T,   W_cc = L_cc^-1 (from potf2_64x4_body),
+// instead of 64 dependent column steps.  A wave owns 16 rows and works on transposes, so
+// that every intermediate stays in MFMA operand form: with D = A B on
+// v_mfma_f64_16x16x4_f64, register r of the D tile IS the B fragment of k-step r, so
+// X_b^T (a D tile) feeds T_c^T -= L_cb X_b^T and X_c^T = W_cc T_c^T directly; L_cb and W_cc
+// are A fragments read from global memory (lane l: row l & 15, k = (l >> 4) + 4 r).
+// 40 MFMAs per wave.  m is a multiple of 16.  The inverse of a 16 x 16 diagonal block of
+// a Cholesky factor is as well conditioned as the block (MAGMA's trtri-based trsm does
+// the same with 128-wide blocks); the parity bars of tests/test_gpu_parity.py hold.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void trsm_blk_kernel(double *__restrict__ X, long ldx,
+                                                       long xstride, int m,
+                                                       const double *__restrict__ Lm, long ldl,
+                                                       long lstride,
+                                                       const double *__restrict__ dinv,
+                                                       long dstride)
+{
+    __builtin_amdgcn_s_setprio(3);
+    const int b = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * 64 + wave * 16;
+    if (row0 >= m)
+        return;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double *Xr = X + (long)b * xstride + row0 + l15 + (long)l4 * ldx;
+    const double *L11 = Lm + (long)b * lstride + l15 + (long)l4 * ldl;
+    const double *W = dinv + (long)b * dstride + 64 + l15 + 16 * l4;
+    // t[c][r] = X[row0 + l15][16 c + l4 + 4 r]: B fragments of the transposed row block
+    double t[4][4], w[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            t[c][r] = Xr[(long)(16 * c + 4 * r) * ldx];
+            w[c][r] = W[256 * c + 64 * r]; // W_c[l15][l4 + 4 r]
+        }
+    // la[c][b][r] = L11[16 c + l15][16 b + l4 + 4 r], c > b
+    double la[4][3][4];
+#pragma unroll
+    for (int c = 1; c < 4; ++c)
+#pragma unroll
+        for (int bb = 0; bb < c; ++bb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                la[c][bb][r] = L11[16 * c + (long)(16 * bb + 4 * r) * ldl];
+    double4_t x[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        // acc = sum_b L_cb X_b^T - T_c^T
+        double4_t acc = {-t[c][0], -t[c][1], -t[c][2], -t[c][3]};
+#pragma unroll
+        for (int bb = 0; bb < c; ++bb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(la[c][bb][r], x[bb][r], acc, 0, 0, 0);
+        // X_c^T = -W_cc acc
+        double4_t xc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            xc = __builtin_amdgcn_mfma_f64_16x16x4f64(-w[c][r], acc[r], xc, 0, 0, 0);
+        x[c] = xc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            Xr[(long)(16 * c + 4 * r) * ldx] = xc[r];
+    }
+}
+
 // reciprocal diagonal of a resident factor: dinv[j] = 1 / L[j0+j, j0+j]
 __global__ void diag_recip_kernel(const double *__restrict__ Lm, long ldl, long lstride, int n,
                                   double *__restrict__ dinv, long dstride)
