@@ -1434,6 +1434,10 @@ extern "C" int bq_batch_fit_predict(bq_ctx *c, int64_t nprob, const double *x, c
     HIPCHK(c, hipMemGetInfo(&freeb, &totalb));
     int64_t chunk = std::max<int64_t>(1, (int64_t)((freeb / 2) / per));
     chunk = std::min<int64_t>(chunk, nprob);
+    // free memory was read with the cached workspace still allocated: keep its size
+    if (const bq_plan *q = c->plan_cache)
+        if (q->d == d && q->n == n && q->M == M && q->nprob <= nprob && q->nprob >= chunk)
+            chunk = q->nprob;
     bq_plan *p = nullptr, *big = nullptr;
     BQCHK(plan_acquire(c, chunk, d, n, M, &p));
     big = p;
@@ -1493,6 +1497,9 @@ extern "C" int bq_gp_logml_grid(bq_ctx *c, const double *x, const double *y, int
         chunk = std::max<int64_t>(1, (int64_t)((freeb / 2) / per));
     }
     chunk = std::min<int64_t>(chunk, G);
+    if (const bq_plan *q = c->plan_cache)
+        if (q->d == d && q->n == n && q->M == 0 && q->nprob <= G && q->nprob >= chunk)
+            chunk = q->nprob;
     bq_plan *p = nullptr, *big = nullptr;
     BQCHK(plan_acquire(c, chunk, d, n, 0, &p));
     big = p;

@@ -356,6 +356,73 @@ def test_c4_size_cholesky_property(engine):
     assert np.allclose(K[i, j], ref, rtol=1e-13, atol=0)
 
 
+def _potrf_dev(eng, x, c, n, nb=0, la=True):
+    """Gram + potrf of the C4-style system of size n on device-resident data -> (K, L)."""
+    from bayesian_quadrature_amd import _lib as L_
+    lib, ctx = eng._lib, eng._ctx
+    w = np.ascontiguousarray(c["w"])
+    xd, Kd, info = eng.alloc(8 * n), eng.alloc(8 * n * n), eng.alloc(64)
+    try:
+        eng.upload(xd, x)
+        eng.set_block(nb)
+        eng.set_lookahead(la)
+        eng._check(lib.bq_gram_gauss_dev(ctx, xd, 1, n, c["h"], L_.dptr(w), c["s"], Kd, n))
+        K = np.empty((n, n), order="F")
+        eng.download(K, Kd)
+        eng._check(lib.bq_potrf_dev(ctx, Kd, n, n, info))
+        Lf = np.empty((n, n), order="F")
+        eng.download(Lf, Kd)
+        hinfo = np.zeros(1, dtype=np.int32)
+        eng.download(hinfo, info)
+        assert hinfo[0] == 0
+    finally:
+        eng.set_block(0)
+        eng.set_lookahead(True)
+        eng.free(xd), eng.free(Kd), eng.free(info)
+    return K, np.tril(Lf)
+
+
+@pytest.mark.parametrize("env,nb,la", [
+    ({}, 0, True),                       # shipped: LDS-staged update, MFMA panel solve
+    ({}, 128, False),                    # k = 128 chunks, sequential launches
+    ({}, 512, True),                     # k = 512
+    ({}, 192, True),                     # k = 192: not a multiple of 32 x 4 -> both kernels
+    ({"BQ_GEMM_LDS": "0"}, 0, True),     # register-streaming four-block MFMA kernel
+    ({"BQ_TILE_ORDER": "2"}, 0, False),  # XCD-aware super-tile order
+    ({"BQ_TRSM_BLK": "0"}, 0, True),     # column-by-column panel solve
+    ({"BQ_MFMA444": "0"}, 256, False),   # v_mfma_f64_16x16x4_f64 kernel
+    ({"BQ_FUSE": "0"}, 0, True),         # no fused diagonal factor
+])
+def test_trailing_update_variants_agree(engine, env, nb, la):
+    """Every kernel variant of the factorisation (selected by the developer switches a
+    context reads when it is created) gives the same factor of an N = 4480 system -- a
+    size that is a multiple of 64 but not of 128, large enough for the 128 x 128 tiles."""
+    import os
+    from bayesian_quadrature_amd import Engine
+    n = 4480
+    c = wl.c4(n)
+    x = np.ascontiguousarray(c["x"])
+    K, Lref = _potrf_dev(engine, x, c, n)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        eng = Engine(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        K2, L2 = _potrf_dev(eng, x, c, n, nb, la)
+    finally:
+        eng.close()
+    assert np.array_equal(K, K2)
+    assert _resid(K, L2, np.random.RandomState(3), nvec=2) < 1e-14 * n
+    # the variants differ only in summation order
+    assert np.max(np.abs(L2 - Lref)) <= 1e-11 * np.max(np.abs(Lref))
+
+
 # ---- closed-form integrals and BQ moments on the device (SURVEY.md section 8f row 1) ------
 MU1, COV1 = np.array([0.3]), np.array([[10.0]])
 
