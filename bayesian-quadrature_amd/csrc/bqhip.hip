@@ -823,6 +823,14 @@ extern "C" int bq_set_lookahead(bq_ctx *c, int on)
     return BQ_OK;
 }
 
+extern "C" int bq_set_lookahead_rows(bq_ctx *c, int min_rows)
+{
+    if (!c || min_rows < 0)
+        return c ? fail(c, BQ_ERR_BAD_ARG, "min_rows must be >= 0") : BQ_ERR_BAD_ARG;
+    c->la_min = min_rows;
+    return BQ_OK;
+}
+
 // ===========================================================================
 // memory, timers, profiling
 // ===========================================================================

@@ -93,8 +93,12 @@ class Engine(object):
     def set_block(self, nb):
         self._check(self._lib.bq_set_block(self._ctx, int(nb)))
 
-    def set_lookahead(self, on):
+    def set_lookahead(self, on, min_rows=None):
+        """Look-ahead on / off; min_rows: rows of the bulk update below which the sweep goes
+        sequential (None keeps the current setting, 0 = look-ahead to the end)."""
         self._check(self._lib.bq_set_lookahead(self._ctx, 1 if on else 0))
+        if min_rows is not None:
+            self._check(self._lib.bq_set_lookahead_rows(self._ctx, int(min_rows)))
 
     def trim(self):
         """Release the workspace the batched calls keep between calls."""

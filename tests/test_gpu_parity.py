@@ -392,6 +392,8 @@ def _potrf_dev(eng, x, c, n, nb=0, la=True):
     ({"BQ_TRSM_BLK": "0"}, 0, True),     # column-by-column panel solve
     ({"BQ_MFMA444": "0"}, 256, False),   # v_mfma_f64_16x16x4_f64 kernel
     ({"BQ_FUSE": "0"}, 0, True),         # no fused diagonal factor
+    ({"BQ_LA_MIN": "0"}, 0, True),       # look-ahead to the last panel (no hand-over)
+    ({"BQ_LA_MIN": "0"}, 128, True),
 ])
 def test_trailing_update_variants_agree(engine, env, nb, la):
     """Every kernel variant of the factorisation (selected by the developer switches a

@@ -36,7 +36,7 @@ def test_random_shapes(engine, oracle, seed):
             n = int(rs.randint(1, 700))
             M = int(rs.randint(1, 200))
             engine.set_block(int(rs.choice([0, 64, 128, 256])))
-            engine.set_lookahead(bool(rs.randint(0, 2)))
+            engine.set_lookahead(bool(rs.randint(0, 2)), min_rows=int(rs.choice([0, 256, 4096])))
             x, y, xo, h, w, s = _case(rs, n, M, d)
             n = x.shape[1]
             mean, var, logml = engine.fit_predict(x, y, h, w, s, xo)
@@ -48,7 +48,7 @@ def test_random_shapes(engine, oracle, seed):
             assert abs(logml - lmo) <= RTOL * abs(lmo), (d, n, M)
     finally:
         engine.set_block(0)
-        engine.set_lookahead(True)
+        engine.set_lookahead(True, min_rows=4096)
 
 
 @pytest.mark.parametrize("nb,la", [(0, True), (128, True), (256, False), (64, True)])
@@ -60,12 +60,12 @@ def test_batch_through_lookahead_path(engine, oracle, nb, la):
     w = c["w"] * 1.2
     try:
         engine.set_block(nb)
-        engine.set_lookahead(la)
+        engine.set_lookahead(la, min_rows=0)
         mean, var, logml, status = engine.batch_fit_predict(c["x"], c["y"], c["h"], w, c["s"],
                                                             c["xo"])
     finally:
         engine.set_block(0)
-        engine.set_lookahead(True)
+        engine.set_lookahead(True, min_rows=4096)
     assert (status == 0).all()
     k0 = oracle.kernel_scale(1, c["h"], w)
     for p in (0, 5, 11):
