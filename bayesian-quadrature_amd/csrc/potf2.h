@@ -168,13 +168,17 @@ __device__ __forceinline__ void potf2w_factor(Potf2W &st, double *slot, int lane
             st.bad = j0 + c + 1;
         double r, sq;
         rsqrt_sqrt_f64(d, r, sq);
-        const double l = (lane == c) ? sq : st.a[QP][s] * r;
-        st.a[QP][s] = l;
+        // the multipliers need only r; the refined square root (three more dependent
+        // operations) goes to the diagonal entry alone, off the pivot chain -- row c of the
+        // later columns is above the diagonal and never read
+        const double l = st.a[QP][s] * r;
         st.myr = (lane == c) ? r : st.myr;
 #pragma unroll
         for (int s2 = s + 1; s2 < 4; ++s2)
             st.a[QP][s2] -= l * readlane_f64(l, 4 * P + s2);
-        slot[s * 64 + lane] = l;
+        const double lf = (lane == c) ? sq : l;
+        st.a[QP][s] = lf;
+        slot[s * 64 + lane] = lf;
     }
 }
 
@@ -248,6 +252,30 @@ __device__ __forceinline__ void potf2_64x4_body(double *__restrict__ Ab, long ld
     if (w == 0)
         potf2w_factor<0>(st, ring, lane, j0);
     Potf2WSteps<0>::run(st, ring, w, lane, j0);
+    // W_b = L_bb^-1 of the four 16 x 16 diagonal sub-blocks, for the MFMA panel solve
+    // (trsm_blk_kernel).  Every wave drops its columns of the four blocks (and its
+    // reciprocal pivots) into LDS straight from registers -- the ring is free now --, then
+    // wave w inverts block w: lane j < 16 runs the forward substitution of unit column j,
+    // every L entry a broadcast LDS read, four partial sums per row (about a microsecond,
+    // instead of 64 dependent column steps in every workgroup of the panel solve).  All of
+    // this comes BEFORE the write-back of the factor: the barrier would otherwise wait for
+    // those 64 stores per lane to be acknowledged (measured: 3 us per launch).
+    double *rd = ring + 1024; // 64 reciprocal pivots
+    {
+        // blk[b][i + 16 k] = L[16 b + i][16 b + k]; my columns: k = 4 w + s of every block
+        const int bq = lane >> 4, i16 = lane & 15;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int sc = 0; sc < 4; ++sc)
+                if (bq == q)
+                    ring[256 * q + i16 + 16 * (4 * w + sc)] = st.a[q][sc];
+        if (((lane >> 2) & 3) == w)
+            rd[lane] = st.myr;
+        if (lane == 0)
+            sbad[w] = st.bad;
+    }
+    __syncthreads();
     // write back the lower triangle of my columns, and my reciprocal pivots
     {
         double *pw = Ab + lane + (long)(4 * w) * lda;
@@ -263,9 +291,7 @@ __device__ __forceinline__ void potf2_64x4_body(double *__restrict__ Ab, long ld
     }
     if (((lane >> 2) & 3) == w)
         dinv_b[lane] = st.myr;
-    if (lane == 0)
-        sbad[w] = st.bad;
-    __syncthreads();
+    // (the stores above drain while the inverses are computed)
     if (threadIdx.x == 0) {
         int first = 0;
         for (int k = 0; k < 4; ++k)
@@ -274,42 +300,22 @@ __device__ __forceinline__ void potf2_64x4_body(double *__restrict__ Ab, long ld
         if (first != 0 && info_b[0] == 0)
             info_b[0] = first;
     }
-    // W_b = L_bb^-1 of the four 16 x 16 diagonal sub-blocks, for the MFMA panel solve
-    // (trsm_blk_kernel).  Every wave drops its columns of the four blocks (and its
-    // reciprocal pivots) into LDS straight from registers -- the ring is free now --, then
-    // wave w inverts block w: lane j < 16 runs the forward substitution of unit column j,
-    // every L entry a broadcast LDS read, four partial sums per row.  About a microsecond,
-    // instead of 64 dependent column steps in every workgroup of the panel solve.
-    {
-        // blk[b][i + 16 k] = L[16 b + i][16 b + k]; my columns: k = 4 w + s of every block
-        const int bq = lane >> 4, i16 = lane & 15;
+    if (lane < 16) {
+        const double *blk = ring + 256 * w;
+        double wc[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int i = 0; i < 16; ++i) {
+            double sacc[4] = {(i == lane) ? 1.0 : 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int sc = 0; sc < 4; ++sc)
-                if (bq == q)
-                    ring[256 * q + i16 + 16 * (4 * w + sc)] = st.a[q][sc];
-        double *rd = ring + 1024; // 64 reciprocal pivots
-        if (((lane >> 2) & 3) == w)
-            rd[lane] = st.myr;
-        __syncthreads();
-        if (lane < 16) {
-            const double *blk = ring + 256 * w;
-            double wc[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                double sacc[4] = {(i == lane) ? 1.0 : 0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int k = 0; k < i; ++k)
-                    sacc[k & 3] -= blk[i + 16 * k] * wc[k];
-                // rows above the column's own are exactly zero (all partial sums are)
-                wc[i] = ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) * rd[16 * w + i];
-            }
-            double *Wb = dinv_b + 64 + 256 * w + 16 * lane;
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                Wb[i] = wc[i];
+            for (int k = 0; k < i; ++k)
+                sacc[k & 3] -= blk[i + 16 * k] * wc[k];
+            // rows above the column's own are exactly zero (all partial sums are)
+            wc[i] = ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) * rd[16 * w + i];
         }
+        double *Wb = dinv_b + 64 + 256 * w + 16 * lane;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            Wb[i] = wc[i];
     }
 }
 
