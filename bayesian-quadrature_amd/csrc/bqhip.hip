@@ -79,6 +79,8 @@ struct bq_ctx {
     int lookahead = 1;
     int potf2_waves = 4; // 4: potf2_64x4_kernel, 1: potf2_64_kernel (BQ_POTF2_WAVES)
     int la_min = 4096;   // look-ahead only while the bulk update has at least this many rows (BQ_LA_MIN)
+    int slab_fuse = 1;   // one launch per 64-column step of small systems (BQ_SLAB)
+    DevBuf panel_ws;     // scratch panel columns of the eager linalg entry points
     int trsm_blk = 1;    // MFMA panel solve from 16x16 block inverses (BQ_TRSM_BLK)
     int gemm_lds = 1;    // LDS-staged 128x128 trailing update (BQ_GEMM_LDS)
     int tile_order = 0;  // 2: XCD-aware super-tile order of the triangular tile list (BQ_TILE_ORDER)
@@ -489,12 +491,53 @@ int enqueue_panel(bq_ctx *c, double *A, long lda, long astride, int batch, int n
 // panel meanwhile.  The two meet through events: update k+1 waits for panel k+1,
 // the panel-column update k+1 waits for trailing update k (which last wrote
 // those columns).
+// doubles of scratch the one-launch slab sweep needs (two panel columns per problem)
+size_t panel_ws_doubles(int ntot, int batch) { return (size_t)2 * 64 * ntot * batch; }
+
+// Outer block 64 (small systems): one launch per 64-column step (slab.h) after the first
+// diagonal factor and the staging of panel 0.
+int enqueue_slab_sweep(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
+                       int ncols, double *dinv, int *info, double *ws)
+{
+    BQCHK(launch_potf2(c, A, lda, astride, 0, dinv, BQ_DINV_STRIDE, info, batch));
+    if (ntot <= 64)
+        return BQ_OK;
+    const long sstride = 64L * ntot;
+    double *S[2] = {ws, ws + sstride * batch};
+    {
+        Bracket br(c, BQ_K_REDUCE);
+        hipLaunchKernelGGL(slab_stage_kernel, dim3((ntot - 64 + 255) / 256, 64, batch), dim3(256),
+                           0, c->cur, A, lda, astride, S[0], (long)ntot, sstride, ntot, 0);
+        HIPCHK(c, hipGetLastError());
+    }
+    for (int j0 = 0, par = 0; j0 < ncols; j0 += 64, par ^= 1) {
+        const int r0 = j0 + 64;
+        if (r0 >= ntot)
+            break;
+        const int T = (ntot - r0) / 64;
+        const int fnext = r0 < ncols;
+        const double m = (double)(ntot - r0);
+        // the tile updates (lower half of 2 m^2 64) and the solve of the panel (m 64^2)
+        Bracket br(c, BQ_K_SYRK_SMALL, (m * m * 64.0 + m * 64.0 * 64.0) * batch);
+        hipLaunchKernelGGL(slab_step_kernel, dim3(T * (T + 1) / 2, 1, batch), dim3(256), 0, c->cur,
+                           A, lda, astride, S[par], S[par ^ 1], (long)ntot, sstride, ntot, j0,
+                           dinv + par * BQ_DINV_HALF, dinv + (par ^ 1) * BQ_DINV_HALF,
+                           (long)BQ_DINV_STRIDE, fnext, !fnext, info);
+        HIPCHK(c, hipGetLastError());
+    }
+    return BQ_OK;
+}
+
 int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
-                          int ncols, double *dinv, int *info)
+                          int ncols, double *dinv, int *info, double *panel_ws = nullptr,
+                          size_t panel_ws_len = 0)
 {
     if ((ntot & 63) || (ncols & 63) || ncols > ntot)
         return fail(c, BQ_ERR_BAD_ARG, "potrf: sizes must be multiples of 64");
     const int NB = auto_nb(c, ntot, batch);
+    if (NB == 64 && c->slab_fuse && c->trsm_blk && c->potf2_waves == 4 && panel_ws &&
+        panel_ws_len >= panel_ws_doubles(ntot, batch) && ncols >= 64)
+        return enqueue_slab_sweep(c, A, lda, astride, batch, ntot, ncols, dinv, info, panel_ws);
     const bool la = c->lookahead && c->aux && NB >= 128 && ncols > NB;
     int K0 = 0;
     bool panel_done = false; // panel K0 was already factored by the look-ahead phase
@@ -685,6 +728,8 @@ static int ctx_init(bq_ctx *c, int device)
         c->lookahead = std::atoi(e);
     if (const char *e = std::getenv("BQ_LA_MIN"))
         c->la_min = std::atoi(e);
+    if (const char *e = std::getenv("BQ_SLAB"))
+        c->slab_fuse = std::atoi(e);
     if (const char *e = std::getenv("BQ_TRSM_BLK"))
         c->trsm_blk = std::atoi(e);
     if (const char *e = std::getenv("BQ_GEMM_LDS"))
@@ -984,7 +1029,10 @@ extern "C" int bq_cho_factor(bq_ctx *c, const double *C, double *L, int64_t n, i
     double *dinv = ws.d();
     int *info = reinterpret_cast<int *>(ws.d() + BQ_DINV_STRIDE);
     HIPCHK(c, hipMemsetAsync(info, 0, sizeof(int), c->stream));
-    BQCHK(enqueue_potrf_partial(c, A.d(), lda, 0, 1, ntot, ntot, dinv, info));
+    if (c->panel_ws.bytes < sizeof(double) * panel_ws_doubles(ntot, 1))
+        HIPCHK(c, c->panel_ws.alloc(sizeof(double) * panel_ws_doubles(ntot, 1)));
+    BQCHK(enqueue_potrf_partial(c, A.d(), lda, 0, 1, ntot, ntot, dinv, info, c->panel_ws.d(),
+                                c->panel_ws.bytes / sizeof(double)));
     int hinfo = 0;
     HIPCHK(c, hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1172,6 +1220,7 @@ struct bq_plan {
     Layout L{};
     long lda = 0, astride = 0;
     DevBuf A, pts, y, gp, dinv, info, scal, mean, var;
+    DevBuf panel; // scratch panel columns of the one-launch slab sweep (small systems)
     std::vector<GaussParams> hgp;
     bool has_inputs = false;
     // the launch sequence of a plan is static: it is captured once into a hipGraph
@@ -1227,6 +1276,7 @@ extern "C" int bq_plan_create(bq_ctx *c, int64_t nprob, int64_t d, int64_t n, in
     A(p->y, sizeof(double) * (size_t)p->L.npad * nprob);
     A(p->gp, sizeof(GaussParams) * (size_t)nprob);
     A(p->dinv, sizeof(double) * BQ_DINV_STRIDE * (size_t)nprob);
+    A(p->panel, sizeof(double) * panel_ws_doubles(p->L.ntot, (int)nprob));
     A(p->info, sizeof(int) * (size_t)nprob);
     A(p->scal, sizeof(double) * 4 * (size_t)nprob);
     A(p->mean, sizeof(double) * (size_t)std::max<int64_t>(M, 1) * nprob);
@@ -1305,7 +1355,7 @@ extern "C" int bq_plan_bytes(bq_plan *p, size_t *bytes)
     if (!p || !bytes)
         return BQ_ERR_BAD_ARG;
     *bytes = p->A.bytes + p->pts.bytes + p->y.bytes + p->gp.bytes + p->dinv.bytes +
-             p->info.bytes + p->scal.bytes + p->mean.bytes + p->var.bytes;
+             p->info.bytes + p->scal.bytes + p->mean.bytes + p->var.bytes + p->panel.bytes;
     return BQ_OK;
 }
 
@@ -1350,7 +1400,8 @@ int plan_enqueue(bq_ctx *c, bq_plan *p)
                           static_cast<GaussParams *>(p->gp.p), 1, p->A.d(), p->lda, p->astride,
                           p->L, p->nprob));
     BQCHK(enqueue_potrf_partial(c, p->A.d(), p->lda, p->astride, p->nprob, p->L.ntot, p->L.npad,
-                                p->dinv.d(), p->info.i()));
+                                p->dinv.d(), p->info.i(), p->panel.d(),
+                                p->panel.bytes / sizeof(double)));
     {
         Bracket br(c, BQ_K_REDUCE, 8.0 * (p->n + 2.0 * p->M) * p->nprob);
         hipLaunchKernelGGL(finalize_kernel, dim3(1, 1, p->nprob), dim3(256), 0, c->stream,
@@ -1383,14 +1434,14 @@ extern "C" int bq_plan_run(bq_ctx *c, bq_plan *p)
         return plan_enqueue(c, p);
     // settings that change the launch sequence invalidate the captured graph
     if (p->graph_state == 1 && (p->graph_nb != c->nb_override || p->graph_la != c->lookahead ||
-                                p->graph_pw != c->la_min * 32 + c->potf2_waves * 16 + c->trsm_blk * 8 + c->gemm_lds * 4 + c->fuse * 2 + c->mfma444)) {
+                                p->graph_pw != c->la_min * 64 + c->slab_fuse * 32 + c->potf2_waves * 16 + c->trsm_blk * 8 + c->gemm_lds * 4 + c->fuse * 2 + c->mfma444)) {
         plan_drop_graph(p);
         p->graph_state = 0;
     }
     if (p->graph_state == 0) {
         p->graph_nb = c->nb_override;
         p->graph_la = c->lookahead;
-        p->graph_pw = c->la_min * 32 + c->potf2_waves * 16 + c->trsm_blk * 8 + c->gemm_lds * 4 + c->fuse * 2 + c->mfma444;
+        p->graph_pw = c->la_min * 64 + c->slab_fuse * 32 + c->potf2_waves * 16 + c->trsm_blk * 8 + c->gemm_lds * 4 + c->fuse * 2 + c->mfma444;
         p->graph_state = -1;
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
             const int st = plan_enqueue(c, p);
@@ -1575,6 +1626,7 @@ struct bq_fit {
     DevBuf y;     // npad
     DevBuf gp;    // GaussParams
     DevBuf dinv;  // npad reciprocal diagonal (+ BQ_DINV_STRIDE scratch for the factorisation)
+    DevBuf panel; // scratch panel columns of the one-launch slab sweep
     DevBuf misc;  // info (int) + scal[4]
     DevBuf alpha; // npad, valid if have_alpha
     bool have_alpha = false;
@@ -1593,7 +1645,8 @@ int fit_factor(bq_ctx *c, bq_fit *f)
     BQCHK(launch_assemble(c, f->d, f->pts.d(), 0, f->y.d(), 0, static_cast<GaussParams *>(f->gp.p),
                           0, f->A.d(), f->ldl, 0, f->L, 1));
     double *scratch = f->dinv.d() + f->npad;
-    BQCHK(enqueue_potrf_partial(c, f->A.d(), f->ldl, 0, 1, ntot, f->npad, scratch, info));
+    BQCHK(enqueue_potrf_partial(c, f->A.d(), f->ldl, 0, 1, ntot, f->npad, scratch, info,
+                                f->panel.d(), f->panel.bytes / sizeof(double)));
     {
         Bracket br(c, BQ_K_REDUCE);
         hipLaunchKernelGGL(finalize_kernel, dim3(1, 1, 1), dim3(256), 0, c->stream, f->A.d(),
@@ -1672,6 +1725,7 @@ extern "C" int bq_gp_fit(bq_ctx *c, const double *x, const double *y, int64_t d,
     A(f->y, sizeof(double) * (size_t)f->npad);
     A(f->gp, sizeof(GaussParams));
     A(f->dinv, sizeof(double) * ((size_t)f->npad + BQ_DINV_STRIDE));
+    A(f->panel, sizeof(double) * panel_ws_doubles(f->L.ntot, 1));
     A(f->misc, sizeof(double) * 8);
     A(f->alpha, sizeof(double) * (size_t)f->npad);
     if (e != hipSuccess) {
