@@ -235,9 +235,12 @@ struct Potf2WSteps<16> {
 // The factorisation proper, callable by any 256-thread workgroup: Ab points at
 // the 64x64 block (leading dimension lda), j0 is its global column (for the
 // failure report), dinv_b / info_b belong to this batch element.
+// src / lsrc: where the block is read from when it is not in place (the slab step hands it
+// over in LDS); the factor always goes to Ab.
 __device__ __forceinline__ void potf2_64x4_body(double *__restrict__ Ab, long lda, int j0,
                                                 double *__restrict__ dinv_b,
-                                                int *__restrict__ info_b, double *ring, int *sbad)
+                                                int *__restrict__ info_b, double *ring, int *sbad,
+                                                const double *src = nullptr, long lsrc = 0)
 {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -248,7 +251,8 @@ __device__ __forceinline__ void potf2_64x4_body(double *__restrict__ Ab, long ld
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int s = 0; s < 4; ++s)
-            st.a[q][s] = Ab[lane + (long)(16 * q + 4 * w + s) * lda];
+            st.a[q][s] = src ? src[lane + (long)(16 * q + 4 * w + s) * lsrc]
+                             : Ab[lane + (long)(16 * q + 4 * w + s) * lda];
     if (w == 0)
         potf2w_factor<0>(st, ring, lane, j0);
     Potf2WSteps<0>::run(st, ring, w, lane, j0);

@@ -72,9 +72,11 @@ __global__ __launch_bounds__(256) void slab_step_kernel(double *__restrict__ A, 
                                                         int factor_next, int last,
                                                         int *__restrict__ info)
 {
-    // Q rows of the tile, [k][row] (A-fragment reads are contiguous over rows); workgroup 0
-    // reuses the space for the diagonal factor's ring
+    // Q rows of the tile, [k][row] (A-fragment reads are contiguous over rows)
     __shared__ __attribute__((aligned(16))) double Qs[64 * 64];
+    // workgroup 0: the updated diagonal block on its way to the factor, and the factor's ring
+    __shared__ __attribute__((aligned(16))) double Ts[64 * 64];
+    __shared__ __attribute__((aligned(16))) double ring[4 * 4 * 64 + 64];
     __shared__ int sbad[4];
     __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.z;
@@ -159,6 +161,17 @@ __global__ __launch_bounds__(256) void slab_step_kernel(double *__restrict__ A, 
         }
     // tile column 0 is the next panel: it goes to the scratch column (the diagonal tile,
     // which workgroup 0 factors in place, and the Schur complement of the last step stay in A)
+    if (blockIdx.x == 0 && factor_next) {
+        // the next diagonal block never touches memory between its update and its factor
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Ts[16 * wave + l15 + 64 * (16 * cb + l4 + 4 * r)] = -acc[cb][r];
+        __syncthreads();
+        potf2_64x4_body(A + r0 + (long)r0 * lda, lda, r0, dout, info + b, ring, sbad, Ts, 64);
+        return;
+    }
     const bool to_s = by == 0 && bx > 0 && !last;
     double *Cout = to_s ? Sout + Rb + 16 * wave + l15 + (long)l4 * lds
                         : A + Rb + 16 * wave + l15 + (long)(Cb + l4) * lda;
@@ -170,10 +183,6 @@ __global__ __launch_bounds__(256) void slab_step_kernel(double *__restrict__ A, 
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             Cout[(long)(16 * cb + 4 * r) * ldo] = -acc[cb][r];
-    }
-    if (blockIdx.x == 0 && factor_next) {
-        __syncthreads(); // the updated block is visible to the whole workgroup, Qs is free
-        potf2_64x4_body(A + r0 + (long)r0 * lda, lda, r0, dout, info + b, Qs, sbad);
     }
 }
 
