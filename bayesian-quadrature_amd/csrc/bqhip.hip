@@ -445,6 +445,18 @@ int auto_nb(const bq_ctx *c, int ntot, int batch)
     // must be wide (256: 46 GB instead of 183 GB of traffic at N=16384), when they do
     // a narrow block means fewer, shorter launches
     const double mb = 8.0 * (double)ntot * ntot * batch / 1e6;
+    if (batch <= 2 && c->slab_fuse && c->trsm_blk && c->potf2_waves == 4) {
+        // One or two matrices cannot fill the chip with a 64-column panel: the sweep is a
+        // chain of dependent launches and the one-launch step of outer block 64 (slab.h) is
+        // the shortest chain until the k = 64 updates cost more than it saves
+        // (tools/potrf_sizes.py on one matrix: N=2048 0.73 / 0.81 ms, 3072 1.24 / 1.31,
+        // 4096 2.03 / 2.00, 6144 4.37 / 3.83 with blocks 64 / 128; 8192 6.49 / 6.44 with 128 / 256)
+        if (ntot < 3600)
+            return 64;
+        if (ntot < 7200)
+            return 128;
+        return 256;
+    }
     if (ntot >= 1024 && mb >= 100.0)
         return 256;
     if (ntot >= 512 && mb >= 30.0)

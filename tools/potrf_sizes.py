@@ -11,6 +11,8 @@ from bayesian_quadrature_amd import workloads as wl  # noqa: E402
 
 e = Engine(0)
 lib, ctx = e._lib, e._ctx
+if os.environ.get("TB_NB"):
+    e.set_block(int(os.environ["TB_NB"]))
 for n in [int(a) for a in sys.argv[1:]]:
     c4 = wl.c4(n)
     w4 = np.ascontiguousarray(c4["w"])
