@@ -468,9 +468,40 @@ int auto_nb(const bq_ctx *c, int ntot, int batch)
 // factor, panel solve -- enqueued on c->cur.  With fusion on, the diagonal factor of a
 // slab rides in the launch that last updates it (the slab update here, or the
 // trailing update of the previous block: `diag_done`).
+// With a scratch column pair `ws` (panel_ws_doubles) every step is ONE launch
+// (panel_step_kernel, slab.h): the workgroups solve the rows they need themselves.
 int enqueue_panel(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot, int K0,
-                  int KB, double *dinv, int *info, bool diag_done)
+                  int KB, double *dinv, int *info, bool diag_done, double *ws = nullptr)
 {
+    // (a batch fills the chip without this: the redundant solves then only cost throughput)
+    if (ws && batch <= 2 && c->slab_fuse && c->trsm_blk && c->potf2_waves == 4) {
+        if (!diag_done)
+            BQCHK(launch_potf2(c, A, lda, astride, K0, dinv, BQ_DINV_STRIDE, info, batch));
+        if (ntot - K0 - 64 <= 0)
+            return BQ_OK;
+        const long sstride = 64L * ntot;
+        double *S[2] = {ws, ws + sstride * batch};
+        double *SL = ws + 2 * sstride * batch; // 64 x 64 per problem
+        const int ns = KB / 64;
+        for (int sidx = 0; sidx < ns; ++sidx) {
+            const int j0 = K0 + 64 * sidx;
+            const int nrb = (ntot - j0 - 64) / 64;
+            if (nrb <= 0)
+                break;
+            const int has_next = sidx + 1 < ns;
+            const double m = 64.0 * nrb;
+            Bracket br(c, BQ_K_GEMM,
+                       (m * 64.0 * 64.0 + (has_next ? 2.0 * m * 64.0 * 64.0 * (sidx + 1) : 0.0)) *
+                           batch);
+            const int par = sidx & 1;
+            hipLaunchKernelGGL(panel_step_kernel, dim3(nrb, 1, batch), dim3(256), 0, c->cur, A,
+                               lda, astride, S[par], S[par ^ 1], (long)ntot, sstride, K0, j0,
+                               dinv + par * BQ_DINV_HALF, dinv + (par ^ 1) * BQ_DINV_HALF,
+                               (long)BQ_DINV_STRIDE, has_next, sidx == 0, SL, info);
+            HIPCHK(c, hipGetLastError());
+        }
+        return BQ_OK;
+    }
     for (int j0 = K0; j0 < K0 + KB; j0 += 64) {
         double *Ajj = A + j0 + (long)j0 * lda;
         if (j0 > K0) {
@@ -504,7 +535,7 @@ int enqueue_panel(bq_ctx *c, double *A, long lda, long astride, int batch, int n
 // the panel-column update k+1 waits for trailing update k (which last wrote
 // those columns).
 // doubles of scratch the one-launch slab sweep needs (two panel columns per problem)
-size_t panel_ws_doubles(int ntot, int batch) { return (size_t)2 * 64 * ntot * batch; }
+size_t panel_ws_doubles(int ntot, int batch) { return ((size_t)2 * 64 * ntot + 4096) * batch; }
 
 // Outer block 64 (small systems): one launch per 64-column step (slab.h) after the first
 // diagonal factor and the staging of panel 0.
@@ -547,9 +578,9 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
     if ((ntot & 63) || (ncols & 63) || ncols > ntot)
         return fail(c, BQ_ERR_BAD_ARG, "potrf: sizes must be multiples of 64");
     const int NB = auto_nb(c, ntot, batch);
-    if (NB == 64 && c->slab_fuse && c->trsm_blk && c->potf2_waves == 4 && panel_ws &&
-        panel_ws_len >= panel_ws_doubles(ntot, batch) && ncols >= 64)
-        return enqueue_slab_sweep(c, A, lda, astride, batch, ntot, ncols, dinv, info, panel_ws);
+    double *ws = (panel_ws && panel_ws_len >= panel_ws_doubles(ntot, batch)) ? panel_ws : nullptr;
+    if (NB == 64 && c->slab_fuse && c->trsm_blk && c->potf2_waves == 4 && ws && ncols >= 64)
+        return enqueue_slab_sweep(c, A, lda, astride, batch, ntot, ncols, dinv, info, ws);
     const bool la = c->lookahead && c->aux && NB >= 128 && ncols > NB;
     int K0 = 0;
     bool panel_done = false; // panel K0 was already factored by the look-ahead phase
@@ -561,7 +592,7 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
         // aux stream: panel 0
         c->cur = c->aux;
         st = enqueue_panel(c, A, lda, astride, batch, ntot, 0, std::min(NB, ncols), dinv, info,
-                           false);
+                           false, ws);
         c->cur = c->stream;
         if (st != BQ_OK)
             return st;
@@ -596,7 +627,7 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
                                  BQ_DINV_STRIDE, info);
                 if (st == BQ_OK)
                     st = enqueue_panel(c, A, lda, astride, batch, ntot, r0, nw, dinv, info,
-                                       fj >= 0);
+                                       fj >= 0, ws);
                 c->cur = c->stream;
                 if (st != BQ_OK)
                     break;
@@ -627,7 +658,8 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
     for (; K0 < ncols; K0 += NB) {
         const int KB = std::min(NB, ncols - K0);
         if (!panel_done)
-            BQCHK(enqueue_panel(c, A, lda, astride, batch, ntot, K0, KB, dinv, info, diag_done));
+            BQCHK(enqueue_panel(c, A, lda, astride, batch, ntot, K0, KB, dinv, info, diag_done,
+                                ws));
         panel_done = false;
         const int r0 = K0 + KB;
         diag_done = false;
@@ -1221,7 +1253,10 @@ extern "C" int bq_potrf_dev(bq_ctx *c, double *A_dev, int64_t n, int64_t lda, in
     if (!c->dinv64.p)
         HIPCHK(c, c->dinv64.alloc(BQ_DINV_STRIDE * sizeof(double)));
     HIPCHK(c, hipMemsetAsync(info_dev, 0, sizeof(int32_t), c->stream));
-    return enqueue_potrf_partial(c, A_dev, lda, 0, 1, (int)n, (int)n, c->dinv64.d(), info_dev);
+    if (c->panel_ws.bytes < sizeof(double) * panel_ws_doubles((int)n, 1))
+        HIPCHK(c, c->panel_ws.alloc(sizeof(double) * panel_ws_doubles((int)n, 1)));
+    return enqueue_potrf_partial(c, A_dev, lda, 0, 1, (int)n, (int)n, c->dinv64.d(), info_dev,
+                                 c->panel_ws.d(), c->panel_ws.bytes / sizeof(double));
 }
 
 // ===========================================================================

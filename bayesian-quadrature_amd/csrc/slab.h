@@ -196,3 +196,180 @@ __global__ void slab_stage_kernel(const double *__restrict__ A, long lda, long a
     if (i < ntot)
         S[(long)b * sstride + i + (long)j * lds] = A[(long)b * astride + i + (long)(j0 + j) * lda];
 }
+
+// ---------------------------------------------------------------------------
+// The same idea for the 64-column steps INSIDE a wide panel (outer block 128 / 256): one
+// launch per step instead of two (left-looking slab update + fused diagonal factor, panel
+// solve).  Step s of the panel that starts at column K0 (j0 = K0 + 64 s), one workgroup per
+// 64-row block below the diagonal block of slab s:
+//   * solve its own rows of slab s (from the scratch column Sin; the first step of a panel
+//     reads them from A) and write them, the final L, to A;
+//   * if the panel has a slab s + 1: solve the rows of row block s + 1 as well (every
+//     workgroup for itself, through LDS) and bring its rows of slab s + 1 up to date with
+//     ALL slabs 0 .. s of the panel (left-looking, k = 64 (s + 1): the earlier slabs' L from
+//     A, slab s from registers / LDS); the result goes to the scratch column Sout, the input
+//     of step s + 1 -- except in workgroup 0, whose rows ARE row block s + 1: its result is
+//     the next diagonal block, handed through LDS to the 4-wave potf2.
+// Nothing waits on another workgroup.  grid: ((ntot - j0 - 64) / 64, 1, batch); block 256.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void panel_step_kernel(double *__restrict__ A, long lda,
+                                                         long astride,
+                                                         const double *__restrict__ Sin,
+                                                         double *__restrict__ Sout, long lds,
+                                                         long sstride, int K0, int j0,
+                                                         const double *__restrict__ din,
+                                                         double *__restrict__ dout, long dstride,
+                                                         int has_next, int first,
+                                                         double *__restrict__ SL,
+                                                         int *__restrict__ info)
+{
+    __shared__ __attribute__((aligned(16))) double Qs[64 * 64];
+    __shared__ __attribute__((aligned(16))) double Ts[64 * 64];
+    __shared__ __attribute__((aligned(16))) double ring[4 * 4 * 64 + 64];
+    __shared__ int sbad[4];
+    __builtin_amdgcn_s_setprio(3);
+    const int b = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    A += (long)b * astride;
+    Sin += (long)b * sstride;
+    Sout += (long)b * sstride;
+    din += (long)b * dstride;
+    dout += (long)b * dstride;
+    const int r0 = j0 + 64;                 // row block s + 1 = the next diagonal block
+    const int Rb = r0 + 64 * blockIdx.x;    // this workgroup's rows
+    const int l15 = lane & 15, l4 = lane >> 4;
+    SL += (long)b * 4096;
+    // The first step of a panel reads its slab straight from A (no staging launch).  Every
+    // workgroup reads its own rows before it overwrites them; the one block that others read
+    // too -- row block s + 1, for their own solve -- is written by workgroup 0 to the side
+    // buffer SL instead, and workgroup 0 of the NEXT step (where those rows are the diagonal
+    // block's and nobody reads them) moves it into place.
+    const double *Sp = first ? A + (long)j0 * lda : Sin;
+    const long ldsp = first ? lda : lds;
+    if (!first && j0 - K0 == 64 && blockIdx.x == 0) {
+        double *dst = A + j0 + (long)(j0 - 64) * lda;
+        for (int e = threadIdx.x; e < 4096; e += 256)
+            dst[(e & 63) + (long)(e >> 6) * lda] = SL[e];
+    }
+
+    double la[4][3][4], wneg[4][4];
+    {
+        const double *L11 = A + j0 + (long)j0 * lda + l15 + (long)l4 * lda;
+        const double *W = din + 64 + l15 + 16 * l4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                wneg[c][r] = -W[256 * c + 64 * r];
+#pragma unroll
+        for (int c = 1; c < 4; ++c)
+#pragma unroll
+            for (int bb = 0; bb < c; ++bb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    la[c][bb][r] = L11[16 * c + (long)(16 * bb + 4 * r) * lda];
+    }
+    double4_t xp[4];
+    if (has_next && blockIdx.x != 0) {
+        double4_t xq[4];
+        slab_solve16(Sp + r0 + 16 * wave + l15 + (long)l4 * ldsp, ldsp, la, wneg, xq);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Qs[(16 * c + l4 + 4 * r) * 64 + 16 * wave + l15] = xq[c][r];
+    }
+    slab_solve16(Sp + Rb + 16 * wave + l15 + (long)l4 * ldsp, ldsp, la, wneg, xp);
+    {
+        // (a lone workgroup has no readers to protect, and no next step to move the block)
+        const bool side = first && has_next && blockIdx.x == 0 && gridDim.x > 1;
+        double *Lw = side ? SL + 16 * wave + l15 + 64 * l4
+                          : A + Rb + 16 * wave + l15 + (long)(j0 + l4) * lda;
+        const long ldw = side ? 64 : lda;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Lw[(long)(16 * c + 4 * r) * ldw] = xp[c][r];
+    }
+    if (!has_next)
+        return;
+    if (blockIdx.x == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Qs[(16 * c + l4 + 4 * r) * 64 + 16 * wave + l15] = xp[c][r];
+    }
+    // my rows of slab s + 1 (columns r0 .. r0 + 63), still as the last trailing update left them
+    const double *Cin = A + Rb + 16 * wave + l15 + (long)(r0 + l4) * lda;
+    double4_t acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[cb][r] = -Cin[(long)(16 * cb + 4 * r) * lda];
+    // slabs 0 .. s-1 of the panel: both operands from A (P: my rows, Q: row block s + 1)
+    {
+        const double *Pg = A + Rb + 16 * wave + l15 + (long)(K0 + l4) * lda;
+        const double *Qg = A + r0 + l15 + (long)(K0 + l4) * lda;
+        // 16 columns (4 k-steps) per trip, the next trip's 20 fragments in flight meanwhile
+        const int kend = j0 - K0; // multiple of 64
+        double pa[4], qa[4][4], pb[4], qb[4][4];
+#define BQ_PANEL_LOAD(PF, QF, KK)                                                                  \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                  \
+    {                                                                                              \
+        PF[t] = Pg[(long)((KK) + 4 * t) * lda];                                                    \
+        _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) QF[t][cb] =                               \
+            Qg[16 * cb + (long)((KK) + 4 * t) * lda];                                              \
+    }
+#define BQ_PANEL_MFMA(PF, QF)                                                                      \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) \
+        acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(QF[t][cb], PF[t], acc[cb], 0, 0, 0);
+        if (kend > 0) {
+            BQ_PANEL_LOAD(pa, qa, 0)
+            for (int kk = 0; kk < kend; kk += 32) {
+                BQ_PANEL_LOAD(pb, qb, kk + 16)
+                __builtin_amdgcn_sched_barrier(0);
+                BQ_PANEL_MFMA(pa, qa)
+                __builtin_amdgcn_sched_barrier(0);
+                const int kn = kk + 32 < kend ? kk + 32 : kk; // clamped: values unused past the end
+                BQ_PANEL_LOAD(pa, qa, kn)
+                __builtin_amdgcn_sched_barrier(0);
+                BQ_PANEL_MFMA(pb, qb)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#undef BQ_PANEL_LOAD
+#undef BQ_PANEL_MFMA
+    }
+    __syncthreads();
+    // slab s: P from registers, Q from LDS
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double pf = xp[c][r];
+            const double *qrow = Qs + (16 * c + l4 + 4 * r) * 64 + l15;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+                acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(qrow[16 * cb], pf, acc[cb], 0, 0, 0);
+        }
+    if (blockIdx.x == 0) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Ts[16 * wave + l15 + 64 * (16 * cb + l4 + 4 * r)] = -acc[cb][r];
+        __syncthreads();
+        potf2_64x4_body(A + r0 + (long)r0 * lda, lda, r0, dout, info + b, ring, sbad, Ts, 64);
+        return;
+    }
+    double *Cout = Sout + Rb + 16 * wave + l15 + (long)l4 * lds;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            Cout[(long)(16 * cb + 4 * r) * lds] = -acc[cb][r];
+}
