@@ -537,6 +537,14 @@ int enqueue_panel(bq_ctx *c, double *A, long lda, long astride, int batch, int n
 // doubles of scratch the one-launch slab sweep needs (two panel columns per problem)
 size_t panel_ws_doubles(int ntot, int batch) { return ((size_t)2 * 64 * ntot + 4096) * batch; }
 
+// whether a sweep over `batch` matrices of size ntot can use that scratch at all (with the
+// block size in force now): callers that own long-lived workspaces skip the allocation else
+bool panel_ws_useful(const bq_ctx *c, int ntot, int batch)
+{
+    return c->slab_fuse && c->trsm_blk && c->potf2_waves == 4 &&
+           (batch <= 2 || auto_nb(c, ntot, batch) == 64);
+}
+
 // Outer block 64 (small systems): one launch per 64-column step (slab.h) after the first
 // diagonal factor and the staging of panel 0.
 int enqueue_slab_sweep(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
@@ -1323,7 +1331,9 @@ extern "C" int bq_plan_create(bq_ctx *c, int64_t nprob, int64_t d, int64_t n, in
     A(p->y, sizeof(double) * (size_t)p->L.npad * nprob);
     A(p->gp, sizeof(GaussParams) * (size_t)nprob);
     A(p->dinv, sizeof(double) * BQ_DINV_STRIDE * (size_t)nprob);
-    A(p->panel, sizeof(double) * panel_ws_doubles(p->L.ntot, (int)nprob));
+    A(p->panel, panel_ws_useful(c, p->L.ntot, (int)nprob)
+                    ? sizeof(double) * panel_ws_doubles(p->L.ntot, (int)nprob)
+                    : 0);
     A(p->info, sizeof(int) * (size_t)nprob);
     A(p->scal, sizeof(double) * 4 * (size_t)nprob);
     A(p->mean, sizeof(double) * (size_t)std::max<int64_t>(M, 1) * nprob);
@@ -1772,7 +1782,8 @@ extern "C" int bq_gp_fit(bq_ctx *c, const double *x, const double *y, int64_t d,
     A(f->y, sizeof(double) * (size_t)f->npad);
     A(f->gp, sizeof(GaussParams));
     A(f->dinv, sizeof(double) * ((size_t)f->npad + BQ_DINV_STRIDE));
-    A(f->panel, sizeof(double) * panel_ws_doubles(f->L.ntot, 1));
+    A(f->panel, panel_ws_useful(c, f->L.ntot, 1) ? sizeof(double) * panel_ws_doubles(f->L.ntot, 1)
+                                                 : 0);
     A(f->misc, sizeof(double) * 8);
     A(f->alpha, sizeof(double) * (size_t)f->npad);
     if (e != hipSuccess) {

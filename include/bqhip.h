@@ -128,7 +128,8 @@ int bq_gram_gauss_cross(bq_ctx *ctx, const double *x1, int64_t n1, const double 
 
 /* ---- device-resident Cholesky (the MFMA roofline path) -------------- */
 /* In-place lower Cholesky of the n x n device matrix (ld = lda).  n must be a
- * multiple of 64 (callers pad with an identity block).  Only enqueues; the
+ * multiple of 64 (callers pad with an identity block).  Only enqueues (the first call at a
+ * new largest n also allocates 1024 n + 32768 bytes of panel scratch in the context); the
  * failing column (0 = success) is written to info_dev[0] (device int32). */
 int bq_potrf_dev(bq_ctx *ctx, double *A_dev, int64_t n, int64_t lda, int32_t *info_dev);
 
