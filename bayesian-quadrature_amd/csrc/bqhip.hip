@@ -1619,14 +1619,14 @@ extern "C" int bq_fit_predict(bq_ctx *c, const double *x, const double *y, int64
     return BQ_OK;
 }
 
-extern "C" int bq_gp_logml_grid(bq_ctx *c, const double *x, const double *y, int64_t d, int64_t n,
-                                const double *h, const double *w, double s, int64_t G, double *out,
-                                int64_t chunk)
+namespace {
+
+// G hyper-parameter points in chunks of batched plans: log-ML per point (-inf where the
+// factorisation fails) and, on request, its two ingredients log|K| and y^T K^-1 y
+int logml_grid_core(bq_ctx *c, const double *x, const double *y, int64_t d, int64_t n,
+                    const double *h, const double *w, double s, int64_t G, int64_t chunk,
+                    double *lm, double *logdet, double *qf)
 {
-    BQCHK(check_dims(c, d, n));
-    if (!x || !y || !h || !w || !out || G < 1)
-        return fail(c, BQ_ERR_BAD_ARG, "illegal value");
-    HIPCHK(c, hipSetDevice(c->device));
     const Layout L = make_layout((int)n, 0, true);
     const size_t per = sizeof(double) * (size_t)pick_ld(L.ntot) * L.ntot;
     if (chunk <= 0) {
@@ -1647,6 +1647,8 @@ extern "C" int bq_gp_logml_grid(bq_ctx *c, const double *x, const double *y, int
         std::memcpy(&xr[(size_t)b * d * n], x, sizeof(double) * d * n);
         std::memcpy(&yr[(size_t)b * n], y, sizeof(double) * n);
     }
+    std::vector<double> scal((size_t)chunk * 4);
+    std::vector<int> info((size_t)chunk);
     int st = BQ_OK;
     for (int64_t g0 = 0; g0 < G && st == BQ_OK; g0 += chunk) {
         const int64_t nb = std::min(chunk, G - g0);
@@ -1660,13 +1662,87 @@ extern "C" int bq_gp_logml_grid(bq_ctx *c, const double *x, const double *y, int
                                 ss.data());
         if (st == BQ_OK)
             st = bq_plan_run(c, p);
-        if (st == BQ_OK)
-            st = bq_plan_results(c, p, nullptr, nullptr, out + g0, nullptr);
+        if (st != BQ_OK)
+            break;
+        hipError_t e = hipMemcpyAsync(scal.data(), p->scal.p, sizeof(double) * 4 * nb,
+                                      hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(info.data(), p->info.p, sizeof(int) * nb, hipMemcpyDeviceToHost,
+                               c->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            st = fail(c, BQ_ERR_HIP, "%s", hipGetErrorString(e));
+            break;
+        }
+        for (int64_t b = 0; b < nb; ++b) {
+            const bool bad = info[(size_t)b] != 0;
+            lm[g0 + b] = bad ? -std::numeric_limits<double>::infinity() : scal[(size_t)b * 4];
+            if (logdet)
+                logdet[g0 + b] = scal[(size_t)b * 4 + 1];
+            if (qf)
+                qf[g0 + b] = scal[(size_t)b * 4 + 2];
+        }
     }
     if (p != big)
         bq_plan_destroy(c, p);
     plan_release(c, big);
     return st;
+}
+
+} // namespace
+
+extern "C" int bq_gp_logml_grid(bq_ctx *c, const double *x, const double *y, int64_t d, int64_t n,
+                                const double *h, const double *w, double s, int64_t G, double *out,
+                                int64_t chunk)
+{
+    BQCHK(check_dims(c, d, n));
+    if (!x || !y || !h || !w || !out || G < 1)
+        return fail(c, BQ_ERR_BAD_ARG, "illegal value");
+    HIPCHK(c, hipSetDevice(c->device));
+    // Without a noise term K = h^2 G(w): chol(K) = h chol(G), so every output scale h of one
+    // length scale w shares ONE factorisation:
+    //   log|K| = log|G| + 2 n log h,   y^T K^-1 y = y^T G^-1 y / h^2.
+    // Only the distinct w are factored, at h = 1.  (A matrix on the edge of numerical
+    // definiteness could pass at one h and fail at another when factored separately; here
+    // all h of one w succeed or fail together.)
+    if (s == 0.0 && G > 1) {
+        std::vector<int64_t> rep((size_t)G), uniq;
+        for (int64_t g = 0; g < G; ++g) {
+            int64_t r = -1;
+            for (size_t u = 0; u < uniq.size() && r < 0; ++u)
+                if (std::memcmp(w + (size_t)uniq[u] * d, w + (size_t)g * d, sizeof(double) * d) == 0)
+                    r = (int64_t)u;
+            if (r < 0) {
+                r = (int64_t)uniq.size();
+                uniq.push_back(g);
+            }
+            rep[(size_t)g] = r;
+        }
+        bool hpos = true;
+        for (int64_t g = 0; g < G; ++g)
+            hpos = hpos && h[g] > 0.0;
+        if ((int64_t)uniq.size() < G && hpos) {
+            const int64_t U = (int64_t)uniq.size();
+            std::vector<double> hu((size_t)U, 1.0), wu((size_t)U * d), lm((size_t)U),
+                ld((size_t)U), qf((size_t)U);
+            for (int64_t u = 0; u < U; ++u)
+                std::memcpy(&wu[(size_t)u * d], w + (size_t)uniq[(size_t)u] * d, sizeof(double) * d);
+            BQCHK(logml_grid_core(c, x, y, d, n, hu.data(), wu.data(), 0.0, U, chunk, lm.data(),
+                                  ld.data(), qf.data()));
+            for (int64_t g = 0; g < G; ++g) {
+                const size_t u = (size_t)rep[(size_t)g];
+                const double hh = h[g];
+                out[g] = std::isinf(lm[u])
+                             ? lm[u]
+                             : -0.5 * qf[u] / (hh * hh) -
+                                   0.5 * (ld[u] + 2.0 * (double)n * std::log(hh)) -
+                                   0.5 * (double)n * 1.8378770664093453;
+            }
+            return BQ_OK;
+        }
+    }
+    return logml_grid_core(c, x, y, d, n, h, w, s, G, chunk, out, nullptr, nullptr);
 }
 
 // ===========================================================================

@@ -160,7 +160,9 @@ int bq_fit_predict(bq_ctx *ctx, const double *x, const double *y, int64_t d, int
 /* log marginal likelihood on a grid of G hyper-parameter points sharing the
  * data (x, y): h[G], w[G*d] (point g uses w[g*d .. g*d+d-1]), one s.
  * out[G]; a point whose Gram is not positive definite yields -inf
- * (bq.py:542-548).  chunk = problems factored per batched launch (0 = auto). */
+ * (bq.py:542-548).  chunk = problems factored per batched launch (0 = auto).
+ * With s == 0 only the distinct w are factored (at h = 1) and every h is derived from
+ * chol(h^2 G) = h chol(G). */
 int bq_gp_logml_grid(bq_ctx *ctx, const double *x, const double *y, int64_t d, int64_t n,
                      const double *h, const double *w, double s, int64_t G, double *out,
                      int64_t chunk);

@@ -235,6 +235,38 @@ def test_logml_grid(engine, oracle):
     assert np.isfinite(out[0]) and np.isfinite(out[2]) and out[1] == -np.inf
 
 
+def test_logml_grid_shares_factorisations_without_noise(engine, oracle):
+    """s = 0: all output scales h of one length scale w come from ONE factorisation
+    (chol(h^2 G) = h chol(G)); every point still equals its own fit."""
+    rs = np.random.RandomState(5)
+    n = 200
+    dx = 10.0 / (n - 1)
+    x = np.linspace(-5, 5, n) + rs.uniform(-dx / 4, dx / 4, n)
+    y = wl.norm_logpdf(x)
+    hs = np.array([0.3, 1.0, 2.5, 7.0])
+    ws = np.array([0.8 * dx, 1.0 * dx, 1.15 * dx])
+    H, W = np.meshgrid(hs, ws, indexing="ij")
+    out = engine.logml_grid(x, y, H.ravel(), W.ravel(), 0.0)
+    for g, (hh, ww) in enumerate(zip(H.ravel(), W.ravel())):
+        _, _, lmo = oracle.gp_fit(x, y, hh, ww, 0.0)
+        # no noise floor here: the quadratic form carries cond(K) eps in either evaluation
+        tol = max(RTOL, 1e-15 * np.linalg.cond(oracle.gram(x, hh, ww, 0.0)))
+        assert abs(out[g] - lmo) <= tol * abs(lmo)
+    # a hopeless length scale fails for every h, the others survive
+    W2 = W.copy()
+    W2[:, 1] = 60 * dx
+    out = engine.logml_grid(x, y, H.ravel(), W2.ravel(), 0.0)
+    bad = np.isinf(out).reshape(H.shape)
+    assert bad[:, 1].all() and not bad[:, [0, 2]].any()
+    # 2-D points, vector w
+    c = wl.c3(side=12, gh=3, gw=2)
+    out = engine.logml_grid(c["x"], c["y"], c["h"], c["w"], 0.0)
+    for g in range(len(out)):
+        _, _, lmo = oracle.gp_fit(c["x"], c["y"], c["h"][g], c["w"][g], 0.0)
+        tol = max(RTOL, 1e-15 * np.linalg.cond(oracle.gram(c["x"], c["h"][g], c["w"][g], 0.0)))
+        assert abs(out[g] - lmo) <= tol * abs(lmo)
+
+
 def test_batch_fit_predict(engine, oracle):
     probs = [3, 4, 5, 6, 7]
     c = wl.c5(probs, n=200, m=33)
