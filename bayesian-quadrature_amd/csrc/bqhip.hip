@@ -629,7 +629,10 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
                 if (have_b)
                     HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_next, 0));
                 c->cur = c->aux;
-                const int fj = c->fuse ? r0 : -1;
+                // (a wide panel's update is worth the LDS-staged kernel, which carries no
+                // fused diagonal factor: enqueue_panel then factors the block itself)
+                const int fj =
+                    (c->fuse && !gemm_uses_lds(c, ntot - r0, nw, KB, 1, batch)) ? r0 : -1;
                 st = launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda,
                                  astride, P, 1, lda, astride, ntot - r0, nw, KB, 1, batch, fj, dinv,
                                  BQ_DINV_STRIDE, info);
