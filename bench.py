@@ -218,8 +218,20 @@ def cpu_baseline(wk, budget_s=12.0):
         el = time.perf_counter() - t0
         if el > budget_s or reps >= 200:
             break
+    # the same problem on ONE thread, a few repetitions (1 thread and all cores)
+    o.set_threads(1)
+    r1, t1 = 0, time.perf_counter()
+    while True:
+        L, a, lm = o.gp_fit(x, y, wk["h"], wk["w"], wk["s"])
+        o.gp_predict(x, wk["h"], wk["w"], L, a, xo)
+        r1 += 1
+        e1 = time.perf_counter() - t1
+        if e1 > 3.0 or r1 >= 20:
+            break
+    o.set_threads(cores)
     return {"value": reps / el, "unit": "problems/s", "cores": cores, "kind": "port",
             "ms_per_problem": el / reps * 1e3,
+            "one_thread": {"value": r1 / e1, "ms_per_problem": e1 / r1 * 1e3, "reps": r1},
             "sample": "%d x (gram + blocked potrf + potrs + predict mean/var + logML) of the "
                       "N=%d, M=%d problem, oracle/bq_oracle.c with OpenMP on %d threads, %.1f s"
                       % (reps, wk["n"], wk["M"], cores, el)}
