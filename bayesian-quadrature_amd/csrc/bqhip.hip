@@ -550,15 +550,16 @@ bool panel_ws_useful(const bq_ctx *c, int ntot, int batch)
 int enqueue_slab_sweep(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
                        int ncols, double *dinv, int *info, double *ws)
 {
-    BQCHK(launch_potf2(c, A, lda, astride, 0, dinv, BQ_DINV_STRIDE, info, batch));
     if (ntot <= 64)
-        return BQ_OK;
+        return launch_potf2(c, A, lda, astride, 0, dinv, BQ_DINV_STRIDE, info, batch);
     const long sstride = 64L * ntot;
     double *S[2] = {ws, ws + sstride * batch};
     {
-        Bracket br(c, BQ_K_REDUCE);
-        hipLaunchKernelGGL(slab_stage_kernel, dim3((ntot - 64 + 255) / 256, 64, batch), dim3(256),
-                           0, c->cur, A, lda, astride, S[0], (long)ntot, sstride, ntot, 0);
+        // the first diagonal factor and the staging of panel 0 share a launch
+        Bracket br(c, BQ_K_POTF2, 64.0 * 64 * 64 / 3.0 * batch);
+        hipLaunchKernelGGL(slab_first_kernel, dim3(ntot / 64, 1, batch), dim3(256), 0, c->cur, A,
+                           lda, astride, S[0], (long)ntot, sstride, ntot, dinv,
+                           (long)BQ_DINV_STRIDE, info);
         HIPCHK(c, hipGetLastError());
     }
     for (int j0 = 0, par = 0; j0 < ncols; j0 += 64, par ^= 1) {

@@ -186,15 +186,33 @@ __global__ __launch_bounds__(256) void slab_step_kernel(double *__restrict__ A, 
     }
 }
 
-// panel column j0 of A (rows >= j0 + 64) -> scratch column, absolute row index
-__global__ void slab_stage_kernel(const double *__restrict__ A, long lda, long astride,
-                                  double *__restrict__ S, long lds, long sstride, int ntot, int j0)
+// first launch of a slab sweep: workgroup 0 factors the leading diagonal block, the others
+// copy panel column 0 (rows >= 64) into the scratch column -- one launch instead of two
+__global__ __launch_bounds__(256) void slab_first_kernel(double *__restrict__ A, long lda,
+                                                         long astride, double *__restrict__ S,
+                                                         long lds, long sstride, int ntot,
+                                                         double *__restrict__ dinv, long dstride,
+                                                         int *__restrict__ info)
 {
+    __shared__ __attribute__((aligned(16))) double ring[4 * 4 * 64 + 64];
+    __shared__ int sbad[4];
     const int b = blockIdx.z;
-    const int i = j0 + 64 + blockIdx.x * 256 + threadIdx.x;
-    const int j = blockIdx.y;
-    if (i < ntot)
-        S[(long)b * sstride + i + (long)j * lds] = A[(long)b * astride + i + (long)(j0 + j) * lda];
+    A += (long)b * astride;
+    if (blockIdx.x == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        potf2_64x4_body(A, lda, 0, dinv + (long)b * dstride, info + b, ring, sbad);
+        return;
+    }
+    // 64 rows x 64 columns per workgroup: thread t copies row (t & 63) of 16 columns
+    const int i = 64 * (int)blockIdx.x + (threadIdx.x & 63);
+    const int jb = (threadIdx.x >> 6) * 16;
+    if (i < ntot) {
+        double *dst = S + (long)b * sstride + i + (long)jb * lds;
+        const double *src = A + i + (long)jb * lda;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            dst[(long)j * lds] = src[(long)j * lda];
+    }
 }
 
 // ---------------------------------------------------------------------------
