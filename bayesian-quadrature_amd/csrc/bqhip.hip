@@ -692,13 +692,18 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
 }
 
 // X (mrows x npad, ld ldx) <- X L^-T, L resident (npad x npad, ld ldl), dinv[npad]
+// dw: the per-block records of diag_winv_kernel (MFMA panel solve), or nullptr
 int enqueue_forward_rows(bq_ctx *c, double *X, long ldx, int mrows, const double *L, long ldl,
-                         const double *dinv, int npad)
+                         const double *dinv, int npad, const double *dw = nullptr)
 {
     for (int jb = 0; jb < npad; jb += 64) {
         const double *L11 = L + jb + (long)jb * ldl;
-        BQCHK(launch_trsm<true>(c, X + (long)jb * ldx, ldx, 0, mrows, L11, ldl, 0, dinv + jb, 0,
-                                1));
+        if (dw && c->trsm_blk && (mrows & 15) == 0)
+            BQCHK(launch_trsm_blk(c, X + (long)jb * ldx, ldx, 0, mrows, L11, ldl, 0,
+                                  dw + (long)(jb / 64) * BQ_DINV_HALF, 0, 1));
+        else
+            BQCHK(launch_trsm<true>(c, X + (long)jb * ldx, ldx, 0, mrows, L11, ldl, 0, dinv + jb,
+                                    0, 1));
         const int rest = npad - jb - 64;
         if (rest > 0)
             BQCHK(launch_gemm(c, BQ_K_GEMM, X + (long)(jb + 64) * ldx, ldx, 0,
@@ -1764,6 +1769,8 @@ struct bq_fit {
     DevBuf gp;    // GaussParams
     DevBuf dinv;  // npad reciprocal diagonal (+ BQ_DINV_STRIDE scratch for the factorisation)
     DevBuf panel; // scratch panel columns of the one-launch slab sweep
+    DevBuf dw;    // diag_winv_kernel records of the resident factor (MFMA solves in the sweeps)
+    DevBuf wV, wx, wout, wz; // prediction workspaces, grown on demand and kept
     DevBuf misc;  // info (int) + scal[4]
     DevBuf alpha; // npad, valid if have_alpha
     bool have_alpha = false;
@@ -1791,6 +1798,9 @@ int fit_factor(bq_ctx *c, bq_fit *f)
         HIPCHK(c, hipGetLastError());
         hipLaunchKernelGGL(diag_recip_kernel, dim3((f->npad + 255) / 256), dim3(256), 0, c->stream,
                            f->A.d(), f->ldl, 0, f->npad, f->dinv.d(), 0);
+        HIPCHK(c, hipGetLastError());
+        hipLaunchKernelGGL(diag_winv_kernel, dim3(f->npad / 64), dim3(256), 0, c->stream, f->A.d(),
+                           f->ldl, f->dw.d());
         HIPCHK(c, hipGetLastError());
     }
     int hinfo = 0;
@@ -1864,6 +1874,7 @@ extern "C" int bq_gp_fit(bq_ctx *c, const double *x, const double *y, int64_t d,
     A(f->dinv, sizeof(double) * ((size_t)f->npad + BQ_DINV_STRIDE));
     A(f->panel, panel_ws_useful(c, f->L.ntot, 1) ? sizeof(double) * panel_ws_doubles(f->L.ntot, 1)
                                                  : 0);
+    A(f->dw, sizeof(double) * BQ_DINV_HALF * (size_t)(f->npad / 64));
     A(f->misc, sizeof(double) * 8);
     A(f->alpha, sizeof(double) * (size_t)f->npad);
     if (e != hipSuccess) {
@@ -1979,9 +1990,13 @@ extern "C" int bq_gp_predict(bq_ctx *c, bq_fit *f, const double *xo, int64_t M, 
     HIPCHK(c, hipSetDevice(c->device));
     const int d = f->d, n = f->n, npad = f->npad;
     const int Mp = (int)roundup(M, 64);
-    DevBuf xod, out;
-    HIPCHK(c, xod.alloc(sizeof(double) * d * M));
-    HIPCHK(c, out.alloc(sizeof(double) * 2 * (size_t)Mp));
+    // workspaces live in the fit and only grow: a BQ object predicts thousands of times
+    auto grow = [&](DevBuf &b, size_t bytes) -> hipError_t {
+        return b.bytes >= bytes ? hipSuccess : b.alloc(bytes);
+    };
+    DevBuf &xod = f->wx, &out = f->wout;
+    HIPCHK(c, grow(xod, sizeof(double) * d * M));
+    HIPCHK(c, grow(out, sizeof(double) * 2 * (size_t)Mp));
     HIPCHK(c, hipMemcpyAsync(xod.p, xo, sizeof(double) * d * M, hipMemcpyHostToDevice, c->stream));
     GaussParams g = f->g;
     if (!var && !cov) {
@@ -2006,14 +2021,15 @@ extern "C" int bq_gp_predict(bq_ctx *c, bq_fit *f, const double *xo, int64_t M, 
         HIPCHK(c, hipGetLastError());
     } else {
         // V = K(xo, x) L^-T by a forward sweep with rows = prediction points
-        DevBuf V;
-        HIPCHK(c, V.alloc(sizeof(double) * (size_t)Mp * npad));
-        HIPCHK(c, hipMemsetAsync(V.p, 0, V.bytes, c->stream));
+        DevBuf &V = f->wV;
+        HIPCHK(c, grow(V, sizeof(double) * (size_t)Mp * npad));
+        HIPCHK(c, hipMemsetAsync(V.p, 0, sizeof(double) * (size_t)Mp * npad, c->stream));
         BQCHK(launch_gram_cross(c, d, xod.d(), (int)M, f->pts.d(), n, g, V.d(), Mp));
-        BQCHK(enqueue_forward_rows(c, V.d(), Mp, Mp, f->A.d(), f->ldl, f->dinv.d(), npad));
+        BQCHK(enqueue_forward_rows(c, V.d(), Mp, Mp, f->A.d(), f->ldl, f->dinv.d(), npad,
+                                   f->dw.d()));
         // z lives in row yrow of the factor with stride ldl: gather it
-        DevBuf z;
-        HIPCHK(c, z.alloc(sizeof(double) * npad));
+        DevBuf &z = f->wz;
+        HIPCHK(c, grow(z, sizeof(double) * npad));
         HIPCHK(c, hipMemcpy2DAsync(z.p, sizeof(double), f->A.d() + f->L.yrow,
                                    sizeof(double) * f->ldl, sizeof(double), npad,
                                    hipMemcpyDeviceToDevice, c->stream));
@@ -2039,7 +2055,7 @@ extern "C" int bq_gp_predict(bq_ctx *c, bq_fit *f, const double *xo, int64_t M, 
             HIPCHK(c, hipMemcpy2DAsync(cov, sizeof(double) * M, Cd.p, sizeof(double) * Mp,
                                        sizeof(double) * M, M, hipMemcpyDeviceToHost, c->stream));
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream)); // V, z, Cd go out of scope
+        HIPCHK(c, hipStreamSynchronize(c->stream)); // Cd goes out of scope
     }
     if (mean)
         HIPCHK(c, hipMemcpyAsync(mean, out.p, sizeof(double) * M, hipMemcpyDeviceToHost,

@@ -351,6 +351,46 @@ __global__ __launch_bounds__(256) void trsm_blk_kernel(double *__restrict__ X, l
     }
 }
 
+// For a RESIDENT factor: the scratch record trsm_blk_kernel wants -- 64 reciprocal pivots and
+// the inverses of the four 16 x 16 diagonal sub-blocks -- of every 64 x 64 diagonal block,
+// BQ_DINV_HALF doubles per block, so that the row-form sweeps over the factor (predictions,
+// solves) can use the MFMA panel solve too.  One workgroup per diagonal block, wave w inverts
+// sub-block w exactly as potf2_64x4_body does.
+__global__ __launch_bounds__(256) void diag_winv_kernel(const double *__restrict__ Lm, long ldl,
+                                                        double *__restrict__ dw)
+{
+    __shared__ __attribute__((aligned(16))) double blk[4][256];
+    __shared__ double rd[64];
+    const int jb = 64 * blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const double *Lw = Lm + jb + 16 * w + (long)(jb + 16 * w) * ldl;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int e = lane + 64 * t; // element i = e & 15, column k = e >> 4
+        blk[w][e] = Lw[(e & 15) + (long)(e >> 4) * ldl];
+    }
+    if (lane < 16)
+        rd[16 * w + lane] = 1.0 / Lw[lane + (long)lane * ldl];
+    __syncthreads();
+    double *out = dw + (long)blockIdx.x * BQ_DINV_HALF;
+    if (lane < 16) {
+        out[16 * w + lane] = rd[16 * w + lane];
+        double wc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double sacc[4] = {(i == lane) ? 1.0 : 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < i; ++k)
+                sacc[k & 3] -= blk[w][i + 16 * k] * wc[k];
+            wc[i] = ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) * rd[16 * w + i];
+        }
+        double *Wb = out + 64 + 256 * w + 16 * lane;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            Wb[i] = wc[i];
+    }
+}
+
 // reciprocal diagonal of a resident factor: dinv[j] = 1 / L[j0+j, j0+j]
 __global__ void diag_recip_kernel(const double *__restrict__ Lm, long ldl, long lstride, int n,
                                   double *__restrict__ dinv, long dstride)
