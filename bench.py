@@ -375,6 +375,23 @@ def batched_configs(eng):
     out["c5_shard_64x2048"] = {"ms_per_batch": ms, "problems_per_s": B / ms * 1e3,
                                "failed": int((status != 0).sum()),
                                "potrf_tflops_lower_bound": flops / (ms * 1e-3) / 1e12}
+    # the headline problem, 256 independent copies per step: what batching buys over the
+    # latency-bound single problem of `value`
+    c2 = wl.c2()
+    B2 = 256
+    plan = eng.plan(B2, 1, 1024, 256)
+    plan.set_inputs(np.repeat(c2["x"][None], B2, axis=0), np.repeat(c2["y"][None], B2, axis=0),
+                    np.repeat(c2["xo"][None], B2, axis=0), c2["h"], c2["w"], c2["s"])
+    plan.run()
+    eng.sync()
+    eng.timer_start()
+    for _ in range(3):
+        plan.run()
+    ms2 = eng.timer_stop_ms() / 3
+    st2 = plan.results()[3]
+    plan.close()
+    out["c2_batch_256x1024"] = {"ms_per_batch": ms2, "problems_per_s": B2 / ms2 * 1e3,
+                                "failed": int((st2 != 0).sum())}
     c3 = wl.c3()
     # one untimed chunk first: the first call pays the 100 x 128 MiB workspace allocation
     eng.logml_grid(c3["x"], c3["y"], c3["h"][:100], c3["w"][:100], c3["s"], chunk=100)
