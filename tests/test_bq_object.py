@@ -266,6 +266,25 @@ def test_fit_hypers(pkg):
     assert bq.gp_log_l.log_lh + bq.gp_l.log_lh >= llh
 
 
+def test_gaussian_example_notebook(pkg):
+    """docs/ipynb/gaussian-example.ipynb of the reference (code cells 1, 3, 5, 7, 11):
+    three samples, fit_hypers(['h', 'w']) by L-BFGS-B, then the printed
+    ``E[Z] = 0.141767`` / ``V(Z) = 0.000737``.  The optimum is the argmax of
+    gp_log_l.log_lh + gp_l.log_lh (bq.py:536-562), so reproducing the prints pins the form
+    of ``log_lh`` -- the one quantity no other reference-held number reaches."""
+    g = known_answers()["gaussian_example"]
+    fx = g["fixture"]
+    np.random.seed(fx["seed"])
+    x = np.array(fx["x"])
+    bq = pkg.BQ(x, f_x(x), kernel=pkg.GaussianKernel, n_candidate=fx["n_candidate"],
+                x_mean=fx["x_mean"], x_var=fx["x_var"],
+                candidate_thresh=fx["candidate_thresh"], optim_method=fx["optim_method"])
+    bq.init(params_tl=tuple(fx["params_tl"]), params_l=tuple(fx["params_l"]))
+    bq.fit_hypers(fx["fit_hypers"])
+    assert "%f" % bq.Z_mean() == g["expected"]["Z_mean"]["printed"]
+    assert "%f" % bq.Z_var() == g["expected"]["Z_var"]["printed"]
+
+
 def test_sample_hypers(pkg):
     npseed()
     bq = make_bq(pkg)

@@ -355,6 +355,56 @@ def test_c3_size_factorisation_property(engine):
     fit.close()
 
 
+def test_c5_full_size_shard(engine, oracle):
+    """BASELINE config 5 at full size: one rank's shard, 64 x (N = 2048, M = 256), through
+    the resident batched plan (outer block 256, batch in blockIdx.z) -- what bench.py
+    --workload c5 times.  Three problems against the oracle at the 1e-10 bar, all 64
+    through the single-problem entry point's invariants."""
+    B = 64
+    c = wl.c5(list(range(B)))
+    plan = engine.plan(B, 1, 2048, 256)
+    plan.set_inputs(c["x"], c["y"], c["xo"], c["h"], c["w"], c["s"])
+    plan.run()
+    mean, var, logml, status = plan.results()
+    plan.close()
+    assert (status == 0).all() and np.isfinite(logml).all()
+    k0 = oracle.kernel_scale(1, c["h"], c["w"])
+    assert (var > -1e-10 * k0).all() and (var <= k0 * (1 + 1e-12)).all()
+    for i in (0, 31, 63):
+        Lo, ao, lmo = oracle.gp_fit(c["x"][i], c["y"][i], c["h"], c["w"], c["s"])
+        mo, vo = oracle.gp_predict(c["x"][i], c["h"], c["w"], Lo, ao, c["xo"][i])
+        assert relmax(mean[i], mo) < RTOL
+        assert relmax(var[i], vo, scale=k0) < RTOL
+        assert abs(logml[i] - lmo) <= RTOL * abs(lmo)
+    # the same problems one at a time (another blocking, another launch sequence)
+    for i in (7, 40):
+        m1, v1, l1 = engine.fit_predict(c["x"][i], c["y"][i], c["h"], c["w"], c["s"], c["xo"][i])
+        assert relmax(mean[i], m1) < RTOL and relmax(var[i], v1, scale=k0) < RTOL
+        assert abs(logml[i] - l1) <= RTOL * abs(l1)
+
+
+def test_c3_full_size_grid(engine, oracle):
+    """BASELINE config 3 at full size: the 20 x 20 (h, w) log-ML grid at N = 4096, d = 2 in
+    chunks of 100 batched factorisations.  Corners and centre against the oracle and
+    against the single-fit path with its log-ML identity; every point finite."""
+    c = wl.c3()
+    lm = engine.logml_grid(c["x"], c["y"], c["h"], c["w"], c["s"], chunk=100)
+    assert lm.shape == (400,) and np.isfinite(lm).all()
+    for g in (0, 19, 210, 380, 399):
+        _, _, lmo = oracle.gp_fit(c["x"], c["y"], c["h"][g], c["w"][g], c["s"])
+        assert abs(lm[g] - lmo) <= RTOL * abs(lmo), (g, lm[g], lmo)
+        fit = engine.gp_fit(c["x"], c["y"], c["h"][g], c["w"][g], c["s"])
+        assert abs(lm[g] - fit.logml) <= RTOL * abs(fit.logml)
+        z, L = fit.z(), fit.L()
+        ref = -0.5 * z.dot(z) - np.log(np.diag(L)).sum() - 0.5 * 4096 * np.log(2 * np.pi)
+        assert abs(lm[g] - ref) <= RTOL * abs(ref)
+        fit.close()
+    # h enters only through K = h^2 G + s^2 I: monotone pieces are not asserted, but the
+    # grid must vary smoothly -- no point is a copy of its neighbour
+    assert len(np.unique(lm)) == 400
+    engine.trim()
+
+
 def test_c4_size_cholesky_property(engine):
     """N = 16384 (the MFMA roofline size) on device-resident data."""
     import ctypes as C

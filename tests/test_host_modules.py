@@ -199,3 +199,43 @@ def test_gp_memoisation_protocol(pkg):
     assert np.allclose(np.diag(g.cov(xo)), g.var(xo), atol=1e-12)
     assert g.Kxoxo(xo).shape == (5, 5) and g.Kxxo(xo).shape == (12, 5)
     assert g._x is g.x and g._y is g.y
+
+
+# ---- slice sampler: the reference's statistical checks (tests/test_util.py:20-49) --------
+def test_slice_sample_normal():
+    """10 000 draws from N(0, 1), 10 burn-in: the 10-bin density histogram stays within 0.02
+    of the pdf at the bin centres (the reference's bar, same seed)."""
+    from bayesian_quadrature_amd import util
+    np.random.seed(8728)
+
+    def logpdf(x):
+        return float((-(x[0] ** 2) / 2.0) - 0.5 * np.log(2 * np.pi))
+
+    samples = util.slice_sample(logpdf, 10000, np.array([1.0]), xval=np.array([0.0]), nburn=10,
+                                freq=1)
+    assert samples.shape == (9990, 1)
+    hist, bins = np.histogram(samples, bins=10, density=True)
+    centers = (bins[:-1] + bins[1:]) / 2.0
+    assert (np.abs(np.exp(-(centers ** 2) / 2.0) / np.sqrt(2 * np.pi) - hist) < 0.02).all()
+
+
+def test_slice_sample_uniform():
+    """U(0, 1) with hard walls (log-pdf -inf outside): 5 bins within 0.05 of 1."""
+    from bayesian_quadrature_amd import util
+    np.random.seed(8728)
+
+    def logpdf(x):
+        if x[0] > 1 or x[0] < 0:
+            return -np.inf
+        return 0.0
+
+    samples = util.slice_sample(logpdf, 10000, np.array([0.5]), xval=np.array([0.0]), nburn=10,
+                                freq=1)
+    hist, _ = np.histogram(samples, bins=5, density=True, range=[0, 1])
+    assert (np.abs(hist - 1) < 0.05).all()
+
+
+def test_slice_sample_zero_probability_start():
+    from bayesian_quadrature_amd import util
+    with pytest.raises(RuntimeError):
+        util.slice_sample(lambda x: -np.inf, 5, np.array([1.0]), xval=np.array([0.0]))
