@@ -1774,6 +1774,9 @@ struct bq_fit {
     DevBuf misc;  // info (int) + scal[4]
     DevBuf alpha; // npad, valid if have_alpha
     bool have_alpha = false;
+    // false from the start of a (re)factorisation until it has succeeded: a refit that hits a
+    // non-positive pivot leaves L, dinv, dw and the scalars overwritten with garbage
+    bool valid = false;
     double logml = 0, logdet = 0, qf = 0;
 };
 
@@ -1784,6 +1787,8 @@ int fit_factor(bq_ctx *c, bq_fit *f)
     const int ntot = f->L.ntot;
     int *info = f->misc.i();
     double *scal = f->misc.d() + 2;
+    f->valid = false;
+    f->have_alpha = false;
     HIPCHK(c, hipMemcpyAsync(f->gp.p, &f->g, sizeof f->g, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(info, 0, sizeof(int), c->stream));
     BQCHK(launch_assemble(c, f->d, f->pts.d(), 0, f->y.d(), 0, static_cast<GaussParams *>(f->gp.p),
@@ -1814,6 +1819,20 @@ int fit_factor(bq_ctx *c, bq_fit *f)
     f->logml = hs[0];
     f->logdet = hs[1];
     f->qf = hs[2];
+    f->valid = true;
+    return BQ_OK;
+}
+
+// every consumer of a fit: the handle exists and its last factorisation succeeded
+int check_fit(bq_ctx *c, const bq_fit *f)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    if (!f)
+        return fail(c, BQ_ERR_BAD_ARG, "null fit handle");
+    if (!f->valid)
+        return fail(c, BQ_ERR_NOT_PD,
+                    "fit holds no valid factor: its last (re)fit was not positive definite");
     return BQ_OK;
 }
 
@@ -1904,8 +1923,10 @@ extern "C" int bq_gp_fit(bq_ctx *c, const double *x, const double *y, int64_t d,
 
 extern "C" int bq_gp_refit(bq_ctx *c, bq_fit *f, double h, const double *w, double s)
 {
-    if (!c || !f)
+    if (!c)
         return BQ_ERR_BAD_ARG;
+    if (!f)
+        return fail(c, BQ_ERR_BAD_ARG, "null fit handle");
     BQCHK(check_w(c, f->d, h, w, s));
     HIPCHK(c, hipSetDevice(c->device));
     f->h = h;
@@ -1929,16 +1950,18 @@ extern "C" void bq_fit_destroy(bq_ctx *c, bq_fit *f)
 
 extern "C" int bq_gp_logml(bq_ctx *c, bq_fit *f, double *out)
 {
-    if (!c || !f || !out)
-        return BQ_ERR_BAD_ARG;
+    BQCHK(check_fit(c, f));
+    if (!out)
+        return fail(c, BQ_ERR_BAD_ARG, "illegal value");
     *out = f->logml;
     return BQ_OK;
 }
 
 extern "C" int bq_gp_get(bq_ctx *c, bq_fit *f, int which, double *out)
 {
-    if (!c || !f || !out)
-        return BQ_ERR_BAD_ARG;
+    BQCHK(check_fit(c, f));
+    if (!out)
+        return fail(c, BQ_ERR_BAD_ARG, "illegal value");
     HIPCHK(c, hipSetDevice(c->device));
     const int n = f->n;
     switch (which) {
@@ -1981,8 +2004,7 @@ extern "C" int bq_gp_get(bq_ctx *c, bq_fit *f, int which, double *out)
 extern "C" int bq_gp_predict(bq_ctx *c, bq_fit *f, const double *xo, int64_t M, double *mean,
                              double *var, double *cov)
 {
-    if (!c || !f)
-        return BQ_ERR_BAD_ARG;
+    BQCHK(check_fit(c, f));
     if (M < 0 || (M && !xo))
         return fail(c, BQ_ERR_BAD_ARG, "illegal value");
     if (M == 0)

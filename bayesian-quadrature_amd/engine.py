@@ -82,6 +82,11 @@ class Engine(object):
     def sync(self):
         self._check(self._lib.bq_ctx_sync(self._ctx))
 
+    def device_count(self):
+        n = C.c_int(0)
+        self._lib.bq_device_count(C.byref(n))
+        return n.value
+
     def info(self):
         name = C.create_string_buffer(64)
         cus, clk, mem = C.c_int(), C.c_int(), C.c_size_t()
@@ -245,14 +250,14 @@ class Engine(object):
     def Z_mean(self, fit_l, mu, cov):
         mu, cov = self._mc(fit_l.d, mu, cov)
         out = C.c_double()
-        self._check(self._lib.bq_bq_Z_mean(self._ctx, fit_l._h, L.dptr(mu), L.dptr(cov),
+        self._check(self._lib.bq_bq_Z_mean(self._ctx, fit_l._handle(), L.dptr(mu), L.dptr(cov),
                                            C.cast(C.byref(out), _dp)))
         return float(out.value)
 
     def Z_var(self, fit_tl, fit_l, mu, cov):
         mu, cov = self._mc(fit_l.d, mu, cov)
         out = C.c_double()
-        self._check(self._lib.bq_bq_Z_var(self._ctx, fit_tl._h, fit_l._h, L.dptr(mu), L.dptr(cov),
+        self._check(self._lib.bq_bq_Z_var(self._ctx, fit_tl._handle(), fit_l._handle(), L.dptr(mu), L.dptr(cov),
                                           C.cast(C.byref(out), _dp)))
         return float(out.value)
 
@@ -403,22 +408,27 @@ class Fit(object):
         except Exception:
             pass
 
+    def _handle(self):
+        if self._h is None or not self._h.value:
+            raise ValueError("fit is closed")
+        return self._h
+
     def refit(self, h, w, s):
         w = _wvec(w, self.d)
         e = self._eng
-        e._check(e._lib.bq_gp_refit(e._ctx, self._h, float(h), L.dptr(w), float(s)))
+        e._check(e._lib.bq_gp_refit(e._ctx, self._handle(), float(h), L.dptr(w), float(s)))
 
     @property
     def logml(self):
         v = C.c_double()
         e = self._eng
-        e._check(e._lib.bq_gp_logml(e._ctx, self._h, C.cast(C.byref(v), _dp)))
+        e._check(e._lib.bq_gp_logml(e._ctx, self._handle(), C.cast(C.byref(v), _dp)))
         return float(v.value)
 
     def _get(self, which, shape):
         out = np.empty(shape, order="F")
         e = self._eng
-        e._check(e._lib.bq_gp_get(e._ctx, self._h, which, L.dptr(out)))
+        e._check(e._lib.bq_gp_get(e._ctx, self._handle(), which, L.dptr(out)))
         return out
 
     def L(self):
@@ -441,7 +451,7 @@ class Fit(object):
             raise ValueError("b has invalid size")
         X = np.empty_like(B, order="F")
         e = self._eng
-        e._check(e._lib.bq_gp_solve(e._ctx, self._h, L.dptr(B), nrhs, L.dptr(X)))
+        e._check(e._lib.bq_gp_solve(e._ctx, self._handle(), L.dptr(B), nrhs, L.dptr(X)))
         return X
 
     def predict(self, xo, want_mean=True, want_var=True, want_cov=False):
@@ -453,7 +463,7 @@ class Fit(object):
         var = np.empty(M) if want_var else None
         cov = np.empty((M, M), order="F") if want_cov else None
         e = self._eng
-        e._check(e._lib.bq_gp_predict(e._ctx, self._h, L.dptr(xo), M, L.dptr(mean), L.dptr(var),
+        e._check(e._lib.bq_gp_predict(e._ctx, self._handle(), L.dptr(xo), M, L.dptr(mean), L.dptr(var),
                                       L.dptr(cov)))
         return mean, var, cov
 
@@ -479,9 +489,14 @@ class Plan(object):
         except Exception:
             pass
 
+    def _handle(self):
+        if self._h is None or not self._h.value:
+            raise ValueError("plan is closed")
+        return self._h
+
     def nbytes(self):
         v = C.c_size_t()
-        self._eng._check(self._eng._lib.bq_plan_bytes(self._h, C.byref(v)))
+        self._eng._check(self._eng._lib.bq_plan_bytes(self._handle(), C.byref(v)))
         return int(v.value)
 
     def set_inputs(self, x, y, xo, h, w, s):
@@ -507,12 +522,12 @@ class Plan(object):
             w = np.repeat(w.reshape(P, 1), d, axis=1)
         w = np.ascontiguousarray(w.reshape(P, d))
         e = self._eng
-        e._check(e._lib.bq_plan_set_inputs(e._ctx, self._h, L.dptr(xb), L.dptr(y), L.dptr(xob),
+        e._check(e._lib.bq_plan_set_inputs(e._ctx, self._handle(), L.dptr(xb), L.dptr(y), L.dptr(xob),
                                            L.dptr(h), L.dptr(w), L.dptr(s)))
 
     def run(self):
         e = self._eng
-        e._check(e._lib.bq_plan_run(e._ctx, self._h))
+        e._check(e._lib.bq_plan_run(e._ctx, self._handle()))
 
     def results(self):
         P, M = self.nprob, self.M
@@ -520,7 +535,7 @@ class Plan(object):
         logml = np.empty(P)
         status = np.zeros(P, dtype=np.int32)
         e = self._eng
-        e._check(e._lib.bq_plan_results(e._ctx, self._h, L.dptr(mean) if M else None,
+        e._check(e._lib.bq_plan_results(e._ctx, self._handle(), L.dptr(mean) if M else None,
                                         L.dptr(var) if M else None, L.dptr(logml),
                                         status.ctypes.data_as(L._i32p)))
         return mean, var, logml, status

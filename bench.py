@@ -6,10 +6,17 @@ Contract (one JSON line on stdout from rank 0):
 A "step" is one pass of the hot path over one batch of synthetic problems that
 are already resident in HBM: assemble the bordered Gaussian-kernel system,
 blocked fp64 Cholesky (MFMA trailing update), posterior mean/variance at the
-candidate points and the log marginal likelihood.  The default workload is
-BASELINE.json configs[1] (C2: d=1, N=1024, M=256); per-GPU work is fixed as N
-grows (weak scaling, no collective on the data path -- ranks only meet at the
-timing barrier).
+candidate points and the log marginal likelihood.  With one GPU the default
+workload is BASELINE.json configs[1] (C2: d=1, N=1024, M=256); with N > 1 it is the
+batched configs[4] (C5: 512 independent N=2048 problems over 8 GPUs = a block of 64
+problems per rank), per-GPU work fixed as N grows (weak scaling, no collective on
+the data path -- ranks only meet at the timing barrier).
+
+Ranks: under ``python -m torch.distributed.run --nproc-per-node N`` every rank reads
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.  Started bare with
+``--gpus N`` (N > 1) the parent process starts N fresh child processes with that
+environment itself -- before it has touched HIP in any way -- waits for them and
+exits non-zero if any of them fails; it never creates an engine and never re-execs.
 
 Extra objects on the same line:
     roofline      the dominant kernel class of the timed workload
@@ -63,12 +70,52 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c5"])
+    ap.add_argument("--workload", default=None, choices=["c2", "c5"],
+                    help="default: c2 on one GPU, c5 (the batched config) on several")
     ap.add_argument("--batch", type=int, default=0, help="problems per GPU per step (0 = default)")
     ap.add_argument("--no-extras", action="store_true", help="skip the C3/C4 roofline runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nb", type=int, default=0, help="outer Cholesky block override")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.workload is None:
+        a.workload = "c2" if a.gpus == 1 else "c5"
+    return a
+
+
+def self_launch(a):
+    """--gpus N > 1 without a launcher: start the N ranks as fresh child processes.
+    Nothing in this (parent) process has touched HIP or torch yet, and nothing will."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env))
+    rcs = [None] * len(procs)
+    # a rank that dies leaves the others in the gloo barrier: stop them instead of waiting
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                try:
+                    rcs[i] = p.wait(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    pass
+        if any(rc not in (None, 0) for rc in rcs):
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    p.terminate()
+    bad = [(i, rc) for i, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print("bench.py: rank(s) failed: %s" % bad, file=sys.stderr)
+        sys.exit(1)
+    sys.exit(0)
 
 
 class Dist(object):
@@ -87,8 +134,14 @@ class Dist(object):
             import torch.distributed as td
             td.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
             self.td, self.torch = td, torch
-        if gpus != self.world and self.rank == 0 and self.world > 1:
-            print("warning: --gpus %d but WORLD_SIZE %d" % (gpus, self.world), file=sys.stderr)
+
+    def gather(self, v):
+        """list of every rank's value (floats)"""
+        if self.td is None:
+            return [v]
+        out = [None] * self.world
+        self.td.all_gather_object(out, v)
+        return out
 
     def barrier(self):
         if self.td is not None:
@@ -150,6 +203,17 @@ def run_main(eng, wk, steps, warmup, dist):
     for _ in range(warmup):
         plan.run()
     eng.sync()
+    solo_ms = None
+    if dist.world > 1:
+        # the N = 1 reference of the scaling line, in the same run: rank 0 passes over ITS
+        # shard alone while the other ranks wait at the barrier (a few steps, untimed region)
+        if dist.rank == 0:
+            k = max(3, min(steps, 10))
+            eng.timer_start()
+            for _ in range(k):
+                plan.run()
+            solo_ms = eng.timer_stop_ms() / k
+        dist.barrier()
     dist.barrier()
     eng.timer_start()
     t0 = time.perf_counter()
@@ -160,6 +224,10 @@ def run_main(eng, wk, steps, warmup, dist):
     ev_ms = eng.timer_stop_ms()
     dist.barrier()
     wall = dist.max(t1 - t0)
+    ranks = dist.gather({"rank": dist.rank, "local_rank": dist.local_rank,
+                         "device": eng.device,
+                         "ms_per_step": (t1 - t0) / steps * 1e3,
+                         "ms_per_step_hip_events": ev_ms / steps, "pid": os.getpid()})
     mean, var, logml, status = plan.results()
     # the same K steps with the result read-back (sync + D2H) inside every step
     t2 = time.perf_counter()
@@ -183,7 +251,7 @@ def run_main(eng, wk, steps, warmup, dist):
     nbytes = plan.nbytes()
     plan.close()
     return dict(wall=wall, ev_ms=ev_ms, rb_ms=rb_ms, prof=prof, mean=mean, var=var, logml=logml,
-                status=status, plan_bytes=nbytes)
+                status=status, plan_bytes=nbytes, ranks=ranks, solo_ms=solo_ms)
 
 
 def parity_spotcheck(wk, res):
@@ -412,8 +480,14 @@ def batched_configs(eng):
 
 def main():
     a = parse()
-    dist = Dist(a.gpus)
-    # the engine must exist before torch could initialise a second HIP runtime
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world == 1:
+        self_launch(a)  # does not return
+    if a.gpus != world:
+        print("bench.py: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    # The engine (HIP context on LOCAL_RANK) exists before torch is imported; torch is used
+    # for the gloo barrier and reductions on CPU tensors only and never initialises HIP.
     from bayesian_quadrature_amd import Engine
     import ctypes as C
     from bayesian_quadrature_amd import _lib as L_
@@ -422,7 +496,16 @@ def main():
     if ndev.value <= 0:
         print("bench.py needs a HIP device (no CPU fallback)", file=sys.stderr)
         sys.exit(2)
-    eng = Engine(dist.local_rank % ndev.value)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one device per rank; BQ_BENCH_SHARE_DEVICE=1 lets several ranks share a device (the
+    # two-rank rehearsal on a one-GPU box in tests/test_sharding.py), never a measurement
+    share = os.environ.get("BQ_BENCH_SHARE_DEVICE", "0") == "1"
+    if ndev.value < world and not share:
+        print("bench.py: --gpus %d needs %d HIP devices, this box has %d"
+              % (a.gpus, world, ndev.value), file=sys.stderr)
+        sys.exit(2)
+    eng = Engine(local_rank % ndev.value)
+    dist = Dist(a.gpus)
     if a.nb:
         eng.set_block(a.nb)
     wk = make_workload(a.workload, a.batch, dist.rank)
@@ -471,7 +554,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": wk["desc"], "problems_per_gpu_per_step": wk["B"],
                        "bordered_system": ntot, "sharding": "independent problems per rank, "
-                       "no data-path collective"},
+                       "no data-path collective",
+                       "ranks": res["ranks"]},
             "ms_per_problem": res["wall"] / a.steps / wk["B"] * 1e3,
             "ms_per_step_hip_events": res["ev_ms"] / a.steps,
             "ms_per_step_with_readback": res["rb_ms"],
@@ -480,6 +564,14 @@ def main():
             "plan_bytes": res["plan_bytes"],
             "roofline": roof,
         }
+        if res["solo_ms"] is not None:
+            solo = wk["B"] / res["solo_ms"] * 1e3
+            line["single_rank_reference"] = {
+                "ms_per_step": res["solo_ms"], "problems_per_s": solo,
+                "parallel_efficiency_in_run": value / (solo * dist.world),
+                "note": "rank 0's shard of the same workload run alone (other ranks idle at "
+                        "the barrier) just before the timed region; informational -- the "
+                        "driver computes scaling from the per-N `value`s"}
         line["parity"] = parity_spotcheck(wk, res)
         if dist.world == 1:
             try:

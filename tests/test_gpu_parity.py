@@ -177,7 +177,17 @@ def test_gp_refit_and_not_pd(engine, oracle):
     assert abs(fit.logml - lmo) <= RTOL * abs(lmo)
     with pytest.raises(np.linalg.LinAlgError):
         fit.refit(1.0, 50 * w, 0.0)  # numerically singular Gaussian Gram
+    # the handle now holds a half-overwritten factor: every consumer refuses it ...
+    for use in (lambda: fit.logml, fit.alpha, fit.L, lambda: fit.predict(x[:3]),
+                lambda: fit.solve(y)):
+        with pytest.raises(np.linalg.LinAlgError):
+            use()
+    # ... until a refit succeeds again
+    fit.refit(0.7, 2 * w, 0.1)
+    assert abs(fit.logml - lmo) <= RTOL * abs(lmo)
     fit.close()
+    with pytest.raises(ValueError, match="closed"):
+        fit.alpha()
 
 
 def test_gp_2d(engine, oracle):

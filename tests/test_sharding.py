@@ -76,3 +76,95 @@ def test_two_rank_gloo_matches_single_process(oracle):
         assert all_idx == [0, 1, 2, 3, 4] and gall == [0, 1, 2]
         assert (gmean == mean).all() and (gvar == var).all() and (glogml == logml).all()
         assert (glm == ref_lm).all()
+
+
+# ---- the same path on the real engine: two processes, two HIP contexts ------------------
+def _gpu_worker(rank, world, port, q):
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port), "LOCAL_RANK": str(rank)})
+    sys.path.insert(0, ROOT)
+    from bayesian_quadrature_amd import Engine      # the HIP context first, torch after
+    eng = Engine(0)                                  # a one-GPU box: both ranks on device 0
+    import torch.distributed as td
+    td.init_process_group(backend="gloo", rank=rank, world_size=world)
+    from bayesian_quadrature_amd import shard as sh
+    from bayesian_quadrature_amd import workloads as wl
+    c = wl.c5(list(range(7)), n=300, m=40)
+    idx, mean, var, logml, status = sh.batch_fit_predict_sharded(
+        eng, c["x"], c["y"], c["xo"], c["h"], c["w"] * 10, c["s"])
+    all_idx, (gmean, gvar, glogml, gstatus) = sh.gather(idx, [mean, var, logml, status])
+    td.barrier()
+    q.put((rank, idx, all_idx, gmean, gvar, glogml, gstatus))
+    td.destroy_process_group()
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_two_ranks_real_engines_match_single_process(engine, oracle):
+    """world_size 2, one process and one HIP context per rank (both on device 0 of the
+    one-GPU test box), block partition, gloo gather: the merged result equals what one
+    process computes for all problems, and the oracle's."""
+    import torch.multiprocessing as mp
+    from bayesian_quadrature_amd import workloads as wl
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert outs[0][1] == [0, 1, 2, 3] and outs[1][1] == [4, 5, 6]
+    c = wl.c5(list(range(7)), n=300, m=40)
+    mean, var, logml, status = engine.batch_fit_predict(c["x"], c["y"], c["h"], c["w"] * 10,
+                                                        c["s"], c["xo"])
+    k0 = oracle.kernel_scale(1, c["h"], c["w"] * 10)
+    for rank, idx, all_idx, gmean, gvar, glogml, gstatus in outs:
+        assert all_idx == list(range(7)) and (gstatus == 0).all()
+        assert np.max(np.abs(gmean - mean)) <= 1e-10 * np.max(np.abs(mean))
+        assert np.max(np.abs(gvar - var)) <= 1e-10 * k0
+        assert np.max(np.abs(glogml - logml) / np.abs(logml)) <= 1e-10
+    for i in (0, 6):
+        Lo, ao, lmo = oracle.gp_fit(c["x"][i], c["y"][i], c["h"], c["w"] * 10, c["s"])
+        assert abs(outs[0][5][i] - lmo) <= 1e-10 * abs(lmo)
+
+
+def _run_bench(args, env_extra):
+    import subprocess
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env,
+                          capture_output=True, text=True, timeout=900)
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks(engine):
+    """``bench.py --gpus 2`` started bare spawns two ranks itself.  On a one-GPU box that
+    must fail loudly; with BQ_BENCH_SHARE_DEVICE=1 (rehearsal only) the two ranks share the
+    device and the line reports n_gpus 2 with two distinct ranks / processes."""
+    import json
+    ndev = engine.device_count()
+    args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-extras",
+            "--no-cpu-baseline"]
+    if ndev < 2:
+        r = _run_bench(args, {})
+        assert r.returncode != 0
+        assert "needs 2 HIP devices" in r.stderr
+    r = _run_bench(args, {"BQ_BENCH_SHARE_DEVICE": "1"} if ndev < 2 else {})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] is not None and line["failed_problems"] == 0
+    assert line["config"]["workload"].startswith("C5")
+    ranks = line["config"]["ranks"]
+    assert sorted(r_["rank"] for r_ in ranks) == [0, 1]
+    assert len({r_["pid"] for r_ in ranks}) == 2
+    assert line["single_rank_reference"]["ms_per_step"] > 0
+    assert line["parity"]["logml_rel"] < 1e-10
