@@ -398,8 +398,8 @@ int launch_potf2(bq_ctx *c, double *A, long lda, long astride, int j0, double *d
         hipLaunchKernelGGL(potf2_64_kernel, dim3(1, 1, batch), dim3(64), 0, c->cur, A, lda,
                            astride, j0, dinv, dstride, info);
     else
-        hipLaunchKernelGGL(potf2_64x4_kernel, dim3(1, 1, batch), dim3(256), 0, c->cur, A, lda,
-                           astride, j0, dinv, dstride, info);
+        hipLaunchKernelGGL(potf2_kernel, dim3(1, 1, batch), dim3(256), 0, c->cur, A, lda, astride,
+                           j0, dinv, dstride, info);
     HIPCHK(c, hipGetLastError());
     return BQ_OK;
 }
@@ -2262,6 +2262,58 @@ extern "C" int bq_probe_rsq(bq_ctx *c, const double *x, int64_t n, double *err3)
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(err3, od.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost,
                              c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BQ_OK;
+}
+
+// The diagonal factor alone: A (64 x 64 host, column-major) is factored `reps` times from a
+// resident copy; L_out / dinv_out (BQ_DINV_HALF doubles) / info_out are the last launch's
+// results, us_per_launch the HIP-event average, stamps5 the in-kernel s_memtime stamps
+// (entry, block loaded, pivot chain done, sub-blocks in LDS, end; 100 MHz ticks).
+extern "C" int bq_probe_potf2(bq_ctx *c, const double *A, int from_lds, int64_t reps,
+                              double *L_out, double *dinv_out, int32_t *info_out,
+                              double *us_per_launch, int64_t *stamps5)
+{
+    if (!c || !A || reps < 1)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf ain, a, dv, inf, st;
+    HIPCHK(c, ain.alloc(sizeof(double) * 4096));
+    HIPCHK(c, a.alloc(sizeof(double) * 4096));
+    HIPCHK(c, dv.alloc(sizeof(double) * BQ_DINV_STRIDE));
+    HIPCHK(c, inf.alloc(64));
+    HIPCHK(c, st.alloc(64));
+    HIPCHK(c, hipMemcpyAsync(ain.p, A, sizeof(double) * 4096, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(inf.p, 0, 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(a.p, 0, sizeof(double) * 4096, c->stream));
+    auto launch = [&]() {
+        hipLaunchKernelGGL(potf2_probe_kernel, dim3(1), dim3(256), 0, c->stream, ain.d(), a.d(),
+                           64L, dv.d(), inf.i(), static_cast<long long *>(st.p), from_lds);
+    };
+    for (int i = 0; i < 5; ++i)
+        launch();
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemsetAsync(inf.p, 0, 64, c->stream));
+    float ms = 0;
+    BQCHK(bq_timer_start(c));
+    for (int64_t i = 0; i < reps; ++i)
+        launch();
+    BQCHK(bq_timer_stop_ms(c, &ms));
+    HIPCHK(c, hipGetLastError());
+    if (us_per_launch)
+        *us_per_launch = ms * 1e3 / (double)reps;
+    if (L_out)
+        HIPCHK(c, hipMemcpyAsync(L_out, a.p, sizeof(double) * 4096, hipMemcpyDeviceToHost,
+                                 c->stream));
+    if (dinv_out)
+        HIPCHK(c, hipMemcpyAsync(dinv_out, dv.p, sizeof(double) * BQ_DINV_HALF,
+                                 hipMemcpyDeviceToHost, c->stream));
+    if (info_out)
+        HIPCHK(c, hipMemcpyAsync(info_out, inf.p, sizeof(int32_t), hipMemcpyDeviceToHost,
+                                 c->stream));
+    if (stamps5)
+        HIPCHK(c, hipMemcpyAsync(stamps5, st.p, sizeof(int64_t) * 5, hipMemcpyDeviceToHost,
+                                 c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return BQ_OK;
 }

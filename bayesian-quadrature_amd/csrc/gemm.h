@@ -342,8 +342,7 @@ __global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C
                                                           double *__restrict__ dinv, long dstride,
                                                           int *__restrict__ info)
 {
-    __shared__ __attribute__((aligned(16))) double ring[4 * 4 * 64 + 64]; // three panel slots; then the four 16x16 blocks + 64 pivots
-    __shared__ int sbad[4];
+    __shared__ __attribute__((aligned(16))) double plds[BQ_POTF2_LDS_DOUBLES]; // the fused diagonal factor's LDS
     // the small-tile forms are the panel's own updates: on the look-ahead stream they share
     // CUs with the bulk trailing update and sit on the critical path, so they issue first
     if (TM < 4)
@@ -374,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C
                 }
             }
         __syncthreads(); // the updated block is visible to the whole workgroup
-        potf2_64x4_body(C, ldc, fuse_j0, dinv + (long)b * dstride, info + b, ring, sbad);
+        potf2_body(C, ldc, fuse_j0, dinv + (long)b * dstride, info + b, plds);
         return;
     }
     const int row0 = (bx * 2 + (wave & 1)) * (TM * 16);
@@ -482,8 +481,7 @@ __global__ __launch_bounds__(256) void gemm_k64_kernel(double *__restrict__ C, l
                                                        double *__restrict__ dinv, long dstride,
                                                        int *__restrict__ info)
 {
-    __shared__ __attribute__((aligned(16))) double ring[4 * 4 * 64 + 64]; // three panel slots; then the four 16x16 blocks + 64 pivots
-    __shared__ int sbad[4];
+    __shared__ __attribute__((aligned(16))) double plds[BQ_POTF2_LDS_DOUBLES]; // the fused diagonal factor's LDS
     __builtin_amdgcn_s_setprio(3); // panel-internal update: see gemm_sub_kernel
     const int b = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -507,7 +505,7 @@ __global__ __launch_bounds__(256) void gemm_k64_kernel(double *__restrict__ C, l
                                           lane);
             }
         __syncthreads();
-        potf2_64x4_body(C, ldc, fuse_j0, dinv + (long)b * dstride, info + b, ring, sbad);
+        potf2_body(C, ldc, fuse_j0, dinv + (long)b * dstride, info + b, plds);
         return;
     }
     const int row0 = (bx * 2 + (wave & 1)) * (TM * 16);

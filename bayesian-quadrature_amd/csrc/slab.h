@@ -74,10 +74,14 @@ __global__ __launch_bounds__(256) void slab_step_kernel(double *__restrict__ A, 
 {
     // Q rows of the tile, [k][row] (A-fragment reads are contiguous over rows)
     __shared__ __attribute__((aligned(16))) double Qs[64 * 64];
-    // workgroup 0: the updated diagonal block on its way to the factor, and the factor's ring
+    // workgroup 0: the updated diagonal block on its way to the factor, and the factor's LDS
+#if BQ_POTF2_SRC_IN_LDS
+    __shared__ __attribute__((aligned(16))) double plds[BQ_POTF2_LDS_DOUBLES];
+    double *const Ts = plds; // the block sits where the factor's panel slots will be
+#else
     __shared__ __attribute__((aligned(16))) double Ts[64 * 64];
-    __shared__ __attribute__((aligned(16))) double ring[4 * 4 * 64 + 64];
-    __shared__ int sbad[4];
+    __shared__ __attribute__((aligned(16))) double plds[BQ_POTF2_LDS_DOUBLES];
+#endif
     __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63;
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256) void slab_step_kernel(double *__restrict__ A, 
             for (int r = 0; r < 4; ++r)
                 Ts[16 * wave + l15 + 64 * (16 * cb + l4 + 4 * r)] = -acc[cb][r];
         __syncthreads();
-        potf2_64x4_body(A + r0 + (long)r0 * lda, lda, r0, dout, info + b, ring, sbad, Ts, 64);
+        potf2_body(A + r0 + (long)r0 * lda, lda, r0, dout, info + b, plds, Ts, 64);
         return;
     }
     const bool to_s = by == 0 && bx > 0 && !last;
@@ -194,13 +198,12 @@ __global__ __launch_bounds__(256) void slab_first_kernel(double *__restrict__ A,
                                                          double *__restrict__ dinv, long dstride,
                                                          int *__restrict__ info)
 {
-    __shared__ __attribute__((aligned(16))) double ring[4 * 4 * 64 + 64];
-    __shared__ int sbad[4];
+    __shared__ __attribute__((aligned(16))) double plds[BQ_POTF2_LDS_DOUBLES];
     const int b = blockIdx.z;
     A += (long)b * astride;
     if (blockIdx.x == 0) {
         __builtin_amdgcn_s_setprio(3);
-        potf2_64x4_body(A, lda, 0, dinv + (long)b * dstride, info + b, ring, sbad);
+        potf2_body(A, lda, 0, dinv + (long)b * dstride, info + b, plds);
         return;
     }
     // 64 rows x 64 columns per workgroup: thread t copies row (t & 63) of 16 columns
@@ -242,9 +245,13 @@ __global__ __launch_bounds__(256) void panel_step_kernel(double *__restrict__ A,
                                                          int *__restrict__ info)
 {
     __shared__ __attribute__((aligned(16))) double Qs[64 * 64];
+#if BQ_POTF2_SRC_IN_LDS
+    __shared__ __attribute__((aligned(16))) double plds[BQ_POTF2_LDS_DOUBLES];
+    double *const Ts = plds; // the block sits where the factor's panel slots will be
+#else
     __shared__ __attribute__((aligned(16))) double Ts[64 * 64];
-    __shared__ __attribute__((aligned(16))) double ring[4 * 4 * 64 + 64];
-    __shared__ int sbad[4];
+    __shared__ __attribute__((aligned(16))) double plds[BQ_POTF2_LDS_DOUBLES];
+#endif
     __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63;
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(256) void panel_step_kernel(double *__restrict__ A,
             for (int r = 0; r < 4; ++r)
                 Ts[16 * wave + l15 + 64 * (16 * cb + l4 + 4 * r)] = -acc[cb][r];
         __syncthreads();
-        potf2_64x4_body(A + r0 + (long)r0 * lda, lda, r0, dout, info + b, ring, sbad, Ts, 64);
+        potf2_body(A + r0 + (long)r0 * lda, lda, r0, dout, info + b, plds, Ts, 64);
         return;
     }
     double *Cout = Sout + Rb + 16 * wave + l15 + (long)l4 * lds;
