@@ -89,6 +89,7 @@ SIGNATURES = {
     "bq_probe_mfma444_layout": (C.c_int, [_vp, C.c_int, C.c_int, _i32p]),
     "bq_probe_rsq": (C.c_int, [_vp, _dp, _i64, _dp]),
     "bq_probe_launch": (C.c_int, [_vp, _i64, _dp]),
+    "bq_probe_c2_timeline": (C.c_int, [_vp, _vp, C.POINTER(C.c_int64), _i64]),
     "bq_probe_potf2": (C.c_int, [_vp, _dp, C.c_int, _i64, _dp, _dp, C.POINTER(C.c_int32), _dp,
                                  C.POINTER(C.c_int64)]),
     "bq_probe_mfma_layout": (C.c_int, [_vp, _dp]),

@@ -77,16 +77,9 @@ struct bq_ctx {
     hipStream_t cur = nullptr;    // stream the launch helpers enqueue on (stream or aux)
     hipEvent_t ev_panel = nullptr, ev_next = nullptr, ev_fork = nullptr;
     int lookahead = 1;
-    int potf2_waves = 4; // 4: potf2_64x4_kernel, 1: potf2_64_kernel (BQ_POTF2_WAVES)
     int la_min = 4096;   // look-ahead only while the bulk update has at least this many rows (BQ_LA_MIN)
-    int slab_fuse = 1;   // one launch per 64-column step of small systems (BQ_SLAB)
     DevBuf panel_ws;     // scratch panel columns of the eager linalg entry points
-    int trsm_blk = 1;    // MFMA panel solve from 16x16 block inverses (BQ_TRSM_BLK)
     int gemm_lds = 1;    // LDS-staged 128x128 trailing update (BQ_GEMM_LDS)
-    int tile_order = 0;  // 2: XCD-aware super-tile order of the triangular tile list (BQ_TILE_ORDER)
-    int mfma444 = 1;     // trailing / panel updates on v_mfma_f64_4x4x4_4b_f64 (BQ_MFMA444)
-    int fuse = 1;        // diagonal factor fused into the launch that last updates it (BQ_FUSE)
-    int gram_nt = 0;     // non-temporal stores in the Gram kernel (BQ_GRAM_NT)
     int use_graph = 1;   // replay plans from a captured hipGraph (BQ_GRAPH=0 disables)
     bool own_stream = false;
     int cus = 256;
@@ -103,6 +96,7 @@ struct bq_ctx {
     GaussParams gbuf_host{};
     bool gbuf_valid = false;
     DevBuf dinv64; // potf2 reciprocal-diagonal scratch
+    long long *stamp_buf = nullptr; // bq_probe_c2_timeline: 16 stamps per slab step
 };
 
 namespace {
@@ -215,7 +209,7 @@ void launch_gram_sym_d(bq_ctx *c, const double *x, long xstride, const GaussPara
 {
     dim3 grid((n + 127) / 128, (n + 63) / 64, batch);
     hipLaunchKernelGGL(gram_sym_kernel<D>, grid, dim3(256), 0, c->cur, x, xstride, gp, gpstride,
-                       K, ldk, kstride, n, c->gram_nt);
+                       K, ldk, kstride, n);
 }
 
 int launch_gram_sym(bq_ctx *c, int d, const double *x, long xstride, const GaussParams *gp,
@@ -309,7 +303,7 @@ static bool gemm_uses_lds(const bq_ctx *c, int m, int n, int k, int lower, int b
     long a = (long)((m + 127) / 128) * ((n + 127) / 128) * batch;
     if (lower)
         a = a / 2 + 1;
-    return c->gemm_lds && c->mfma444 && a >= c->cus && n >= 128 && (m % 64) == 0 &&
+    return c->gemm_lds && a >= c->cus && n >= 128 && (m % 64) == 0 &&
            (n % 64) == 0 && (k % 32) == 0;
 }
 
@@ -343,7 +337,7 @@ int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const dou
     };
     // the 4x4x4 four-block MFMA sustains ~1.5x the rate of the 16x16x4 form on gfx950; it
     // needs unit-stride Q rows and whole wave tiles (every padded system here has them)
-    const bool f444 = c->mfma444 && qsj == 1 && (m % 64) == 0 && (n % 64) == 0;
+    const bool f444 = qsj == 1 && (m % 64) == 0 && (n % 64) == 0;
 #define BQ_GEMM_SUB(TM_, TN_, T_)                                                                  \
     do {                                                                                           \
         if (f444)                                                                                  \
@@ -359,14 +353,8 @@ int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const dou
     if (tiles(128) >= cu && n >= 128) {
         if (f444 && fuse_j0 < 0 && gemm_uses_lds(c, m, n, k, lower, batch)) {
             dim3 g = grid_for(128);
-            const int order = tri ? c->tile_order : 0;
-            if (order == 2) { // super-tile list of the triangle rounded up to 8 tiles a side
-                const unsigned ts = ((unsigned)((m + 127) / 128) + 7) / 8;
-                g.x = 32 * ts * ts + 4 * ts;
-            }
             hipLaunchKernelGGL(gemm_lds_kernel, g, dim3(256), BQ_LDS_BYTES, c->cur,
-                               C, ldc, cstride, P, ldp, pstride, Q, qsk, qstride, m, n, k, mode,
-                               order);
+                               C, ldc, cstride, P, ldp, pstride, Q, qsk, qstride, m, n, k, mode);
         } else {
             BQ_GEMM_SUB(4, 4, 128);
         }
@@ -394,11 +382,7 @@ int launch_potf2(bq_ctx *c, double *A, long lda, long astride, int j0, double *d
                  int *info, int batch)
 {
     Bracket br(c, BQ_K_POTF2, 64.0 * 64 * 64 / 3.0 * batch);
-    if (c->potf2_waves == 1)
-        hipLaunchKernelGGL(potf2_64_kernel, dim3(1, 1, batch), dim3(64), 0, c->cur, A, lda,
-                           astride, j0, dinv, dstride, info);
-    else
-        hipLaunchKernelGGL(potf2_kernel, dim3(1, 1, batch), dim3(256), 0, c->cur, A, lda, astride,
+    hipLaunchKernelGGL(potf2_kernel, dim3(1, 1, batch), dim3(256), 0, c->cur, A, lda, astride,
                            j0, dinv, dstride, info);
     HIPCHK(c, hipGetLastError());
     return BQ_OK;
@@ -445,7 +429,7 @@ int auto_nb(const bq_ctx *c, int ntot, int batch)
     // must be wide (256: 46 GB instead of 183 GB of traffic at N=16384), when they do
     // a narrow block means fewer, shorter launches
     const double mb = 8.0 * (double)ntot * ntot * batch / 1e6;
-    if (batch <= 2 && c->slab_fuse && c->trsm_blk && c->potf2_waves == 4) {
+    if (batch <= 2) {
         // One or two matrices cannot fill the chip with a 64-column panel: the sweep is a
         // chain of dependent launches and the one-launch step of outer block 64 (slab.h) is
         // the shortest chain until the k = 64 updates cost more than it saves
@@ -474,7 +458,7 @@ int enqueue_panel(bq_ctx *c, double *A, long lda, long astride, int batch, int n
                   int KB, double *dinv, int *info, bool diag_done, double *ws = nullptr)
 {
     // (a batch fills the chip without this: the redundant solves then only cost throughput)
-    if (ws && batch <= 2 && c->slab_fuse && c->trsm_blk && c->potf2_waves == 4) {
+    if (ws && batch <= 2) {
         if (!diag_done)
             BQCHK(launch_potf2(c, A, lda, astride, K0, dinv, BQ_DINV_STRIDE, info, batch));
         if (ntot - K0 - 64 <= 0)
@@ -505,7 +489,7 @@ int enqueue_panel(bq_ctx *c, double *A, long lda, long astride, int batch, int n
     for (int j0 = K0; j0 < K0 + KB; j0 += 64) {
         double *Ajj = A + j0 + (long)j0 * lda;
         if (j0 > K0) {
-            const int fj = c->fuse ? j0 : -1;
+            const int fj = j0;
             BQCHK(launch_gemm(c, BQ_K_GEMM, Ajj, lda, astride, A + j0 + (long)K0 * lda, lda,
                               astride, A + j0 + (long)K0 * lda, 1, lda, astride, ntot - j0, 64,
                               j0 - K0, 0, batch, fj, dinv, BQ_DINV_STRIDE, info));
@@ -514,12 +498,8 @@ int enqueue_panel(bq_ctx *c, double *A, long lda, long astride, int batch, int n
         } else if (!diag_done) {
             BQCHK(launch_potf2(c, A, lda, astride, j0, dinv, BQ_DINV_STRIDE, info, batch));
         }
-        if (c->trsm_blk && c->potf2_waves == 4)
-            BQCHK(launch_trsm_blk(c, Ajj + 64, lda, astride, ntot - j0 - 64, Ajj, lda, astride,
-                                  dinv, BQ_DINV_STRIDE, batch));
-        else
-            BQCHK(launch_trsm<true>(c, Ajj + 64, lda, astride, ntot - j0 - 64, Ajj, lda, astride,
-                                    dinv, BQ_DINV_STRIDE, batch));
+        BQCHK(launch_trsm_blk(c, Ajj + 64, lda, astride, ntot - j0 - 64, Ajj, lda, astride, dinv,
+                              BQ_DINV_STRIDE, batch));
     }
     return BQ_OK;
 }
@@ -541,8 +521,7 @@ size_t panel_ws_doubles(int ntot, int batch) { return ((size_t)2 * 64 * ntot + 4
 // block size in force now): callers that own long-lived workspaces skip the allocation else
 bool panel_ws_useful(const bq_ctx *c, int ntot, int batch)
 {
-    return c->slab_fuse && c->trsm_blk && c->potf2_waves == 4 &&
-           (batch <= 2 || auto_nb(c, ntot, batch) == 64);
+    return batch <= 2 || auto_nb(c, ntot, batch) == 64;
 }
 
 // Outer block 64 (small systems): one launch per 64-column step (slab.h) after the first
@@ -571,10 +550,18 @@ int enqueue_slab_sweep(bq_ctx *c, double *A, long lda, long astride, int batch, 
         const double m = (double)(ntot - r0);
         // the tile updates (lower half of 2 m^2 64) and the solve of the panel (m 64^2)
         Bracket br(c, BQ_K_SYRK_SMALL, (m * m * 64.0 + m * 64.0 * 64.0) * batch);
-        hipLaunchKernelGGL(slab_step_kernel, dim3(T * (T + 1) / 2, 1, batch), dim3(256), 0, c->cur,
-                           A, lda, astride, S[par], S[par ^ 1], (long)ntot, sstride, ntot, j0,
-                           dinv + par * BQ_DINV_HALF, dinv + (par ^ 1) * BQ_DINV_HALF,
-                           (long)BQ_DINV_STRIDE, fnext, !fnext, info);
+        if (c->stamp_buf)
+            hipLaunchKernelGGL(slab_step_kernel<true>, dim3(T * (T + 1) / 2, 1, batch), dim3(256),
+                               0, c->cur, A, lda, astride, S[par], S[par ^ 1], (long)ntot, sstride,
+                               ntot, j0, dinv + par * BQ_DINV_HALF,
+                               dinv + (par ^ 1) * BQ_DINV_HALF, (long)BQ_DINV_STRIDE, fnext,
+                               !fnext, info, c->stamp_buf + 16 * (j0 / 64));
+        else
+            hipLaunchKernelGGL(slab_step_kernel<false>, dim3(T * (T + 1) / 2, 1, batch), dim3(256),
+                               0, c->cur, A, lda, astride, S[par], S[par ^ 1], (long)ntot, sstride,
+                               ntot, j0, dinv + par * BQ_DINV_HALF,
+                               dinv + (par ^ 1) * BQ_DINV_HALF, (long)BQ_DINV_STRIDE, fnext,
+                               !fnext, info, (long long *)nullptr);
         HIPCHK(c, hipGetLastError());
     }
     return BQ_OK;
@@ -588,7 +575,7 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
         return fail(c, BQ_ERR_BAD_ARG, "potrf: sizes must be multiples of 64");
     const int NB = auto_nb(c, ntot, batch);
     double *ws = (panel_ws && panel_ws_len >= panel_ws_doubles(ntot, batch)) ? panel_ws : nullptr;
-    if (NB == 64 && c->slab_fuse && c->trsm_blk && c->potf2_waves == 4 && ws && ncols >= 64)
+    if (NB == 64 && ws && ncols >= 64)
         return enqueue_slab_sweep(c, A, lda, astride, batch, ntot, ncols, dinv, info, ws);
     const bool la = c->lookahead && c->aux && NB >= 128 && ncols > NB;
     int K0 = 0;
@@ -633,7 +620,7 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
                 // (a wide panel's update is worth the LDS-staged kernel, which carries no
                 // fused diagonal factor: enqueue_panel then factors the block itself)
                 const int fj =
-                    (c->fuse && !gemm_uses_lds(c, ntot - r0, nw, KB, 1, batch)) ? r0 : -1;
+                    !gemm_uses_lds(c, ntot - r0, nw, KB, 1, batch) ? r0 : -1;
                 st = launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda,
                                  astride, P, 1, lda, astride, ntot - r0, nw, KB, 1, batch, fj, dinv,
                                  BQ_DINV_STRIDE, info);
@@ -678,7 +665,7 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
         if (r0 < ntot) {
             const double *P = A + r0 + (long)K0 * lda;
             // the trailing update also factors the next diagonal block if there is one
-            const int fj = (c->fuse && r0 < ncols &&
+            const int fj = (r0 < ncols &&
                             !gemm_uses_lds(c, ntot - r0, ntot - r0, KB, 1, batch))
                                ? r0
                                : -1;
@@ -698,7 +685,7 @@ int enqueue_forward_rows(bq_ctx *c, double *X, long ldx, int mrows, const double
 {
     for (int jb = 0; jb < npad; jb += 64) {
         const double *L11 = L + jb + (long)jb * ldl;
-        if (dw && c->trsm_blk && (mrows & 15) == 0)
+        if (dw && (mrows & 15) == 0)
             BQCHK(launch_trsm_blk(c, X + (long)jb * ldx, ldx, 0, mrows, L11, ldl, 0,
                                   dw + (long)(jb / 64) * BQ_DINV_HALF, 0, 1));
         else
@@ -789,24 +776,10 @@ static int ctx_init(bq_ctx *c, int device)
         c->lookahead = std::atoi(e);
     if (const char *e = std::getenv("BQ_LA_MIN"))
         c->la_min = std::atoi(e);
-    if (const char *e = std::getenv("BQ_SLAB"))
-        c->slab_fuse = std::atoi(e);
-    if (const char *e = std::getenv("BQ_TRSM_BLK"))
-        c->trsm_blk = std::atoi(e);
     if (const char *e = std::getenv("BQ_GEMM_LDS"))
         c->gemm_lds = std::atoi(e);
-    if (const char *e = std::getenv("BQ_TILE_ORDER"))
-        c->tile_order = std::atoi(e);
-    if (const char *e = std::getenv("BQ_MFMA444"))
-        c->mfma444 = std::atoi(e);
-    if (const char *e = std::getenv("BQ_FUSE"))
-        c->fuse = std::atoi(e);
-    if (const char *e = std::getenv("BQ_GRAM_NT"))
-        c->gram_nt = std::atoi(e);
     if (const char *e = std::getenv("BQ_GRAPH"))
         c->use_graph = std::atoi(e);
-    if (const char *e = std::getenv("BQ_POTF2_WAVES"))
-        c->potf2_waves = std::atoi(e) == 1 ? 1 : 4;
     return BQ_OK;
 }
 
@@ -1500,14 +1473,14 @@ extern "C" int bq_plan_run(bq_ctx *c, bq_plan *p)
         return plan_enqueue(c, p);
     // settings that change the launch sequence invalidate the captured graph
     if (p->graph_state == 1 && (p->graph_nb != c->nb_override || p->graph_la != c->lookahead ||
-                                p->graph_pw != c->la_min * 64 + c->slab_fuse * 32 + c->potf2_waves * 16 + c->trsm_blk * 8 + c->gemm_lds * 4 + c->fuse * 2 + c->mfma444)) {
+                                p->graph_pw != c->la_min * 2 + c->gemm_lds)) {
         plan_drop_graph(p);
         p->graph_state = 0;
     }
     if (p->graph_state == 0) {
         p->graph_nb = c->nb_override;
         p->graph_la = c->lookahead;
-        p->graph_pw = c->la_min * 64 + c->slab_fuse * 32 + c->potf2_waves * 16 + c->trsm_blk * 8 + c->gemm_lds * 4 + c->fuse * 2 + c->mfma444;
+        p->graph_pw = c->la_min * 2 + c->gemm_lds;
         p->graph_state = -1;
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
             const int st = plan_enqueue(c, p);
@@ -2262,6 +2235,27 @@ extern "C" int bq_probe_rsq(bq_ctx *c, const double *x, int64_t n, double *err3)
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(err3, od.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost,
                              c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BQ_OK;
+}
+
+// One eager (not graph-replayed) pass of a plan with the profiling instantiation of the slab
+// step: stamps[16 * step + k] = s_memtime of workgroup 0 at (0) entry, (1) factor fragments
+// loaded, (2) panel rows solved, (3) tile loaded + Q in LDS, (4) tile updated, (5..9) the
+// diagonal factor's entry / block in registers / pivot chain done / sub-blocks in LDS / end.
+extern "C" int bq_probe_c2_timeline(bq_ctx *c, bq_plan *p, int64_t *stamps, int64_t nsteps)
+{
+    if (!c || !p || !stamps || nsteps < 1 || nsteps > 1024)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf st;
+    HIPCHK(c, st.alloc(sizeof(long long) * 16 * (size_t)nsteps));
+    HIPCHK(c, hipMemsetAsync(st.p, 0, st.bytes, c->stream));
+    c->stamp_buf = static_cast<long long *>(st.p);
+    int rc = plan_enqueue(c, p);
+    c->stamp_buf = nullptr;
+    BQCHK(rc);
+    HIPCHK(c, hipMemcpyAsync(stamps, st.p, st.bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return BQ_OK;
 }

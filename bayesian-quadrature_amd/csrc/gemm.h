@@ -16,37 +16,6 @@ __device__ __forceinline__ void tri_decode(int t, int &bx, int &by)
     by = t - bx * (bx + 1) / 2;
 }
 
-// XCD-aware order of the lower-triangular workgroup-tile list.  Hardware sends workgroup id
-// to XCD id % 8, and every XCD has its own L2.  Row by row, the 64 workgroups resident on
-// one XCD hold ~5 different P row blocks and ~60 different Q row blocks: about half of
-// their operand chunks miss L2 (TCC_MISS, PMC) and cross the fabric.  Here the tile
-// triangle is cut into 8 x 8 super-tiles (diagonal ones hold 36 tiles), listed super-tile
-// by super-tile, and inside every run of 512 workgroup ids XCD x takes list entries
-// [64 x, 64 x + 64): its 64 resident workgroups share 8 P and 8 Q row blocks.
-// Returns false for ids that fall outside the triangle (the triangle side is rounded up to
-// a multiple of 8 tiles; those workgroups exit at once).
-__device__ __forceinline__ bool supertile_decode(int id, int nid, int tn, int &bx, int &by)
-{
-    // the last, partial run of 512 ids keeps the list order
-    const int u = id < (nid & ~511) ? (id & ~511) + ((id & 7) << 6) + ((id >> 3) & 63) : id;
-    int sx = (int)((__builtin_sqrt(16.0 + 128.0 * u) - 4.0) * (1.0 / 64.0));
-    while (32 * (sx + 1) * (sx + 1) + 4 * (sx + 1) <= u)
-        ++sx;
-    while (32 * sx * sx + 4 * sx > u)
-        --sx;
-    const int rem = u - (32 * sx * sx + 4 * sx);
-    if (rem < 64 * sx) {
-        bx = 8 * sx + ((rem & 63) >> 3);
-        by = 8 * (rem >> 6) + (rem & 7);
-    } else {
-        int ix, iy;
-        tri_decode(rem - 64 * sx, ix, iy);
-        bx = 8 * sx + ix;
-        by = 8 * sx + iy;
-    }
-    return bx < tn;
-}
-
 // one wave tile of C -= P Q^T (see gemm_sub_kernel); C, P, Q already point at the batch element
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_sub_tile(double *__restrict__ C, long ldc,
@@ -547,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C
                                                           long ldp, long pstride,
                                                           const double *__restrict__ Q, long ldq,
                                                           long qstride, int m, int n, int k,
-                                                          int lower, int order)
+                                                          int lower)
 {
     // [buffer][P rows 0..15 | Q rows 16..31][128 doubles + pad]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -555,14 +524,8 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6); // scalar: LDS-DMA bases stay in SGPRs
     int bx = blockIdx.x, by = blockIdx.y;
-    if (lower == 2) {
-        if (order == 2) {
-            if (!supertile_decode(blockIdx.x, gridDim.x, (m + 127) >> 7, bx, by))
-                return;
-        } else {
-            tri_decode(blockIdx.x, bx, by);
-        }
-    }
+    if (lower == 2)
+        tri_decode(blockIdx.x, bx, by);
     C += (long)b * cstride;
     P += (long)b * pstride;
     Q += (long)b * qstride;

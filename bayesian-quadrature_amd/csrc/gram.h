@@ -13,7 +13,7 @@ template <int D>
 __global__ __launch_bounds__(256) void gram_sym_kernel(const double *__restrict__ x, long xstride,
                                                        const GaussParams *__restrict__ gp,
                                                        int gpstride, double *__restrict__ K,
-                                                       long ldk, long kstride, int n, int nt)
+                                                       long ldk, long kstride, int n)
 {
     const int b = blockIdx.z;
     x += (long)b * xstride;
@@ -41,14 +41,8 @@ __global__ __launch_bounds__(256) void gram_sym_kernel(const double *__restrict_
 #pragma unroll
         for (int k = 0; k < D; ++k)
             xj[k] = x[k + (long)j * D];
-        double v0, v1;
-        if (nt & 2) { // timing diagnostic only (BQ_GRAM_NT=2): no exp, wrong values
-            v0 = g.c * gauss_q<D>(xi0, xj, g);
-            v1 = g.c * gauss_q<D>(xi1, xj, g);
-        } else {
-            v0 = g.c * exp_gauss(gauss_q<D>(xi0, xj, g));
-            v1 = g.c * exp_gauss(gauss_q<D>(xi1, xj, g));
-        }
+        double v0 = g.c * exp_gauss(gauss_q<D>(xi0, xj, g));
+        double v1 = g.c * exp_gauss(gauss_q<D>(xi1, xj, g));
         if (i == j)
             v0 += g.s2;
         if (i + 1 == j)
@@ -56,10 +50,7 @@ __global__ __launch_bounds__(256) void gram_sym_kernel(const double *__restrict_
         double *dst = K + i + (long)j * ldk;
         if (vec) {
             double2_t v = {v0, v1};
-            if (nt & 1)
-                __builtin_nontemporal_store(v, reinterpret_cast<double2_t *>(dst));
-            else
-                *reinterpret_cast<double2_t *>(dst) = v;
+            *reinterpret_cast<double2_t *>(dst) = v;
         } else {
             dst[0] = v0;
             if (two)

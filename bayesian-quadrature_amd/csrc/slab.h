@@ -36,16 +36,19 @@
 // Solve 16 rows of the panel: returns X^T blocks x[c] (D / B-fragment form: x[c][r] of lane l
 // is X[row l & 15][16 c + (l >> 4) + 4 r]).  la / w: A fragments of L_jj's off-diagonal
 // blocks and of the (negated) block inverses, shared by every solve of the wave.
-__device__ __forceinline__ void slab_solve16(const double *__restrict__ S, long lds,
-                                             const double (&la)[4][3][4],
-                                             const double (&wneg)[4][4], double4_t (&x)[4])
+__device__ __forceinline__ void slab_load16(const double *__restrict__ S, long lds,
+                                            double (&t)[4][4])
 {
-    double t[4][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             t[c][r] = S[(long)(16 * c + 4 * r) * lds];
+}
+
+__device__ __forceinline__ void slab_solve16(const double (&t)[4][4], const double (&la)[4][3][4],
+                                             const double (&wneg)[4][4], double4_t (&x)[4])
+{
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         double4_t acc = {-t[c][0], -t[c][1], -t[c][2], -t[c][3]};
@@ -62,6 +65,9 @@ __device__ __forceinline__ void slab_solve16(const double *__restrict__ S, long 
     }
 }
 
+// STAMP: a profiling instantiation (tools/c2_timeline.py) whose workgroup 0 records s_memtime
+// at its phase boundaries; the shipped launches use STAMP = false and carry no stamp code.
+template <bool STAMP>
 __global__ __launch_bounds__(256) void slab_step_kernel(double *__restrict__ A, long lda,
                                                         long astride,
                                                         const double *__restrict__ Sin,
@@ -70,18 +76,23 @@ __global__ __launch_bounds__(256) void slab_step_kernel(double *__restrict__ A, 
                                                         const double *__restrict__ din,
                                                         double *__restrict__ dout, long dstride,
                                                         int factor_next, int last,
-                                                        int *__restrict__ info)
+                                                        int *__restrict__ info,
+                                                        long long *stamps)
 {
+#define BQ_SSTAMP(k, dep)                                                                          \
+    if (STAMP) {                                                                                   \
+        asm volatile("" ::"v"(dep));                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (blockIdx.x == 0 && threadIdx.x == 0)                                                   \
+            stamps[k] = (long long)__builtin_amdgcn_s_memtime();                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    }
+    BQ_SSTAMP(0, 0)
     // Q rows of the tile, [k][row] (A-fragment reads are contiguous over rows)
     __shared__ __attribute__((aligned(16))) double Qs[64 * 64];
     // workgroup 0: the updated diagonal block on its way to the factor, and the factor's LDS
-#if BQ_POTF2_SRC_IN_LDS
     __shared__ __attribute__((aligned(16))) double plds[BQ_POTF2_LDS_DOUBLES];
     double *const Ts = plds; // the block sits where the factor's panel slots will be
-#else
-    __shared__ __attribute__((aligned(16))) double Ts[64 * 64];
-    __shared__ __attribute__((aligned(16))) double plds[BQ_POTF2_LDS_DOUBLES];
-#endif
     __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63;
@@ -97,36 +108,77 @@ __global__ __launch_bounds__(256) void slab_step_kernel(double *__restrict__ A, 
     const int Rb = r0 + 64 * bx, Cb = r0 + 64 * by;
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    // A fragments of L_jj (blocks below its diagonal) and of the negated block inverses
-    double la[4][3][4], wneg[4][4];
+    // Every global load of the step is issued here, before the first MFMA: the fragments of
+    // L_jj (blocks below its diagonal) and of the negated block inverses, the unsolved panel
+    // rows of both row blocks and the C tile.  (Loaded where they are first used, the tile
+    // waited behind the factor's stores, which may alias it, and the launch paid three
+    // memory round trips one after the other.)
+    double la[4][3][4], wneg[4][4], tp[4][4], tq[4][4];
+    double4_t acc[4];
     {
-        const double *L11 = A + j0 + (long)j0 * lda + l15 + (long)l4 * lda;
-        const double *W = din + 64 + l15 + 16 * l4;
+        // The fragments of L_jj and W are the same for all four waves: the workgroup fetches
+        // the six 16 x 16 blocks below L_jj's diagonal and the four block inverses ONCE into
+        // LDS (10 doubles per thread; the region is the diagonal factor's, free until the
+        // tile update is over) instead of 64 doubles per lane from L2 -- a CU takes in about
+        // 40 B per cycle and the fragment loads were half of the launch's 190 KB.
+        double *Fs = plds;          // block (c, bb), c > bb, at 256 ((c (c - 1)) / 2 + bb)
+        double *Ws = plds + 6 * 256; // W blocks as in global memory
+        {
+            const int t = threadIdx.x, ti = t & 15, tk = t >> 4;
+            const double *L11 = A + j0 + (long)j0 * lda + ti + (long)tk * lda;
+            double f[6], wv[4];
+#pragma unroll
+            for (int c = 1; c < 4; ++c)
+#pragma unroll
+                for (int bb = 0; bb < c; ++bb)
+                    f[(c * (c - 1)) / 2 + bb] = L11[16 * c + (long)(16 * bb) * lda];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                wv[q] = din[64 + 256 * q + t];
+            if (bx != by)
+                slab_load16(Sin + Cb + 16 * wave + l15 + (long)l4 * lds, lds, tq);
+            slab_load16(Sin + Rb + 16 * wave + l15 + (long)l4 * lds, lds, tp);
+            // C tile rows 16 wave .. +15, four 16-column blocks (negated: the MFMAs add Q P^T)
+            const double *Cin = A + Rb + 16 * wave + l15 + (long)(Cb + l4) * lda;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[cb][r] = -Cin[(long)(16 * cb + 4 * r) * lda];
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                Fs[256 * q + t] = f[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                Ws[256 * q + t] = -wv[q];
+        }
+        __syncthreads();
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                wneg[c][r] = -W[256 * c + 64 * r];
+                wneg[c][r] = Ws[256 * c + 64 * r + l15 + 16 * l4];
 #pragma unroll
         for (int c = 1; c < 4; ++c)
 #pragma unroll
             for (int bb = 0; bb < c; ++bb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    la[c][bb][r] = L11[16 * c + (long)(16 * bb + 4 * r) * lda];
+                    la[c][bb][r] = Fs[256 * ((c * (c - 1)) / 2 + bb) + l15 + 16 * (l4 + 4 * r)];
     }
+    BQ_SSTAMP(1, la[3][2][3] + wneg[3][3])
     // Q rows (row block by) -> LDS; P rows (row block bx) stay in registers
     double4_t xp[4];
     if (bx != by) {
         double4_t xq[4];
-        slab_solve16(Sin + Cb + 16 * wave + l15 + (long)l4 * lds, lds, la, wneg, xq);
+        slab_solve16(tq, la, wneg, xq);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 Qs[(16 * c + l4 + 4 * r) * 64 + 16 * wave + l15] = xq[c][r];
     }
-    slab_solve16(Sin + Rb + 16 * wave + l15 + (long)l4 * lds, lds, la, wneg, xp);
+    slab_solve16(tp, la, wneg, xp);
     if (bx == by) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -134,6 +186,7 @@ __global__ __launch_bounds__(256) void slab_step_kernel(double *__restrict__ A, 
             for (int r = 0; r < 4; ++r)
                 Qs[(16 * c + l4 + 4 * r) * 64 + 16 * wave + l15] = xp[c][r];
     }
+    BQ_SSTAMP(2, xp[3][3])
     // the solved rows are the factor: tile column 0 owns the write
     if (by == 0) {
         double *Lw = A + Rb + 16 * wave + l15 + (long)(j0 + l4) * lda;
@@ -143,16 +196,10 @@ __global__ __launch_bounds__(256) void slab_step_kernel(double *__restrict__ A, 
             for (int r = 0; r < 4; ++r)
                 Lw[(long)(16 * c + 4 * r) * lda] = xp[c][r];
     }
-    // C tile rows 16 wave .. +15, four 16-column blocks: D[n][i] = sum_k Q[n][k] P[i][k]
-    // (A operand = Q fragment from LDS, B operand = P as it stands), C -= D^T
-    const double *Cin = A + Rb + 16 * wave + l15 + (long)(Cb + l4) * lda;
-    double4_t acc[4];
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            acc[cb][r] = -Cin[(long)(16 * cb + 4 * r) * lda];
+    // D[n][i] = sum_k Q[n][k] P[i][k] (A operand = Q fragment from LDS, B operand = P as it
+    // stands), C -= D^T
     __syncthreads();
+    BQ_SSTAMP(3, acc[3][3] + acc[0][0])
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -163,6 +210,7 @@ __global__ __launch_bounds__(256) void slab_step_kernel(double *__restrict__ A, 
             for (int cb = 0; cb < 4; ++cb)
                 acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(qrow[16 * cb], pf, acc[cb], 0, 0, 0);
         }
+    BQ_SSTAMP(4, acc[3][3] + acc[0][0])
     // tile column 0 is the next panel: it goes to the scratch column (the diagonal tile,
     // which workgroup 0 factors in place, and the Schur complement of the last step stay in A)
     if (blockIdx.x == 0 && factor_next) {
@@ -173,7 +221,8 @@ __global__ __launch_bounds__(256) void slab_step_kernel(double *__restrict__ A, 
             for (int r = 0; r < 4; ++r)
                 Ts[16 * wave + l15 + 64 * (16 * cb + l4 + 4 * r)] = -acc[cb][r];
         __syncthreads();
-        potf2_body(A + r0 + (long)r0 * lda, lda, r0, dout, info + b, plds, Ts, 64);
+        potf2_body(A + r0 + (long)r0 * lda, lda, r0, dout, info + b, plds, Ts, 64,
+                   STAMP ? stamps + 5 : nullptr);
         return;
     }
     const bool to_s = by == 0 && bx > 0 && !last;
@@ -188,6 +237,7 @@ __global__ __launch_bounds__(256) void slab_step_kernel(double *__restrict__ A, 
         for (int r = 0; r < 4; ++r)
             Cout[(long)(16 * cb + 4 * r) * ldo] = -acc[cb][r];
     }
+#undef BQ_SSTAMP
 }
 
 // first launch of a slab sweep: workgroup 0 factors the leading diagonal block, the others
@@ -245,13 +295,8 @@ __global__ __launch_bounds__(256) void panel_step_kernel(double *__restrict__ A,
                                                          int *__restrict__ info)
 {
     __shared__ __attribute__((aligned(16))) double Qs[64 * 64];
-#if BQ_POTF2_SRC_IN_LDS
     __shared__ __attribute__((aligned(16))) double plds[BQ_POTF2_LDS_DOUBLES];
     double *const Ts = plds; // the block sits where the factor's panel slots will be
-#else
-    __shared__ __attribute__((aligned(16))) double Ts[64 * 64];
-    __shared__ __attribute__((aligned(16))) double plds[BQ_POTF2_LDS_DOUBLES];
-#endif
     __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63;
@@ -298,14 +343,20 @@ __global__ __launch_bounds__(256) void panel_step_kernel(double *__restrict__ A,
     double4_t xp[4];
     if (has_next && blockIdx.x != 0) {
         double4_t xq[4];
-        slab_solve16(Sp + r0 + 16 * wave + l15 + (long)l4 * ldsp, ldsp, la, wneg, xq);
+        double tq[4][4];
+        slab_load16(Sp + r0 + 16 * wave + l15 + (long)l4 * ldsp, ldsp, tq);
+        slab_solve16(tq, la, wneg, xq);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 Qs[(16 * c + l4 + 4 * r) * 64 + 16 * wave + l15] = xq[c][r];
     }
-    slab_solve16(Sp + Rb + 16 * wave + l15 + (long)l4 * ldsp, ldsp, la, wneg, xp);
+    {
+        double tp[4][4];
+        slab_load16(Sp + Rb + 16 * wave + l15 + (long)l4 * ldsp, ldsp, tp);
+        slab_solve16(tp, la, wneg, xp);
+    }
     {
         // (a lone workgroup has no readers to protect, and no next step to move the block)
         const bool side = first && has_next && blockIdx.x == 0 && gridDim.x > 1;

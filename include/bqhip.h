@@ -254,6 +254,9 @@ int bq_probe_mfma444_layout(bq_ctx *ctx, int cbsz, int abid, int32_t *out8192);
 int bq_probe_rsq(bq_ctx *ctx, const double *x, int64_t n, double *err3);
 /* device time per launch of a chain of n empty, dependent kernels (us) */
 int bq_probe_launch(bq_ctx *ctx, int64_t n, double *us_per_launch);
+/* One eager pass of a plan (one or two problems, outer block 64) with the profiling
+ * instantiation of the one-launch slab step: 16 s_memtime stamps of workgroup 0 per step. */
+int bq_probe_c2_timeline(bq_ctx *ctx, bq_plan *plan, int64_t *stamps, int64_t nsteps);
 /* The 64 x 64 diagonal factor alone (the launch that heads every panel step): A is a
  * 64 x 64 host matrix, factored `reps` times from a resident copy (from_lds != 0: handed
  * over through LDS as the one-launch steps do).  Last launch's factor, its

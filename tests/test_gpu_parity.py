@@ -479,17 +479,15 @@ def _potrf_dev(eng, x, c, n, nb=0, la=True):
     ({}, 128, False),                    # k = 128 chunks, sequential launches
     ({}, 512, True),                     # k = 512
     ({}, 192, True),                     # k = 192: not a multiple of 32 x 4 -> both kernels
-    ({"BQ_GEMM_LDS": "0"}, 0, True),     # register-streaming four-block MFMA kernel
-    ({"BQ_TILE_ORDER": "2"}, 0, False),  # XCD-aware super-tile order
-    ({"BQ_TRSM_BLK": "0"}, 0, True),     # column-by-column panel solve
-    ({"BQ_MFMA444": "0"}, 256, False),   # v_mfma_f64_16x16x4_f64 kernel
-    ({"BQ_FUSE": "0"}, 0, True),         # no fused diagonal factor
+    ({"BQ_GEMM_LDS": "0"}, 0, True),     # the reference variant: register-streaming kernel
+    ({"BQ_GEMM_LDS": "0"}, 256, False),
     ({"BQ_LA_MIN": "0"}, 0, True),       # look-ahead to the last panel (no hand-over)
     ({"BQ_LA_MIN": "0"}, 128, True),
 ])
 def test_trailing_update_variants_agree(engine, env, nb, la):
-    """Every kernel variant of the factorisation (selected by the developer switches a
-    context reads when it is created) gives the same factor of an N = 4480 system -- a
+    """Every blocking / scheduling of the factorisation, and the one reference kernel variant
+    kept beside the shipped trailing update (BQ_GEMM_LDS=0, read when a context is created),
+    gives the same factor of an N = 4480 system -- a
     size that is a multiple of 64 but not of 128, large enough for the 128 x 128 tiles."""
     import os
     from bayesian_quadrature_amd import Engine
