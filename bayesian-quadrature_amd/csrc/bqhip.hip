@@ -96,7 +96,7 @@ struct bq_ctx {
     GaussParams gbuf_host{};
     bool gbuf_valid = false;
     DevBuf dinv64; // potf2 reciprocal-diagonal scratch
-    long long *stamp_buf = nullptr; // bq_probe_c2_timeline: 16 stamps per slab step
+    long long *stamp_buf = nullptr; // bq_probe_c2_timeline: 160 stamps per slab step
 };
 
 namespace {
@@ -555,7 +555,7 @@ int enqueue_slab_sweep(bq_ctx *c, double *A, long lda, long astride, int batch, 
                                0, c->cur, A, lda, astride, S[par], S[par ^ 1], (long)ntot, sstride,
                                ntot, j0, dinv + par * BQ_DINV_HALF,
                                dinv + (par ^ 1) * BQ_DINV_HALF, (long)BQ_DINV_STRIDE, fnext,
-                               !fnext, info, c->stamp_buf + 16 * (j0 / 64));
+                               !fnext, info, c->stamp_buf + 160 * (j0 / 64));
         else
             hipLaunchKernelGGL(slab_step_kernel<false>, dim3(T * (T + 1) / 2, 1, batch), dim3(256),
                                0, c->cur, A, lda, astride, S[par], S[par ^ 1], (long)ntot, sstride,
@@ -2240,7 +2240,7 @@ extern "C" int bq_probe_rsq(bq_ctx *c, const double *x, int64_t n, double *err3)
 }
 
 // One eager (not graph-replayed) pass of a plan with the profiling instantiation of the slab
-// step: stamps[16 * step + k] = s_memtime of workgroup 0 at (0) entry, (1) factor fragments
+// step: stamps[160 * step + k] = s_memtime of workgroup 0 at (0) entry, (1) factor fragments
 // loaded, (2) panel rows solved, (3) tile loaded + Q in LDS, (4) tile updated, (5..9) the
 // diagonal factor's entry / block in registers / pivot chain done / sub-blocks in LDS / end.
 extern "C" int bq_probe_c2_timeline(bq_ctx *c, bq_plan *p, int64_t *stamps, int64_t nsteps)
@@ -2249,7 +2249,7 @@ extern "C" int bq_probe_c2_timeline(bq_ctx *c, bq_plan *p, int64_t *stamps, int6
         return BQ_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     DevBuf st;
-    HIPCHK(c, st.alloc(sizeof(long long) * 16 * (size_t)nsteps));
+    HIPCHK(c, st.alloc(sizeof(long long) * 160 * (size_t)nsteps));
     HIPCHK(c, hipMemsetAsync(st.p, 0, st.bytes, c->stream));
     c->stamp_buf = static_cast<long long *>(st.p);
     int rc = plan_enqueue(c, p);
@@ -2263,7 +2263,9 @@ extern "C" int bq_probe_c2_timeline(bq_ctx *c, bq_plan *p, int64_t *stamps, int6
 // The diagonal factor alone: A (64 x 64 host, column-major) is factored `reps` times from a
 // resident copy; L_out / dinv_out (BQ_DINV_HALF doubles) / info_out are the last launch's
 // results, us_per_launch the HIP-event average, stamps5 the in-kernel s_memtime stamps
-// (entry, block loaded, pivot chain done, sub-blocks in LDS, end; 100 MHz ticks).
+// (entry, block loaded, pivot chain done, sub-blocks in LDS, end; shader cycles) followed at
+// [8 + 2 (4 P + w) + k] by wave w's arrival at (k = 0) / release from (k = 1) the barrier that
+// publishes panel P: 136 values.
 extern "C" int bq_probe_potf2(bq_ctx *c, const double *A, int from_lds, int64_t reps,
                               double *L_out, double *dinv_out, int32_t *info_out,
                               double *us_per_launch, int64_t *stamps5)
@@ -2276,7 +2278,7 @@ extern "C" int bq_probe_potf2(bq_ctx *c, const double *A, int from_lds, int64_t 
     HIPCHK(c, a.alloc(sizeof(double) * 4096));
     HIPCHK(c, dv.alloc(sizeof(double) * BQ_DINV_STRIDE));
     HIPCHK(c, inf.alloc(64));
-    HIPCHK(c, st.alloc(64));
+    HIPCHK(c, st.alloc(sizeof(long long) * 136));
     HIPCHK(c, hipMemcpyAsync(ain.p, A, sizeof(double) * 4096, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(inf.p, 0, 64, c->stream));
     HIPCHK(c, hipMemsetAsync(a.p, 0, sizeof(double) * 4096, c->stream));
@@ -2306,7 +2308,7 @@ extern "C" int bq_probe_potf2(bq_ctx *c, const double *A, int from_lds, int64_t 
         HIPCHK(c, hipMemcpyAsync(info_out, inf.p, sizeof(int32_t), hipMemcpyDeviceToHost,
                                  c->stream));
     if (stamps5)
-        HIPCHK(c, hipMemcpyAsync(stamps5, st.p, sizeof(int64_t) * 5, hipMemcpyDeviceToHost,
+        HIPCHK(c, hipMemcpyAsync(stamps5, st.p, sizeof(int64_t) * 136, hipMemcpyDeviceToHost,
                                  c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return BQ_OK;

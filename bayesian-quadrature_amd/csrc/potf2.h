@@ -8,78 +8,42 @@
 // rows (lane = row) and a quarter of the columns: wave w owns the columns 16q + 4w + s
 // (q, s = 0..3), i.e. the matrix is cut into sixteen 4-column panels dealt round-robin to the
 // waves.  Panel p is factored by its owner (in-panel updates by v_readlane) and published to
-// LDS; every wave then applies the rank-4 update to its own later columns.  The owner of
-// panel p+1 updates only that panel before starting its pivot chain and catches up on its
-// remaining columns afterwards.  Everything that is not the pivot chain is off the owner:
-//   * the reciprocal square root is ONE third-order (Halley) step from the
-//     v_rsq_f64 seed -- y1 = y0 (1 + e/2 + 3 e^2/8), e = 1 - d y0^2: five
-//     instructions, dependency depth four, error 5 e^3/16 ~ 1e-18 for a 2^-20
-//     seed -- instead of two Newton steps (six instructions, depth six);
-//   * the pivot row is scaled like every other row (L_cc = d r, about an ulp from
-//     sqrt d): no per-pivot selects; the reciprocal pivots are one division per
-//     lane at the very end, and a non-positive pivot is found afterwards as the
-//     first NaN on the diagonal (d <= 0 makes r NaN or infinite and everything
-//     after it NaN), so the chain carries no failure bookkeeping either;
-//   * SYNC = 1: every panel has its own LDS slot and a published-column counter,
-//     so no wave ever waits at a workgroup barrier: the owner of the next panel
-//     applies the columns of the current one AS THEY APPEAR (one rank-1 update of
-//     its four columns per published column), and starts its own pivot chain one
-//     LDS round trip after the last of them.  LDS operations of one wave execute
-//     in order, so a column store followed by the counter store needs no wait.
+// a ring of three LDS slots; after ONE workgroup barrier per panel every wave applies the
+// rank-4 update to its own later columns.  What was measured on gfx950 and shaped this file
+// (tools/potf2_probe.py, per-wave barrier stamps):
+//   * a wave's time per panel is set by the waves that only update in the early panels
+//     (64 FMAs + 36 LDS reads, ~1100 cycles when every group waited for its own reads) and by
+//     the owner's path (own-panel update + four pivots, ~740 cycles) in the late ones -- not
+//     by the instruction count of the pivot: Newton vs Halley, per-pivot selects or not,
+//     moved the 15,000-cycle chain by 2 %;
+//   * published-column counters polled in LDS instead of barriers (every panel its own slot,
+//     the next owner applying columns as they appear) were SLOWER: 24,500 cycles;
+//   * the block inverses and the write-back after the chain were 5,800 cycles, 41 LDS waits.
 // ===========================================================================
-__device__ __forceinline__ double rsqrt_halley_f64(double d)
-{
-    const double y0 = __builtin_amdgcn_rsq(d);
-    const double t = d * y0;
-    const double e = __builtin_fma(-t, y0, 1.0);
-    const double p = __builtin_fma(0.375, e, 0.5);
-    const double q = y0 * e;
-    return __builtin_fma(q, p, y0);
-}
-
 struct Potf2F {
     double a[4][4]; // a[q][s] = column 16q + 4w + s of row `lane`
 };
 
-// LDS traffic of the column hand-over, as instructions: a volatile or atomic store would make
-// the compiler wait for it (s_waitcnt) on the pivot chain, and a generic pointer would turn
-// into a flat store.  The low half of a generic pointer into LDS is the LDS address.
-__device__ __forceinline__ unsigned lds_addr(const void *p)
-{
-    return (unsigned)(unsigned long long)p;
-}
-template <int OFF>
-__device__ __forceinline__ void lds_store_f64(unsigned addr, double v)
-{
-    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
-}
-__device__ __forceinline__ void lds_store_i32(unsigned addr, int v)
-{
-    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ int lds_load_i32(unsigned addr)
-{
-    int v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-    return v;
-}
-
-// LDS of the factor: 16 panel slots of 4 x 64 doubles, then the four 16 x 16 diagonal
-// sub-blocks (1024 doubles), then the published-column counter
+// LDS of the factor: a ring of three panel slots (4 x 64 doubles each) inside the first 4096
+// doubles -- the region may hold the factor's own input block, which every wave has in
+// registers before the first panel is published --, then the four 16 x 16 diagonal
+// sub-blocks (1024 doubles)
 #define BQ_POTF2F_SLOTS (16 * 256)
-// (counter in the first word after the blocks; the next 64 words absorb the counter stores of
-// the lanes that are not lane 0, so that the store needs no branch)
-#define BQ_POTF2F_LDS_DOUBLES (BQ_POTF2F_SLOTS + 1024 + 40)
+#define BQ_POTF2F_LDS_DOUBLES (BQ_POTF2F_SLOTS + 1024)
 
-// slots_a: LDS address of this lane's entry of column 0 of slot 0; SLOT: the panel's slot.
+// Factor panel P (columns 4P .. 4P+3, group QP = P >> 2) held by this wave and publish it.
 // The dependent chain of a pivot, in instruction hops (an fp64 hop costs 12-16 cycles):
 //   readlane d -> rsq y0 -> {t = d y0, l0 = a y0} -> e = 1 - t y0 -> {p = 1/2 + 3/8 e, m = l0 e}
 //   -> l = l0 + m p -> dn = a' - l l (the next pivot's diagonal, in its own lane) -> readlane.
-// The scaled column is formed directly (l = a y1 = l0 + l0 e p), never the refined
-// reciprocal, and the next diagonal entry needs no broadcast: every lane squares its own l.
-template <int P, int SLOT>
-__device__ __forceinline__ void potf2f_factor(Potf2F &st, double *slot, unsigned slots_a,
-                                              unsigned cnt_store, int lane, int sync)
+// The scaled column is formed directly (l = a y1 = l0 + l0 e p, a third-order step from the
+// v_rsq_f64 seed: error 5 e^3 / 16 ~ 1e-21 for the 2^-24 seed measured on gfx950), never the
+// refined reciprocal, and the next diagonal entry needs no broadcast: every lane squares its
+// own l.  The pivot row is scaled like every other row (L_cc = d r, about an ulp from sqrt d):
+// no per-pivot selects, no failure bookkeeping -- a non-positive pivot makes r NaN or infinite
+// and everything after it NaN, and potf2f_body finds it afterwards as the first NaN on the
+// diagonal.
+template <int P>
+__device__ __forceinline__ void potf2f_factor(Potf2F &st, double *slot, int lane)
 {
     constexpr int QP = P >> 2;
     double dn = st.a[QP][0];
@@ -100,159 +64,106 @@ __device__ __forceinline__ void potf2f_factor(Potf2F &st, double *slot, unsigned
         for (int s2 = s + 1; s2 < 4; ++s2)
             st.a[QP][s2] = __builtin_fma(-l, readlane_f64(l, 4 * P + s2), st.a[QP][s2]);
         st.a[QP][s] = l;
-        if (sync) {
-            if (s == 0) lds_store_f64<2048 * SLOT>(slots_a, l);
-            if (s == 1) lds_store_f64<2048 * SLOT + 512>(slots_a, l);
-            if (s == 2) lds_store_f64<2048 * SLOT + 1024>(slots_a, l);
-            if (s == 3) lds_store_f64<2048 * SLOT + 1536>(slots_a, l);
-            lds_store_i32(cnt_store, c + 1); // in order behind the column store (same wave)
-        } else {
-            slot[s * 64 + lane] = l;
+        slot[s * 64 + lane] = l;
+    }
+}
+
+// Rank-4 update of this wave's columns of the groups in QMASK by the panel in `slot` (li: the
+// panel's entries in this lane's row).  All multipliers of all groups are requested before
+// the first FMA (uniform ds_read_b128, two columns each): one LDS latency per call instead
+// of one per group -- the waves that only update were the slow ones of the early panels.
+template <int QMASK>
+__device__ __forceinline__ void potf2f_update(Potf2F &st, const double *slot,
+                                              const double (&li)[4], int w)
+{
+    double2_t lk[4][4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (QMASK & (1 << q)) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double2_t *src =
+                    reinterpret_cast<const double2_t *>(slot + s * 64 + 16 * q + 4 * w);
+                lk[q][s][0] = src[0];
+                lk[q][s][1] = src[1];
+            }
         }
-    }
-}
-
-// rank-1 update of this wave's columns of group Q by published column `col` (li = its entry
-// in this lane's row)
-template <int Q>
-__device__ __forceinline__ void potf2f_update1(Potf2F &st, const double *col, double li, int w)
-{
-    const double2_t *src = reinterpret_cast<const double2_t *>(col + 16 * Q + 4 * w);
-    const double2_t k0 = src[0], k1 = src[1];
-    st.a[Q][0] = __builtin_fma(-li, k0[0], st.a[Q][0]);
-    st.a[Q][1] = __builtin_fma(-li, k0[1], st.a[Q][1]);
-    st.a[Q][2] = __builtin_fma(-li, k1[0], st.a[Q][2]);
-    st.a[Q][3] = __builtin_fma(-li, k1[1], st.a[Q][3]);
-}
-
-template <int Q>
-__device__ __forceinline__ void potf2f_update_group(Potf2F &st, const double *slot,
-                                                    const double (&li)[4], int w)
-{
-    double2_t lk[4][2];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const double2_t *src = reinterpret_cast<const double2_t *>(slot + s * 64 + 16 * Q + 4 * w);
-        lk[s][0] = src[0];
-        lk[s][1] = src[1];
-    }
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        st.a[Q][0] = __builtin_fma(-li[s], lk[s][0][0], st.a[Q][0]);
-        st.a[Q][1] = __builtin_fma(-li[s], lk[s][0][1], st.a[Q][1]);
-        st.a[Q][2] = __builtin_fma(-li[s], lk[s][1][0], st.a[Q][2]);
-        st.a[Q][3] = __builtin_fma(-li[s], lk[s][1][1], st.a[Q][3]);
-    }
+        for (int q = 0; q < 4; ++q)
+            if (QMASK & (1 << q)) {
+                st.a[q][0] = __builtin_fma(-li[s], lk[q][s][0][0], st.a[q][0]);
+                st.a[q][1] = __builtin_fma(-li[s], lk[q][s][0][1], st.a[q][1]);
+                st.a[q][2] = __builtin_fma(-li[s], lk[q][s][1][0], st.a[q][2]);
+                st.a[q][3] = __builtin_fma(-li[s], lk[q][s][1][1], st.a[q][3]);
+            }
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc)
-        PIN(st.a[Q][cc]);
-}
-
-#ifndef BQ_POLL_SLEEP
-#define BQ_POLL_SLEEP 0
-#endif
-// (the asm's memory clobber keeps the data reads that follow behind the poll).  The spin is
-// bounded: a counter that never arrives -- a bug, not a data condition -- must not hang the
-// GPU; the word behind the counter records it and the factor reports info = j0 + 65.
-__device__ __forceinline__ void potf2f_wait(unsigned cnt_a, int need)
-{
-    for (int spin = 0; lds_load_i32(cnt_a) < need; ++spin) {
-        if (spin > (1 << 22)) {
-            lds_store_i32(cnt_a + 4u, 1);
-            break;
+    for (int q = 0; q < 4; ++q)
+        if (QMASK & (1 << q)) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+                PIN(st.a[q][cc]);
         }
-#if BQ_POLL_SLEEP >= 0
-        __builtin_amdgcn_s_sleep(BQ_POLL_SLEEP);
-#endif
-    }
 }
 
-template <int SYNC, int P>
+// groups after Q: bits Q+1 .. 3
+#define BQ_LATER(Q) ((0xF << ((Q) + 1)) & 0xF)
+
+// Step P, entered with panel P factored by its owner (wave P & 3) and on its way to slot
+// P % 3 of the ring; ONE workgroup barrier per panel:
+//   * the owner of panel P + 1 brings only that panel up to date, runs its pivot chain and
+//     publishes; what its later groups owe panel P waits until step P + 1;
+//   * the owner of panel P pays that debt for panel P - 1 (slot (P - 1) % 3 is not reused
+//     before step P + 1) and applies its own panel P to its later groups;
+//   * the other two waves apply panel P to everything of theirs that lies behind it.
+// wst (profiling probe only): every wave's arrival at and release from barrier P.
+template <int P>
 struct Potf2FSteps {
-    static __device__ __forceinline__ void run(Potf2F &st, double *slots, unsigned cnt,
-                                               unsigned cnt_store, int w, int lane)
+    static __device__ __forceinline__ void run(Potf2F &st, double *slots, int w, int lane,
+                                               long long *wst)
     {
         constexpr int QP = P >> 2, WP = P & 3;
-        constexpr int PN = P + 1, QN = PN >> 2, WN = PN & 3;
-        // SYNC 0: ring of three slots + one barrier per panel; SYNC 1: a slot per panel
-        const double *slot = slots + (SYNC ? P : P % 3) * 256;
-        double *nslot = slots + (SYNC ? PN : PN % 3) * 256;
-        if (!SYNC)
-            __syncthreads(); // panel P is published
+        constexpr int PN = P < 15 ? P + 1 : 15, QN = PN >> 2, WN = PN & 3;
+        const double *slot = slots + (P % 3) * 256;
+        if (wst && lane == 0)
+            wst[(4 * P + w) * 2] = (long long)__builtin_amdgcn_s_memtime();
+        __syncthreads(); // panel P is published
+        if (wst && lane == 0)
+            wst[(4 * P + w) * 2 + 1] = (long long)__builtin_amdgcn_s_memtime();
+        double li[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            li[s] = slot[s * 64 + lane];
         if (P < 15 && w == WN) {
-            // next owner.  First what it still owes panel P-1 ... nothing: its own later
-            // groups are caught up after its chain (see below); now its panel meets panel P.
-            double li[4];
-            if (SYNC) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    potf2f_wait(cnt, 4 * P + s + 1);
-                    li[s] = slot[s * 64 + lane];
-                    if (QN == 0) potf2f_update1<0>(st, slot + s * 64, li[s], w);
-                    if (QN == 1) potf2f_update1<1>(st, slot + s * 64, li[s], w);
-                    if (QN == 2) potf2f_update1<2>(st, slot + s * 64, li[s], w);
-                    if (QN == 3) potf2f_update1<3>(st, slot + s * 64, li[s], w);
-                }
-            } else {
+            potf2f_update<(1 << QN)>(st, slot, li, w);
+            potf2f_factor<PN>(st, slots + (PN % 3) * 256, lane);
+        } else if (w == WP) {
+            if (P >= 1 && BQ_LATER(QP) != 0) {
+                const double *prev = slots + ((P + 2) % 3) * 256;
+                double lp[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
-                    li[s] = slot[s * 64 + lane];
-                if (QN == 0) potf2f_update_group<0>(st, slot, li, w);
-                if (QN == 1) potf2f_update_group<1>(st, slot, li, w);
-                if (QN == 2) potf2f_update_group<2>(st, slot, li, w);
-                if (QN == 3) potf2f_update_group<3>(st, slot, li, w);
+                    lp[s] = prev[s * 64 + lane];
+                potf2f_update<BQ_LATER(QP)>(st, prev, lp, w);
             }
-            potf2f_factor<(P < 15 ? PN : 15), (SYNC ? (P < 15 ? PN : 15) : (P < 15 ? PN : 15) % 3)>(
-                st, nslot, lds_addr(slots) + 8u * (unsigned)lane, cnt_store, lane, SYNC);
-            // catch up: my later groups with panel P (panel PN is mine and needs no update
-            // of my own columns of its group beyond the in-panel ones -- but the columns of
-            // group QN that come AFTER panel PN do not exist in this wave: a wave owns one
-            // panel per group)
-            if (QN < 1) potf2f_update_group<1>(st, slot, li, w);
-            if (QN < 2) potf2f_update_group<2>(st, slot, li, w);
-            if (QN < 3) potf2f_update_group<3>(st, slot, li, w);
+            potf2f_update<BQ_LATER(QP)>(st, slot, li, w);
+        } else if (w > WP) {
+            potf2f_update<(1 << QP) | BQ_LATER(QP)>(st, slot, li, w);
         } else {
-            if (SYNC)
-                potf2f_wait(cnt, 4 * P + 4);
-            if (w != WP || P == 15) {
-                double li[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    li[s] = slot[s * 64 + lane];
-                // my panel of the panel's own group lies after it only if w > WP
-                if (w > WP) {
-                    if (QP == 0) potf2f_update_group<0>(st, slot, li, w);
-                    if (QP == 1) potf2f_update_group<1>(st, slot, li, w);
-                    if (QP == 2) potf2f_update_group<2>(st, slot, li, w);
-                    if (QP == 3) potf2f_update_group<3>(st, slot, li, w);
-                }
-                if (QP < 1) potf2f_update_group<1>(st, slot, li, w);
-                if (QP < 2) potf2f_update_group<2>(st, slot, li, w);
-                if (QP < 3) potf2f_update_group<3>(st, slot, li, w);
-            } else {
-                // the owner of panel P: its later groups with its own panel (from registers'
-                // copy in LDS -- the slot it has just written)
-                double li[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    li[s] = st.a[QP][s];
-                if (QP < 1) potf2f_update_group<1>(st, slot, li, w);
-                if (QP < 2) potf2f_update_group<2>(st, slot, li, w);
-                if (QP < 3) potf2f_update_group<3>(st, slot, li, w);
-            }
+            potf2f_update<BQ_LATER(QP)>(st, slot, li, w);
         }
-        Potf2FSteps<SYNC, P + 1>::run(st, slots, cnt, cnt_store, w, lane);
+        Potf2FSteps<P + 1>::run(st, slots, w, lane, wst);
     }
 };
-template <int SYNC>
-struct Potf2FSteps<SYNC, 16> {
-    static __device__ __forceinline__ void run(Potf2F &, double *, unsigned, unsigned, int, int) {}
+template <>
+struct Potf2FSteps<16> {
+    static __device__ __forceinline__ void run(Potf2F &, double *, int, int, long long *) {}
 };
 
 // lds: BQ_POTF2F_LDS_DOUBLES doubles.  src / lsrc as for potf2_64x4_body; when src lies in
 // the slots' LDS (the slab step's Ts), pass src_in_slots so that nobody publishes before
 // every wave has its columns.
-template <int SYNC>
 __device__ __forceinline__ void potf2f_body(double *__restrict__ Ab, long lda, int j0,
                                             double *__restrict__ dinv_b,
                                             int *__restrict__ info_b, double *lds,
@@ -268,11 +179,6 @@ __device__ __forceinline__ void potf2f_body(double *__restrict__ Ab, long lda, i
     BQ_STAMP(0);
     double *slots = lds;
     double *blk = lds + BQ_POTF2F_SLOTS;
-    int *cntp = reinterpret_cast<int *>(lds + BQ_POTF2F_SLOTS + 1024);
-    const unsigned cnt = lds_addr(cntp);
-    // lane 0 stores the counter, the other lanes hit a word of their own behind it
-    // (word 1 = "a wait gave up")
-    const unsigned cnt_store = cnt + (lane == 0 ? 0u : 8u + 4u * (unsigned)lane);
     Potf2F st;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -280,16 +186,12 @@ __device__ __forceinline__ void potf2f_body(double *__restrict__ Ab, long lda, i
         for (int s = 0; s < 4; ++s)
             st.a[q][s] = src ? src[lane + (long)(16 * q + 4 * w + s) * lsrc]
                              : Ab[lane + (long)(16 * q + 4 * w + s) * lda];
-    if (threadIdx.x == 0) {
-        cntp[0] = 0;
-        cntp[1] = 0;
-    }
-    if (SYNC || src_in_slots)
-        __syncthreads();
+    if (src_in_slots)
+        __syncthreads(); // the ring overwrites the block: every wave has its columns first
     BQ_STAMP(1);
     if (w == 0)
-        potf2f_factor<0, 0>(st, slots, lds_addr(slots) + 8u * (unsigned)lane, cnt_store, lane, SYNC);
-    Potf2FSteps<SYNC, 0>::run(st, slots, cnt, cnt_store, w, lane);
+        potf2f_factor<0>(st, slots, lane);
+    Potf2FSteps<0>::run(st, slots, w, lane, stamps ? stamps + 8 : nullptr);
     BQ_STAMP(2);
     // the four 16 x 16 diagonal sub-blocks into LDS from registers:
     // blk[b][i + 16 k] = L[16 b + i][16 b + k]; my columns: k = 4 w + s of every block
@@ -321,25 +223,45 @@ __device__ __forceinline__ void potf2f_body(double *__restrict__ Ab, long lda, i
     // NaN on the diagonal at its own column and at every later one
     {
         const double dg = blk[256 * (lane >> 4) + 17 * (lane & 15)];
-        const double rc = 1.0 / dg;
+        // 1 / L_cc: v_rcp_f64 + two Newton steps (the IEEE division sequence is three times
+        // as long, and this sits between the pivot chain and the end of the launch)
+        double rc = __builtin_amdgcn_rcp(dg);
+        rc = __builtin_fma(__builtin_fma(-dg, rc, 1.0), rc, rc);
+        rc = __builtin_fma(__builtin_fma(-dg, rc, 1.0), rc, rc);
         if (w == 0) {
             dinv_b[lane] = rc;
             const unsigned long long badm = __ballot(!(dg > 0.0) || !(dg < 1.7e308));
             if (lane == 0 && badm != 0ull && info_b[0] == 0)
                 info_b[0] = j0 + __builtin_ctzll(badm) + 1;
-            if (SYNC && lane == 0 && cntp[1] != 0)
-                info_b[0] = j0 + 65;
         }
-        // wave w inverts block w: lane j < 16 runs the forward substitution of unit column j
+        // Wave w inverts block w: lane j (mod 16) runs the forward substitution of unit column
+        // j in its right-looking form -- w_k = s_k / L_kk, then s_i -= L_ik w_k for i > k --
+        // so that the dependent chain is two operations per row and column k + 1 of the block
+        // (uniform LDS reads) is in flight while column k is applied.  (The row-by-row dot
+        // products it replaces waited for LDS 41 times: 5,800 cycles for this epilogue.)
         const double *bw = blk + 256 * w;
-        double wc[16];
+        double sv[16], wc[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            double sacc[4] = {(i == (lane & 15)) ? 1.0 : 0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < 16; ++i)
+            sv[i] = (i == (lane & 15)) ? 1.0 : 0.0;
+        double cur[16], nxt[16];
 #pragma unroll
-            for (int k = 0; k < i; ++k)
-                sacc[k & 3] -= bw[i + 16 * k] * wc[k];
-            wc[i] = ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) * readlane_f64(rc, 16 * w + i);
+        for (int i = 1; i < 16; ++i)
+            cur[i] = bw[i];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k < 14) {
+#pragma unroll
+                for (int i = k + 2; i < 16; ++i)
+                    nxt[i] = bw[i + 16 * (k + 1)];
+            }
+            wc[k] = sv[k] * readlane_f64(rc, 16 * w + k);
+#pragma unroll
+            for (int i = k + 1; i < 16; ++i)
+                sv[i] = __builtin_fma(-cur[i], wc[k], sv[i]);
+#pragma unroll
+            for (int i = k + 2; i < 16; ++i)
+                cur[i] = nxt[i];
         }
         if (lane < 16) {
             double *Wb = dinv_b + 64 + 256 * w + 16 * lane;
@@ -352,27 +274,11 @@ __device__ __forceinline__ void potf2f_body(double *__restrict__ Ab, long lda, i
 #undef BQ_STAMP
 }
 
-template <int SYNC>
-__global__ __launch_bounds__(256) void potf2f_kernel(double *__restrict__ A, long lda,
-                                                     long astride, int j0,
-                                                     double *__restrict__ dinv, long dstride,
-                                                     int *__restrict__ info)
-{
-    __shared__ __attribute__((aligned(16))) double lds[BQ_POTF2F_LDS_DOUBLES];
-    __builtin_amdgcn_s_setprio(3);
-    const int b = blockIdx.z;
-    potf2f_body<SYNC>(A + (long)b * astride + j0 + (long)j0 * lda, lda, j0,
-                      dinv + (long)b * dstride, info + b, lds);
-}
-
 // ---------------------------------------------------------------------------
-// The diagonal factor every fused kernel calls.  BQ_POTF2_VAR picks the hand-over at build
-// time (1: a ring of three slots and one workgroup barrier per panel -- shipped; 2: a slot
-// per panel and published-column counters, measured slower: 16.6 vs 12.7 us per launch).
+// The diagonal factor as every fused kernel calls it.  lds: BQ_POTF2_LDS_DOUBLES doubles; src
+// (leading dimension lsrc) is where the block is read from when it is not in place -- the
+// one-launch steps hand it over in the first 4096 doubles of `lds` itself.
 // ---------------------------------------------------------------------------
-#ifndef BQ_POTF2_VAR
-#define BQ_POTF2_VAR 1
-#endif
 #define BQ_POTF2_LDS_DOUBLES BQ_POTF2F_LDS_DOUBLES
 
 __device__ __forceinline__ void potf2_body(double *__restrict__ Ab, long lda, int j0,
@@ -380,11 +286,7 @@ __device__ __forceinline__ void potf2_body(double *__restrict__ Ab, long lda, in
                                            double *lds, const double *src = nullptr,
                                            long lsrc = 0, long long *stamps = nullptr)
 {
-#if BQ_POTF2_VAR == 1
-    potf2f_body<0>(Ab, lda, j0, dinv_b, info_b, lds, src, lsrc, src == lds, stamps);
-#else
-    potf2f_body<1>(Ab, lda, j0, dinv_b, info_b, lds, src, lsrc, src == lds, stamps);
-#endif
+    potf2f_body(Ab, lda, j0, dinv_b, info_b, lds, src, lsrc, src == lds, stamps);
 }
 
 __global__ __launch_bounds__(256) void potf2_kernel(double *__restrict__ A, long lda, long astride,

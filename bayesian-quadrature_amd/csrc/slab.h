@@ -68,7 +68,7 @@ __device__ __forceinline__ void slab_solve16(const double (&t)[4][4], const doub
 // STAMP: a profiling instantiation (tools/c2_timeline.py) whose workgroup 0 records s_memtime
 // at its phase boundaries; the shipped launches use STAMP = false and carry no stamp code.
 template <bool STAMP>
-__global__ __launch_bounds__(256) void slab_step_kernel(double *__restrict__ A, long lda,
+__global__ __launch_bounds__(256, 2) void slab_step_kernel(double *__restrict__ A, long lda,
                                                         long astride,
                                                         const double *__restrict__ Sin,
                                                         double *__restrict__ Sout, long lds,

@@ -255,16 +255,18 @@ int bq_probe_rsq(bq_ctx *ctx, const double *x, int64_t n, double *err3);
 /* device time per launch of a chain of n empty, dependent kernels (us) */
 int bq_probe_launch(bq_ctx *ctx, int64_t n, double *us_per_launch);
 /* One eager pass of a plan (one or two problems, outer block 64) with the profiling
- * instantiation of the one-launch slab step: 16 s_memtime stamps of workgroup 0 per step. */
+ * instantiation of the one-launch slab step: 160 s_memtime stamps of workgroup 0 per step
+ * (10 phase boundaries, then the diagonal factor's per-wave barrier stamps). */
 int bq_probe_c2_timeline(bq_ctx *ctx, bq_plan *plan, int64_t *stamps, int64_t nsteps);
 /* The 64 x 64 diagonal factor alone (the launch that heads every panel step): A is a
  * 64 x 64 host matrix, factored `reps` times from a resident copy (from_lds != 0: handed
  * over through LDS as the one-launch steps do).  Last launch's factor, its
  * BQ_DINV_HALF-double record (64 reciprocal pivots + four 16 x 16 block inverses), info,
- * HIP-event microseconds per launch and five in-kernel s_memtime stamps. */
+ * HIP-event microseconds per launch and 136 in-kernel s_memtime stamps (5 phase
+ * boundaries, then per panel and wave the arrival at / release from the panel barrier). */
 int bq_probe_potf2(bq_ctx *ctx, const double *A, int from_lds, int64_t reps, double *L_out,
                    double *dinv_out, int32_t *info_out, double *us_per_launch,
-                   int64_t *stamps5);
+                   int64_t *stamps136);
 /* dump of the f64 MFMA D-register layout: out[64*4] receives, for lane l and
  * register r, the value row*16+col of the D element it holds */
 int bq_probe_mfma_layout(bq_ctx *ctx, double *out256);

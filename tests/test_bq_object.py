@@ -281,8 +281,18 @@ def test_gaussian_example_notebook(pkg):
                 candidate_thresh=fx["candidate_thresh"], optim_method=fx["optim_method"])
     bq.init(params_tl=tuple(fx["params_tl"]), params_l=tuple(fx["params_l"]))
     bq.fit_hypers(fx["fit_hypers"])
-    assert "%f" % bq.Z_mean() == g["expected"]["Z_mean"]["printed"]
-    assert "%f" % bq.Z_var() == g["expected"]["Z_var"]["printed"]
+    # L-BFGS-B with finite-difference gradients stops anywhere on the flat top of the
+    # optimum: E[Z] moves in its seventh digit with the rounding of the engine underneath
+    # (0.14176663 on the CPU double, 0.14176648 on the HIP path).  The bar is the printed
+    # value within 1.5 units of its last digit; the starting point is 300 units away.
+    assert abs(bq.Z_mean() - g["expected"]["Z_mean"]["value"]) < 1.5e-6
+    assert abs(bq.Z_var() - g["expected"]["Z_var"]["value"]) < 1.5e-6
+    before = pkg.BQ(x, f_x(x), kernel=pkg.GaussianKernel, n_candidate=fx["n_candidate"],
+                    x_mean=fx["x_mean"], x_var=fx["x_var"],
+                    candidate_thresh=fx["candidate_thresh"], optim_method=fx["optim_method"])
+    np.random.seed(fx["seed"])
+    before.init(params_tl=tuple(fx["params_tl"]), params_l=tuple(fx["params_l"]))
+    assert abs(before.Z_mean() - g["expected"]["Z_mean"]["value"]) > 1e-4
 
 
 def test_sample_hypers(pkg):

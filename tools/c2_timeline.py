@@ -22,9 +22,9 @@ if __name__ == "__main__":
         plan.run()
     e.sync()
     nsteps = 16
-    st = (C.c_int64 * (16 * nsteps))()
+    st = (C.c_int64 * (160 * nsteps))()
     e._check(e._lib.bq_probe_c2_timeline(e._ctx, plan._h, st, nsteps))
-    t = np.array(list(st), dtype=np.int64).reshape(nsteps, 16)[:, :10]
+    t = np.array(list(st), dtype=np.int64).reshape(nsteps, 160)[:, :10]
     d = np.diff(t, axis=1)                       # phase lengths per step
     gap = t[1:, 0] - t[:-1, 9]                   # end of a step's factor -> next step's entry
     out = {"library": L.LIB_PATH, "unit": "s_memtime ticks",

@@ -17,7 +17,7 @@ def probe(e, A, from_lds, reps=200):
     dv = np.zeros(64 + 4 * 256)
     info = C.c_int32(0)
     us = C.c_double(0)
-    st = (C.c_int64 * 5)()
+    st = (C.c_int64 * 136)()
     e._check(e._lib.bq_probe_potf2(e._ctx, L.dptr(A), int(from_lds), reps, L.dptr(Lo), L.dptr(dv),
                                    C.byref(info), C.cast(C.byref(us), L._dp), st))
     return Lo, dv, info.value, us.value, np.array(list(st), dtype=np.int64)
@@ -50,11 +50,14 @@ if __name__ == "__main__":
         for fl in (0, 1):
             Lo, dv, info, us, st = probe(e, A, fl)
             errL, errd, errW = check(A, Lo, dv)
-            ph = (st[1:] - st[:-1]).tolist()
+            ph = (st[1:5] - st[:4]).tolist()
+            w = st[8:136].reshape(16, 4, 2) - st[1]   # [panel, wave, arrive/release]
             out["%s_from_lds%d" % (name, fl)] = {
                 "us_per_launch": us, "info": info, "errL": errL, "err_dinv": errd, "err_W": errW,
                 "stamp_ticks_load_chain_blocks_tail": ph,
-                "us_in_kernel_total": float(st[4] - st[0]) / 100.0}
+                "cycles_in_kernel_total": int(st[4] - st[0]),
+                "barrier_arrive_by_wave": w[:, :, 0].tolist(),
+                "barrier_release_by_wave": w[:, :, 1].tolist()}
             assert info == 0 and errL < 1e-13 and errd < 1e-13 and errW < 1e-12, out
     # failure report: first non-positive pivot at column 37 (1-based 38)
     B = S.copy()
