@@ -61,8 +61,12 @@ def pmc_traffic(kernel):
         k = json.load(f)["kernels"].get(kernel)
     if not k:
         return None, None
-    return (k.get("FETCH_SIZE_bytes_avg", 0.0) + k.get("WRITE_SIZE_bytes_avg", 0.0),
-            os.path.basename(files[-1]))
+    # FETCH_SIZE_corrected_bytes_avg: the guide's x2 for 16-B-per-lane reads applied to the
+    # share of the fetch that is read that way (tools/pmc_summary.py); raw where no share is known
+    fetch = k.get("FETCH_SIZE_corrected_bytes_avg", k.get("FETCH_SIZE_bytes_avg", 0.0))
+    return (fetch + k.get("WRITE_SIZE_bytes_avg", 0.0),
+            "profiles/%s (separate rocprofv3 --pmc passes, not this run)"
+            % os.path.basename(files[-1]))
 
 
 def parse():
@@ -298,6 +302,11 @@ def cpu_baseline(wk, budget_s=12.0):
             break
     o.set_threads(cores)
     return {"value": reps / el, "unit": "problems/s", "cores": cores, "kind": "port",
+            "reference_timings_baseline_md": "the reference's own Cython + OpenBLAS path, "
+            "measured in the survey container (8 vCPU Xeon 2.1 GHz, BASELINE.md section 2), "
+            "N=1024: Gram 18.8 ms + cho_factor 11.9 ms + cho_solve_vec 0.97 ms = 31.7 ms; "
+            "N=2048: 85.4 + 67.8 + 3.3 ms; N=4096: 373 + 477 + 15.4 ms.  It cannot run on "
+            "the GPU box (Python 2 + the absent gp package)",
             "ms_per_problem": el / reps * 1e3,
             "one_thread": {"value": r1 / e1, "ms_per_problem": e1 / r1 * 1e3, "reps": r1},
             "sample": "%d x (gram + blocked potrf + potrs + predict mean/var + logML) of the "
@@ -408,6 +417,7 @@ def extras(eng, nb_override):
             eng.free(info)
         eng.free(xd)
         eng.free(Kd)
+    out.update(solve_predict_rooflines(eng))
     out.update(batched_configs(eng))
     # the same C2 problem through the host-buffer entry point (allocation, PCIe both
     # ways, synchronisation inside every call): never the headline `value`
@@ -418,6 +428,81 @@ def extras(eng, nb_override):
         eng.fit_predict(c2["x"], c2["y"], c2["h"], c2["w"], c2["s"], c2["xo"])
     out["c2_host_buffer_call"] = {"ms_per_call": (time.perf_counter() - t0) / 10 * 1e3,
                                   "note": "bq_fit_predict: plan creation + H2D + run + D2H per call"}
+    return out
+
+
+def _prof_call(eng, fn, reps=3):
+    """Device time of fn(): HIP events around every kernel launch (per class), averaged
+    over `reps` calls after one warm-up; also the host wall time of a call."""
+    fn()
+    eng.sync()
+    eng.profile(True)
+    eng.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    wall = (time.perf_counter() - t0) / reps
+    pr = eng.profile_read()
+    eng.profile(False)
+    ms = {k: v["ms"] / reps for k, v in pr.items() if v["launches"]}
+    return sum(ms.values()), ms, wall * 1e3
+
+
+def solve_predict_rooflines(eng):
+    """the triangular solves (cho_solve: 8 N^2 bytes for one right-hand side --
+    two passes over the lower triangle --, 2 N^2 flop per right-hand side) and the posterior
+    over M points (mean M N kernel evaluations, variance M N^2 flop through the forward
+    sweep) on resident fits."""
+    from bayesian_quadrature_amd import workloads as wl
+    out = {}
+    for n in (4096, 16384):
+        c = wl.c4(n)
+        y = wl.norm_logpdf(c["x"])
+        fit = eng.gp_fit(c["x"], y, c["h"], c["w"], c["s"])
+        rs = np.random.RandomState(n)
+        b1 = rs.randn(n)
+        dev, cls, wall = _prof_call(eng, lambda: fit.solve(b1))
+        byt = 8.0 * n * n
+        out["cho_solve_n%d_rhs1" % n] = {
+            "bound": "hbm", "achieved": byt / (dev * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+            "unit": "GB/s", "frac": byt / (dev * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+            "ms_kernels": dev, "ms_call_host_buffers": wall, "class_ms": cls,
+            "algorithmic_bytes": byt,
+            "note": "bq_gp_solve on a resident factor, one right-hand side (the sweeps carry "
+                    "64 rows: the padding of the row form); forward + backward sweep"}
+        B = np.asfortranarray(rs.randn(n, 256))
+        dev, cls, wall = _prof_call(eng, lambda: fit.solve(B), reps=2)
+        fl = 2.0 * n * n * 256
+        out["cho_solve_n%d_rhs256" % n] = {
+            "bound": "mfma", "achieved": fl / (dev * 1e-3) / 1e12, "peak": PEAK_FP64_TFLOPS,
+            "unit": "TFLOP/s", "frac": fl / (dev * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
+            "traffic": None, "ms_kernels": dev, "ms_call_host_buffers": wall, "class_ms": cls,
+            "algorithmic_flops": fl}
+        fit.close()
+    c2 = wl.c2()
+    fit = eng.gp_fit(c2["x"], c2["y"], c2["h"], c2["w"], c2["s"])
+    for M in (256, 1000):
+        xo = np.linspace(-5.0, 5.0, M) + 1e-3
+        dev, cls, wall = _prof_call(eng, lambda: fit.predict(xo), reps=5)
+        fl = float(M) * 1024 * 1024
+        out["predict_mean_var_n1024_m%d" % M] = {
+            "bound": "mfma", "achieved": fl / (dev * 1e-3) / 1e12, "peak": PEAK_FP64_TFLOPS,
+            "unit": "TFLOP/s", "frac": fl / (dev * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
+            "traffic": None, "ms_kernels": dev, "ms_call_host_buffers": wall, "class_ms": cls,
+            "algorithmic_flops": fl,
+            "note": "bq_gp_predict mean + variance: cross Gram, forward sweep V = K(xo,x) L^-T "
+                    "(M N^2 flop), row reductions; a chain of 16 x 2 dependent launches, "
+                    "latency bound at this N"}
+        dev, cls, wall = _prof_call(eng, lambda: fit.predict(xo, want_var=False), reps=5)
+        out["predict_mean_n1024_m%d" % M] = {
+            "bound": "hbm", "achieved": 8.0 * (2 * 1024 + M) / (dev * 1e-3) / 1e9,
+            "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": 8.0 * (2 * 1024 + M) / (dev * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+            "ms_kernels": dev, "ms_call_host_buffers": wall,
+            "kernel_evaluations": float(M) * 1024,
+            "note": "fused cross-Gram x alpha (predict_mean_kernel): M N exp evaluations, "
+                    "8 (N + M + N) algorithmic bytes -- a single short launch"}
+    fit.close()
     return out
 
 
@@ -438,11 +523,30 @@ def batched_configs(eng):
         plan.run()
     ms = eng.timer_stop_ms() / 3
     status = plan.results()[3]
+    dev, cls, _ = _prof_call(eng, plan.run, reps=2)
+    eng.profile(True)
+    eng.profile_reset()
+    plan.run()
+    pr = eng.profile_read()
+    eng.profile(False)
     plan.close()
-    flops = B * ((2048 + 64) ** 3 / 3.0)   # the factorisation alone, per problem N^3/3
+    flops = B * (2048 ** 3 / 3.0)   # the factorisation alone, per problem N^3/3
+    post = B * (256.0 * 2048 * 2048 + 256.0 * 256 * 2048)  # the posterior's M N^2 + M^2 N
+    sy = pr["syrk_trailing"]
     out["c5_shard_64x2048"] = {"ms_per_batch": ms, "problems_per_s": B / ms * 1e3,
                                "failed": int((status != 0).sum()),
-                               "potrf_tflops_lower_bound": flops / (ms * 1e-3) / 1e12}
+                               "potrf_tflops_lower_bound": flops / (ms * 1e-3) / 1e12,
+                               "tflops_incl_posterior": (flops + post) / (ms * 1e-3) / 1e12,
+                               "frac_incl_posterior":
+                                   (flops + post) / (ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
+                               "class_ms_sequential_events": cls,
+                               "dominant_kernel": {
+                                   "kernel": TRAILING_KERNEL, "bound": "mfma",
+                                   "achieved": sy["work"] / (max(sy["ms"], 1e-9) * 1e-3) / 1e12,
+                                   "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": sy["work"] / (max(sy["ms"], 1e-9) * 1e-3) / 1e12
+                                   / PEAK_FP64_TFLOPS,
+                                   "ms": sy["ms"], "launches": sy["launches"]}}
     # the headline problem, 256 independent copies per step: what batching buys over the
     # latency-bound single problem of `value`
     c2 = wl.c2()
@@ -469,7 +573,22 @@ def batched_configs(eng):
         lm = eng.logml_grid(c3["x"], c3["y"], c3["h"], c3["w"], c3["s"], chunk=100)
         walls.append(time.perf_counter() - t0)
     wall = min(walls)
+    eng.profile(True)
+    eng.profile_reset()
+    eng.logml_grid(c3["x"], c3["y"], c3["h"][:100], c3["w"][:100], c3["s"], chunk=100)
+    pr = eng.profile_read()
+    eng.profile(False)
+    sy = pr["syrk_trailing"]
     out["c3_grid_400x4096"] = {"wall_ms": wall * 1e3, "wall_ms_all": [w * 1e3 for w in walls],
+                               "class_ms_one_chunk_of_100": {k: v["ms"] for k, v in pr.items()
+                                                             if v["launches"]},
+                               "dominant_kernel": {
+                                   "kernel": TRAILING_KERNEL, "bound": "mfma",
+                                   "achieved": sy["work"] / (max(sy["ms"], 1e-9) * 1e-3) / 1e12,
+                                   "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": sy["work"] / (max(sy["ms"], 1e-9) * 1e-3) / 1e12
+                                   / PEAK_FP64_TFLOPS,
+                                   "ms": sy["ms"], "launches": sy["launches"]},
                                "ms_per_point": wall * 1e3 / len(lm),
                                "n_minus_inf": int(np.isinf(lm).sum()),
                                "potrf_tflops_lower_bound": len(lm) * (4096 ** 3 / 3.0) / wall / 1e12,
@@ -530,15 +649,24 @@ def main():
             ach = prof[dom]["work"] / (dom_ms * 1e-3) / 1e12
             roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / PEAK_FP64_TFLOPS, "traffic": None}
+        dom_kernel = {"syrk_trailing_small": "slab_step_kernel<false>",
+                      "syrk_trailing": TRAILING_KERNEL}.get(dom)
+        if dom_kernel:
+            roof["traffic"], roof["traffic_source"] = pmc_traffic(dom_kernel)
+            roof["kernel_symbol"] = dom_kernel
         roof.update({"launches_per_step": prof[dom]["launches"], "ms_per_launch": per_launch_ms,
                      "ms_per_step_in_class": dom_ms,
                      "algorithmic_work_per_step": prof[dom]["work"],
                      "class_ms_per_step": {k: v["ms"] for k, v in prof.items()},
                      "class_launches_per_step": {k: v["launches"] for k, v in prof.items()},
                      "note": "dominant kernel class of the timed workload (HIP events on the "
-                             "engine stream, instrumented pass).  This workload is latency "
-                             "bound: potf2_64_kernel is one wave of fp64 VALU work per launch; "
-                             "the kernels with a roofline target are under 'rooflines'"})
+                             "engine stream, instrumented pass; the events' own overhead makes "
+                             "the class sum exceed ms_per_step).  A single C2 problem is a "
+                             "chain of 16 dependent one-launch steps, each bound by ONE "
+                             "workgroup's critical path (panel-row solve, tile update, the "
+                             "64-pivot diagonal factor: tools/c2_timeline.py), not by the "
+                             "chip's MFMA rate; the kernels with a roofline target are under "
+                             "'rooflines'"})
         line = {
             "metric": "bq_fit_posterior_throughput",
             "value": value,
