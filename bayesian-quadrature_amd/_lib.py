@@ -76,6 +76,7 @@ SIGNATURES = {
     "bq_bq_Z_var": (C.c_int, [_vp, _vp, _vp, _dp, _dp, _dp]),
     "bq_esm_batch": (C.c_int, [_vp, _dp, _dp, _i64, _i64, _dp, _i64, _dbl, _dbl, _dbl, _dp, _dp, _dp,
                                _dp, _i32p]),
+    "bq_esm_border": (C.c_int, [_vp, _vp, _i64, _dp, _i64, _dbl, _dp, _dp, _dp, _dp, _i32p]),
     "bq_plan_create": (C.c_int, [_vp, _i64, _i64, _i64, _i64, C.POINTER(_vp)]),
     "bq_plan_destroy": (None, [_vp, _vp]),
     "bq_plan_set_inputs": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp, _dp, _dp]),
@@ -90,6 +91,7 @@ SIGNATURES = {
     "bq_probe_rsq": (C.c_int, [_vp, _dp, _i64, _dp]),
     "bq_probe_launch": (C.c_int, [_vp, _i64, _dp]),
     "bq_probe_c2_timeline": (C.c_int, [_vp, _vp, C.POINTER(C.c_int64), _i64]),
+    "bq_probe_exp": (C.c_int, [_vp, _dp, _i64, _dp]),
     "bq_probe_potf2": (C.c_int, [_vp, _dp, C.c_int, _i64, _dp, _dp, C.POINTER(C.c_int32), _dp,
                                  C.POINTER(C.c_int64)]),
     "bq_probe_mfma_layout": (C.c_int, [_vp, _dp]),

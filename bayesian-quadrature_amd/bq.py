@@ -162,10 +162,11 @@ class BQ(object):
 
     def _esm_and_em_batch(self, x_a):
         """All candidates of x_a at once.  The reference loops over them and
-        re-factors an (nsc+1)^2 Gram for each (bq.py:399-402,447-527); here the
-        bordered systems are assembled and factored in one batched launch sequence
-        (bq_esm_batch) and the closed forms of bq_c.pyx:425-490 are applied to the
-        results.  Same short-circuit, jitter and fallback rules."""
+        re-factors an (nsc+1)^2 Gram for each (bq.py:399-402,447-527); here all of them are
+        one bordered update of gp_l's resident factor (bq_esm_border; with a noise term in
+        gp_l: one batched factorisation, bq_esm_batch) and the closed forms of
+        bq_c.pyx:425-490 are applied to the results.  Same short-circuit, jitter and
+        fallback rules."""
         self._require_exact()
         x_a = np.atleast_1d(np.asarray(x_a, dtype=DTYPE))
         if x_a.ndim != 1 or np.isnan(x_a).any() or np.isinf(x_a).any():
@@ -189,9 +190,18 @@ class BQ(object):
         if idx.size == 0:
             return out
         xa = np.ascontiguousarray(x_a[idx])
-        A_a, A_sc_l, status = get_engine().esm_batch(
-            self.x_sc, self.l_sc, self.ns, xa, self.gp_l.K.h, self.gp_l.K.w,
-            self.options["candidate_thresh"], self.options["x_mean"], self.options["x_cov"])
+        eng = get_engine()
+        if hasattr(eng, "esm_border") and float(self.gp_l.s) == 0.0:
+            # bordered update of gp_l's resident factor: one multi-right-hand-side solve for
+            # all candidates instead of a factorisation each
+            A_a, A_sc_l, status = eng.esm_border(
+                self.gp_l._device_fit(), self.ns, xa, self.options["candidate_thresh"],
+                self.options["x_mean"], self.options["x_cov"])
+        else:
+            A_a, A_sc_l, status = eng.esm_batch(
+                self.x_sc, self.l_sc, self.ns, xa, self.gp_l.K.h, self.gp_l.K.w,
+                self.options["candidate_thresh"], self.options["x_mean"],
+                self.options["x_cov"])
         tm_a, tC_a = self.gp_log_l.mean_var(xa)
         # int exp(c x) N(x | m, S) dx = exp(c m + c^2 S / 2), saturating (gauss_c.pyx:65-92)
         arg1 = tm_a + 0.5 * tC_a

@@ -2221,6 +2221,23 @@ extern "C" int bq_probe_mfma444_layout(bq_ctx *c, int cbsz, int abid, int32_t *o
     return BQ_OK;
 }
 
+extern "C" int bq_probe_exp(bq_ctx *c, const double *x, int64_t n, double *out)
+{
+    if (!c || !x || !out || n < 1 || n > (1 << 28))
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf xd, od;
+    HIPCHK(c, xd.alloc(sizeof(double) * n));
+    HIPCHK(c, od.alloc(sizeof(double) * n));
+    HIPCHK(c, hipMemcpyAsync(xd.p, x, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(probe_exp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                       xd.d(), od.d(), (int)n);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, od.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BQ_OK;
+}
+
 extern "C" int bq_probe_rsq(bq_ctx *c, const double *x, int64_t n, double *err3)
 {
     if (!c || !x || !err3 || n < 1)

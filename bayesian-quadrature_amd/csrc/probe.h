@@ -27,6 +27,14 @@ __global__ void probe_rsq_kernel(const double *x, double *out, int n)
     out[3 * i + 2] = fabs(y - ref) / ref;
 }
 
+// exp_gauss (common.h) on an array of arguments, for the per-element accuracy test
+__global__ void probe_exp_kernel(const double *x, double *out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        out[i] = exp_gauss(x[i]);
+}
+
 // MFMA issue study: NACC independent accumulators per wave, 16x16x4 (KIND 0) or the
 // four-block 4x4x4 form (KIND 1); waves per SIMD are set by the grid.
 template <int KIND, int NACC>

@@ -276,6 +276,20 @@ class Engine(object):
             L.dptr(A_sc_l), status.ctypes.data_as(L._i32p)))
         return A_a, A_sc_l, status
 
+    def esm_border(self, fit_l, ns, x_a, thresh, mu, cov):
+        """(A_a, A_sc_l, status) for every candidate of x_a from the RESIDENT factor of
+        gp_l (a Fit over (x_sc, l_sc), s = 0): one multi-right-hand-side solve instead of
+        one factorisation per candidate; see bq_esm_border."""
+        x_a = np.ascontiguousarray(x_a, dtype=np.float64)
+        mu, cov = self._mc(1, mu, cov)
+        M = x_a.shape[0]
+        A_a, A_sc_l = np.empty(M), np.empty(M)
+        status = np.zeros(M, dtype=np.int32)
+        self._check(self._lib.bq_esm_border(
+            self._ctx, fit_l._handle(), int(ns), L.dptr(x_a), M, float(thresh), L.dptr(mu),
+            L.dptr(cov), L.dptr(A_a), L.dptr(A_sc_l), status.ctypes.data_as(L._i32p)))
+        return A_a, A_sc_l, status
+
     # -- GP fits --------------------------------------------------------------
     def gp_fit(self, x, y, h, w, s=0.0):
         return Fit(self, x, y, h, w, s)

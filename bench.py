@@ -708,6 +708,10 @@ def main():
                                   "fma_f64_tflops": eng.probe_fma_f64()}
                 wgb, cgb = eng.probe_hbm(1 << 30)
                 line["probes"].update({"hbm_write_gbs": wgb, "hbm_copy_gbs": cgb})
+                # the size of the N = 4096 Gram (134 MB, inside the 256 MiB Infinity Cache):
+                # what a kernel that only stores reaches on this box
+                wgb2, cgb2 = eng.probe_hbm(1 << 27)
+                line["probes"].update({"hbm_write_gbs_128MiB": wgb2, "hbm_copy_gbs_128MiB": cgb2})
             except Exception as e:  # probes are informational
                 line["probes"] = {"error": str(e)}
             if not a.no_extras:

@@ -216,6 +216,16 @@ int bq_bq_Z_var(bq_ctx *ctx, bq_fit *gp_log_l, bq_fit *gp_l, const double *mu, c
 int bq_esm_batch(bq_ctx *ctx, const double *x_sc, const double *l_sc, int64_t ns, int64_t nsc,
                  const double *x_a, int64_t M, double h, double w, double thresh, const double *mu,
                  const double *cov, double *A_a, double *A_sc_l, int32_t *status);
+/* The same quantities as bq_esm_batch, as a bordered UPDATE of gp_l's resident factor
+ * instead of M refactorisations (bq.py:447-527 with the jitter rule of bq_c.pyx:136): one
+ * multi-right-hand-side solve for the M borders, the candidate unit vectors, int K p and
+ * l_sc, then a c x c Woodbury system per candidate (c = candidates within `thresh`).
+ * gp_l: the fit over (x_sc, l_sc), samples first (ns of them), noise-free (s = 0) --
+ * BQ_ERR_BAD_ARG otherwise.  status[a] = 1 where the bordered matrix is not positive
+ * definite (the reference's LinAlgError fallback, bq.py:481-490). */
+int bq_esm_border(bq_ctx *ctx, bq_fit *gp_l, int64_t ns, const double *x_a, int64_t M,
+                  double thresh, const double *mu, const double *cov, double *A_a,
+                  double *A_sc_l, int32_t *status);
 
 /* ---- resident batch pipeline (what bench.py times) ------------------ */
 /* A plan owns device copies of the inputs and all workspaces, so that a run
@@ -252,6 +262,9 @@ int bq_probe_mfma444_layout(bq_ctx *ctx, int cbsz, int abid, int32_t *out8192);
 /* relative error of v_rsq_f64 raw / after one / after two Newton steps at x[0..n):
  * err3[3*i + {0,1,2}] */
 int bq_probe_rsq(bq_ctx *ctx, const double *x, int64_t n, double *err3);
+/* out[i] = the Gram kernels' own exp (exp_gauss, csrc/common.h) of x[i] <= 0: per-element
+ * accuracy probe (tests/test_gpu_parity.py::test_exp_gauss_accuracy). */
+int bq_probe_exp(bq_ctx *ctx, const double *x, int64_t n, double *out);
 /* device time per launch of a chain of n empty, dependent kernels (us) */
 int bq_probe_launch(bq_ctx *ctx, int64_t n, double *us_per_launch);
 /* One eager pass of a plan (one or two problems, outer block 64) with the profiling

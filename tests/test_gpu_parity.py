@@ -28,6 +28,35 @@ def test_mfma_f64_layout(engine):
             assert lay[l, r] == 16 * row + col, (l, r, lay[l, r])
 
 
+def test_exp_gauss_accuracy(engine):
+    """The Gram kernels' hand-written exp (csrc/common.h: ln 2 hi/lo reduction, degree-13
+    polynomial, v_ldexp_f64) per element: within 1 ulp of the true exp -- taken in x87
+    extended precision -- over 10^6 arguments of [-745.2, 0], the subnormal results
+    (x < -708.4) and the flush to zero included.  Gram parity is max|dK| / max|K| and says
+    nothing about entries 300 orders of magnitude below the diagonal; this does."""
+    from bayesian_quadrature_amd import _lib as L
+    rs = np.random.RandomState(42)
+    x = np.concatenate([rs.uniform(-745.2, 0.0, 600000), rs.uniform(-745.2, -708.0, 150000),
+                        -np.exp(rs.uniform(-40, 3, 249000)),
+                        np.array([0.0, -0.0, -1e-300, -708.396418532264, -745.1332191019411,
+                                  -745.1332191019412, -746.0, -800.0, -1e4])])
+    out = np.empty_like(x)
+    engine._check(engine._lib.bq_probe_exp(engine._ctx, L.dptr(x), x.size, L.dptr(out)))
+    truth = np.exp(x.astype(np.longdouble))
+    ref = truth.astype(np.float64)
+    ulp = np.spacing(np.maximum(np.abs(ref), np.finfo(np.float64).tiny * 2.0 ** -52))
+    err = np.abs(out.astype(np.longdouble) - truth) / ulp
+    assert np.isfinite(out).all() and (out >= 0).all()
+    assert float(err.max()) <= 1.0, (float(err.max()), x[np.argmax(err)])
+    assert out[0] == 1.0 and out[1] == 1.0 and out[-1] == 0.0 and out[-2] == 0.0
+    # no glitch at the range-reduction seams: on a sorted sample the result never falls by
+    # more than the one ulp the accuracy bound allows
+    xs = np.sort(x[:200000])
+    o2 = np.empty_like(xs)
+    engine._check(engine._lib.bq_probe_exp(engine._ctx, L.dptr(xs), xs.size, L.dptr(o2)))
+    assert (np.diff(o2) >= -np.spacing(o2[1:])).all()
+
+
 # ---- Gram ------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [1, 2, 9, 63, 64, 129, 1000])
 def test_gram_1d(engine, oracle, n):
@@ -626,6 +655,48 @@ def test_esm_batch_vs_reference_recipe(engine, oracle, ns, nc, M):
     scale = max(np.abs(ref[0]).max(), np.abs(ref[1]).max())
     assert np.max(np.abs(got[0] - ref[0])) <= tol * scale
     assert np.max(np.abs(got[1] - ref[1])) <= tol * scale
+
+
+@pytest.mark.parametrize("ns,nc,M", [(9, 2, 25), (60, 8, 40), (300, 20, 64), (1000, 24, 300)])
+def test_esm_border_vs_refactorisation(engine, oracle, ns, nc, M):
+    """bq_esm_border -- the bordered update of gp_l's resident factor, O(n^2) per candidate
+     -- against the reference's recipe, which re-factors the jittered
+    (nsc + 1)^2 matrix for every candidate (bq.py:463-480): the oracle for the smaller
+    sizes, the batched device refactorisation bq_esm_batch for all.  Same inputs as
+    test_esm_batch_vs_reference_recipe, including candidates inside the jitter radius of
+    one or two candidate points and one nearly on top of a sample."""
+    from engine_double import EngineDouble
+    from bayesian_quadrature_amd import bq_c
+    rs = np.random.RandomState(ns + M)
+    xs = np.linspace(-5, 5, ns)
+    dx = 10.0 / (ns - 1)
+    xc = rs.uniform(-6, 6, 4 * nc)
+    bq_c.filter_candidates(xc, xs, 0.4 * dx)
+    xc = np.sort(xc[~np.isnan(xc)])[:nc]
+    x_sc = np.concatenate([xs, xc])
+    l_sc = np.exp(wl.norm_logpdf(x_sc))
+    x_a = np.concatenate([rs.uniform(-7, 7, M - 4), xc[:2] + 0.05, [0.5 * (xc[0] + xc[1])],
+                          [xs[3] + 2e-4]])
+    h, w, thresh = 0.2, 1.04 * dx, 0.5
+    fit = engine.gp_fit(x_sc, l_sc, h, w, 0.0)
+    got = engine.esm_border(fit, ns, x_a, thresh, MU1, COV1)
+    chk = engine.esm_batch(x_sc, l_sc, ns, x_a, h, w, thresh, MU1, COV1)
+    assert (got[2] == 0).all() and (chk[2] == 0).all()
+    K = oracle.gram_cross(x_sc, x_sc, h, w)
+    tol = max(1e-10, 50 * np.linalg.cond(K) * 2.2e-16)
+    scale = max(np.abs(chk[0]).max(), np.abs(chk[1]).max())
+    assert np.max(np.abs(got[0] - chk[0])) <= tol * scale
+    assert np.max(np.abs(got[1] - chk[1])) <= tol * scale
+    if ns <= 300:
+        ref = EngineDouble(oracle).esm_batch(x_sc, l_sc, ns, x_a, h, w, thresh, MU1, COV1)
+        assert np.max(np.abs(got[0] - ref[0])) <= tol * scale
+        assert np.max(np.abs(got[1] - ref[1])) <= tol * scale
+    # a noisy gp_l has no Kxoxo factor to update: refused, the caller re-factors
+    noisy = engine.gp_fit(x_sc, l_sc, h, w, 1e-3)
+    with pytest.raises(ValueError):
+        engine.esm_border(noisy, ns, x_a, thresh, MU1, COV1)
+    noisy.close()
+    fit.close()
 
 
 def test_bq_expected_moments_gpu_vs_double(engine, oracle):
