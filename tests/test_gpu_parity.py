@@ -48,7 +48,7 @@ def test_exp_gauss_accuracy(engine):
     err = np.abs(out.astype(np.longdouble) - truth) / ulp
     assert np.isfinite(out).all() and (out >= 0).all()
     assert float(err.max()) <= 1.0, (float(err.max()), x[np.argmax(err)])
-    assert out[0] == 1.0 and out[1] == 1.0 and out[-1] == 0.0 and out[-2] == 0.0
+    assert (out[-9:-6] == 1.0).all() and (out[-3:] == 0.0).all()
     # no glitch at the range-reduction seams: on a sorted sample the result never falls by
     # more than the one ulp the accuracy bound allows
     xs = np.sort(x[:200000])
