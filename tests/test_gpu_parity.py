@@ -675,7 +675,7 @@ def test_esm_border_vs_refactorisation(engine, oracle, ns, nc, M):
     xc = np.sort(xc[~np.isnan(xc)])[:nc]
     x_sc = np.concatenate([xs, xc])
     l_sc = np.exp(wl.norm_logpdf(x_sc))
-    x_a = np.concatenate([rs.uniform(-7, 7, M - 4), xc[:2] + 0.05, [0.5 * (xc[0] + xc[1])],
+    x_a = np.concatenate([rs.uniform(-7, 7, M - 4), xc[:2] + 0.05, [0.5 * (xc[0] + xc[-1])],
                           [xs[3] + 2e-4]])
     h, w, thresh = 0.2, 1.04 * dx, 0.5
     fit = engine.gp_fit(x_sc, l_sc, h, w, 0.0)
