@@ -1402,8 +1402,10 @@ extern "C" int bq_plan_set_inputs(bq_ctx *c, bq_plan *p, const double *x, const 
                                   const double *xo, const double *h, const double *w,
                                   const double *s)
 {
-    if (!c || !p)
+    if (!c)
         return BQ_ERR_BAD_ARG;
+    if (!p)
+        return fail(c, BQ_ERR_BAD_ARG, "null plan handle");
     if (!x || !y || (!xo && p->M) || !h || !w || !s)
         return fail(c, BQ_ERR_BAD_ARG, "illegal value");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1465,8 +1467,10 @@ void plan_drop_graph(bq_plan *p)
 
 extern "C" int bq_plan_run(bq_ctx *c, bq_plan *p)
 {
-    if (!c || !p)
+    if (!c)
         return BQ_ERR_BAD_ARG;
+    if (!p)
+        return fail(c, BQ_ERR_BAD_ARG, "null plan handle");
     if (!p->has_inputs)
         return fail(c, BQ_ERR_BAD_ARG, "plan has no inputs");
     if (c->prof || !c->use_graph || !c->own_stream)
@@ -1509,8 +1513,10 @@ extern "C" int bq_plan_run(bq_ctx *c, bq_plan *p)
 extern "C" int bq_plan_results(bq_ctx *c, bq_plan *p, double *mean, double *var, double *logml,
                                int32_t *status)
 {
-    if (!c || !p)
+    if (!c)
         return BQ_ERR_BAD_ARG;
+    if (!p)
+        return fail(c, BQ_ERR_BAD_ARG, "null plan handle");
     const int nb = p->nprob, M = p->M;
     std::vector<double> scal((size_t)nb * 4);
     std::vector<int> info((size_t)nb);
