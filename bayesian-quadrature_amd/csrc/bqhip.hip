@@ -77,6 +77,7 @@ struct bq_ctx {
     hipStream_t cur = nullptr;    // stream the launch helpers enqueue on (stream or aux)
     hipEvent_t ev_panel = nullptr, ev_next = nullptr, ev_fork = nullptr;
     int lookahead = 1;
+    int split_batch = 1; // halves of a mid-sized batch on the two streams (BQ_SPLIT=0: lock-step)
     int la_min = 4096;   // look-ahead only while the bulk update has at least this many rows (BQ_LA_MIN)
     DevBuf panel_ws;     // scratch panel columns of the eager linalg entry points
     int gemm_lds = 1;    // LDS-staged 128x128 trailing update (BQ_GEMM_LDS)
@@ -420,6 +421,11 @@ int launch_trsm_blk(bq_ctx *c, double *X, long ldx, long xstride, int m, const d
     return BQ_OK;
 }
 
+// below this size one or two matrices sweep with the one-launch steps of outer block 64
+// (tools/potrf_sizes.py, ms with blocks 64 / 128 / 256: N = 2048 0.57 / 0.76 / 0.80,
+// 4096 1.69 / 1.93 / 1.92, 6144 4.21 / 3.72 / 3.57)
+#define BQ_SLAB_MAX 4800
+
 int auto_nb(const bq_ctx *c, int ntot, int batch)
 {
     if (c->nb_override > 0)
@@ -435,10 +441,8 @@ int auto_nb(const bq_ctx *c, int ntot, int batch)
         // the shortest chain until the k = 64 updates cost more than it saves
         // (tools/potrf_sizes.py on one matrix: N=2048 0.73 / 0.81 ms, 3072 1.24 / 1.31,
         // 4096 2.03 / 2.00, 6144 4.37 / 3.83 with blocks 64 / 128; 8192 6.49 / 6.44 with 128 / 256)
-        if (ntot < 3600)
+        if (ntot < BQ_SLAB_MAX)
             return 64;
-        if (ntot < 7200)
-            return 128;
         return 256;
     }
     if (ntot >= 1024 && mb >= 100.0)
@@ -526,11 +530,14 @@ bool panel_ws_useful(const bq_ctx *c, int ntot, int batch)
 
 // Outer block 64 (small systems): one launch per 64-column step (slab.h) after the first
 // diagonal factor and the staging of panel 0.
+// col0: global column of A's first column (a sweep over the trailing block of a larger
+// factorisation reports failures in the larger matrix's numbering)
 int enqueue_slab_sweep(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
-                       int ncols, double *dinv, int *info, double *ws)
+                       int ncols, double *dinv, int *info, double *ws, int col0 = 0)
 {
     if (ntot <= 64)
-        return launch_potf2(c, A, lda, astride, 0, dinv, BQ_DINV_STRIDE, info, batch);
+        return launch_potf2(c, A - col0 - (long)col0 * lda, lda, astride, col0, dinv,
+                            BQ_DINV_STRIDE, info, batch);
     const long sstride = 64L * ntot;
     double *S[2] = {ws, ws + sstride * batch};
     {
@@ -538,7 +545,7 @@ int enqueue_slab_sweep(bq_ctx *c, double *A, long lda, long astride, int batch, 
         Bracket br(c, BQ_K_POTF2, 64.0 * 64 * 64 / 3.0 * batch);
         hipLaunchKernelGGL(slab_first_kernel, dim3(ntot / 64, 1, batch), dim3(256), 0, c->cur, A,
                            lda, astride, S[0], (long)ntot, sstride, ntot, dinv,
-                           (long)BQ_DINV_STRIDE, info);
+                           (long)BQ_DINV_STRIDE, info, col0);
         HIPCHK(c, hipGetLastError());
     }
     for (int j0 = 0, par = 0; j0 < ncols; j0 += 64, par ^= 1) {
@@ -555,25 +562,24 @@ int enqueue_slab_sweep(bq_ctx *c, double *A, long lda, long astride, int batch, 
                                0, c->cur, A, lda, astride, S[par], S[par ^ 1], (long)ntot, sstride,
                                ntot, j0, dinv + par * BQ_DINV_HALF,
                                dinv + (par ^ 1) * BQ_DINV_HALF, (long)BQ_DINV_STRIDE, fnext,
-                               !fnext, info, c->stamp_buf + 160 * (j0 / 64));
+                               !fnext, info, col0, c->stamp_buf + 160 * (j0 / 64));
         else
             hipLaunchKernelGGL(slab_step_kernel<false>, dim3(T * (T + 1) / 2, 1, batch), dim3(256),
                                0, c->cur, A, lda, astride, S[par], S[par ^ 1], (long)ntot, sstride,
                                ntot, j0, dinv + par * BQ_DINV_HALF,
                                dinv + (par ^ 1) * BQ_DINV_HALF, (long)BQ_DINV_STRIDE, fnext,
-                               !fnext, info, (long long *)nullptr);
+                               !fnext, info, col0, (long long *)nullptr);
         HIPCHK(c, hipGetLastError());
     }
     return BQ_OK;
 }
 
-int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
-                          int ncols, double *dinv, int *info, double *panel_ws = nullptr,
-                          size_t panel_ws_len = 0)
+// nb_forced: the outer block of the whole batch when this call factors one half of it
+int enqueue_potrf_group(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
+                        int ncols, double *dinv, int *info, double *panel_ws, size_t panel_ws_len,
+                        int nb_forced)
 {
-    if ((ntot & 63) || (ncols & 63) || ncols > ntot)
-        return fail(c, BQ_ERR_BAD_ARG, "potrf: sizes must be multiples of 64");
-    const int NB = auto_nb(c, ntot, batch);
+    const int NB = nb_forced > 0 ? nb_forced : auto_nb(c, ntot, batch);
     double *ws = (panel_ws && panel_ws_len >= panel_ws_doubles(ntot, batch)) ? panel_ws : nullptr;
     if (NB == 64 && ws && ncols >= 64)
         return enqueue_slab_sweep(c, A, lda, astride, batch, ntot, ncols, dinv, info, ws);
@@ -662,10 +668,14 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
         panel_done = false;
         const int r0 = K0 + KB;
         diag_done = false;
+        // The last rows of a large matrix are a small factorisation of their own -- the
+        // Schur complement once this block's update is in --, and for one or two matrices
+        // the one-launch steps are its shortest chain: hand the rest to the slab sweep.
+        const bool to_slab = batch <= 2 && ws && NB > 64 && r0 < ncols && ntot - r0 < BQ_SLAB_MAX;
         if (r0 < ntot) {
             const double *P = A + r0 + (long)K0 * lda;
             // the trailing update also factors the next diagonal block if there is one
-            const int fj = (r0 < ncols &&
+            const int fj = (r0 < ncols && !to_slab &&
                             !gemm_uses_lds(c, ntot - r0, ntot - r0, KB, 1, batch))
                                ? r0
                                : -1;
@@ -674,8 +684,46 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
                               BQ_DINV_STRIDE, info));
             diag_done = fj >= 0;
         }
+        if (to_slab)
+            return enqueue_slab_sweep(c, A + r0 + (long)r0 * lda, lda, astride, batch, ntot - r0,
+                                      ncols - r0, dinv, info, ws, r0);
     }
     return BQ_OK;
+}
+
+// Eliminate the first ncols columns of `batch` matrices.  A batch of mid-sized matrices
+// (config C5: 64 x N = 2048) sweeps in lock-step: every 64-column panel step is two short
+// dependent launches that leave most of the chip idle, and a third of the sweep's time is
+// such panel work.  The batch is therefore cut in two halves on the two streams: one half's
+// panel chain runs beside the other half's MFMA trailing update.  (Large single matrices
+// use the second stream for the look-ahead instead, small ones the one-launch steps.)
+int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
+                          int ncols, double *dinv, int *info, double *panel_ws = nullptr,
+                          size_t panel_ws_len = 0)
+{
+    if ((ntot & 63) || (ncols & 63) || ncols > ntot)
+        return fail(c, BQ_ERR_BAD_ARG, "potrf: sizes must be multiples of 64");
+    const int NB = auto_nb(c, ntot, batch);
+    const bool la = c->lookahead && c->aux && NB >= 128 && ncols > NB &&
+                    ntot - std::min(NB, ncols) >= c->la_min;
+    if (c->split_batch && c->lookahead && c->aux && c->cur == c->stream && batch >= 8 &&
+        NB >= 128 && !la) {
+        const int b0 = batch / 2, b1 = batch - b0;
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+        c->cur = c->aux;
+        int st = enqueue_potrf_group(c, A + (long)b0 * astride, lda, astride, b1, ntot, ncols,
+                                     dinv + (long)b0 * BQ_DINV_STRIDE, info + b0, nullptr, 0, NB);
+        c->cur = c->stream;
+        if (st != BQ_OK)
+            return st;
+        HIPCHK(c, hipEventRecord(c->ev_panel, c->aux));
+        BQCHK(enqueue_potrf_group(c, A, lda, astride, b0, ntot, ncols, dinv, info, nullptr, 0, NB));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_panel, 0));
+        return BQ_OK;
+    }
+    return enqueue_potrf_group(c, A, lda, astride, batch, ntot, ncols, dinv, info, panel_ws,
+                               panel_ws_len, 0);
 }
 
 // X (mrows x npad, ld ldx) <- X L^-T, L resident (npad x npad, ld ldl), dinv[npad]
@@ -774,6 +822,8 @@ static int ctx_init(bq_ctx *c, int device)
                                   hipFuncAttributeMaxDynamicSharedMemorySize, BQ_LDS_BYTES));
     if (const char *e = std::getenv("BQ_LOOKAHEAD"))
         c->lookahead = std::atoi(e);
+    if (const char *e = std::getenv("BQ_SPLIT"))
+        c->split_batch = std::atoi(e);
     if (const char *e = std::getenv("BQ_LA_MIN"))
         c->la_min = std::atoi(e);
     if (const char *e = std::getenv("BQ_GEMM_LDS"))
@@ -1477,14 +1527,14 @@ extern "C" int bq_plan_run(bq_ctx *c, bq_plan *p)
         return plan_enqueue(c, p);
     // settings that change the launch sequence invalidate the captured graph
     if (p->graph_state == 1 && (p->graph_nb != c->nb_override || p->graph_la != c->lookahead ||
-                                p->graph_pw != c->la_min * 2 + c->gemm_lds)) {
+                                p->graph_pw != c->la_min * 4 + c->split_batch * 2 + c->gemm_lds)) {
         plan_drop_graph(p);
         p->graph_state = 0;
     }
     if (p->graph_state == 0) {
         p->graph_nb = c->nb_override;
         p->graph_la = c->lookahead;
-        p->graph_pw = c->la_min * 2 + c->gemm_lds;
+        p->graph_pw = c->la_min * 4 + c->split_batch * 2 + c->gemm_lds;
         p->graph_state = -1;
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
             const int st = plan_enqueue(c, p);

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void slab_step_kernel(double *__restrict__ 
                                                         const double *__restrict__ din,
                                                         double *__restrict__ dout, long dstride,
                                                         int factor_next, int last,
-                                                        int *__restrict__ info,
+                                                        int *__restrict__ info, int col0,
                                                         long long *stamps)
 {
 #define BQ_SSTAMP(k, dep)                                                                          \
@@ -221,7 +221,8 @@ __global__ __launch_bounds__(256, 2) void slab_step_kernel(double *__restrict__ 
             for (int r = 0; r < 4; ++r)
                 Ts[16 * wave + l15 + 64 * (16 * cb + l4 + 4 * r)] = -acc[cb][r];
         __syncthreads();
-        potf2_body(A + r0 + (long)r0 * lda, lda, r0, dout, info + b, plds, Ts, 64,
+        // (col0: the global column of this sweep's first column, for the failure report)
+        potf2_body(A + r0 + (long)r0 * lda, lda, col0 + r0, dout, info + b, plds, Ts, 64,
                    STAMP ? stamps + 5 : nullptr);
         return;
     }
@@ -246,14 +247,14 @@ __global__ __launch_bounds__(256) void slab_first_kernel(double *__restrict__ A,
                                                          long astride, double *__restrict__ S,
                                                          long lds, long sstride, int ntot,
                                                          double *__restrict__ dinv, long dstride,
-                                                         int *__restrict__ info)
+                                                         int *__restrict__ info, int col0)
 {
     __shared__ __attribute__((aligned(16))) double plds[BQ_POTF2_LDS_DOUBLES];
     const int b = blockIdx.z;
     A += (long)b * astride;
     if (blockIdx.x == 0) {
         __builtin_amdgcn_s_setprio(3);
-        potf2_body(A, lda, 0, dinv + (long)b * dstride, info + b, plds);
+        potf2_body(A, lda, col0, dinv + (long)b * dstride, info + b, plds);
         return;
     }
     // 64 rows x 64 columns per workgroup: thread t copies row (t & 63) of 16 columns
