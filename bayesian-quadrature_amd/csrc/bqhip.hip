@@ -443,7 +443,10 @@ int auto_nb(const bq_ctx *c, int ntot, int batch)
         // 4096 2.03 / 2.00, 6144 4.37 / 3.83 with blocks 64 / 128; 8192 6.49 / 6.44 with 128 / 256)
         if (ntot < BQ_SLAB_MAX)
             return 64;
-        return 256;
+        // a wider block halves the trailing update's C traffic per flop (60 instead of 56
+        // TFLOP/s at k = 512); it pays once the panel it lengthens hides behind the bulk
+        // update (N = 8192: 5.43 / 5.56 ms with 256 / 512, 12288: 13.55 / 13.11, 16384: 28.0 / 26.9)
+        return ntot < 12000 ? 256 : 512;
     }
     if (ntot >= 1024 && mb >= 100.0)
         return 256;
@@ -695,7 +698,8 @@ int enqueue_potrf_group(bq_ctx *c, double *A, long lda, long astride, int batch,
 // (config C5: 64 x N = 2048) sweeps in lock-step: every 64-column panel step is two short
 // dependent launches that leave most of the chip idle, and a third of the sweep's time is
 // such panel work.  The batch is therefore cut in two halves on the two streams: one half's
-// panel chain runs beside the other half's MFMA trailing update.  (Large single matrices
+// panel chain runs beside the other half's MFMA trailing update (C5 shard: 7.21 -> 6.78 ms;
+// three or four groups on more streams were slower, 7.8 / 7.5 ms).  (Large single matrices
 // use the second stream for the look-ahead instead, small ones the one-launch steps.)
 int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
                           int ncols, double *dinv, int *info, double *panel_ws = nullptr,

@@ -350,7 +350,10 @@ def extras(eng, nb_override):
         if n == 16384:
             # ---- C4: potrf on the matrix just built ------------------------------
             info = eng.alloc(64)
-            nb = auto_nb(n, nb_override)
+            # BASELINE config 4 names the blocking: tile = 256.  The engine's own choice at
+            # this size (512) is timed below as potrf_n16384_engine_block.
+            nb = nb_override or 256
+            eng.set_block(nb)
             tfl = wl.trailing_flops(n, nb)
 
             def potrf_runs(reps):
@@ -414,6 +417,12 @@ def extras(eng, nb_override):
                     "note": "same flops while the next block's panel kernels share the GPU"},
                 "note": "sequential launches (look-ahead off), HIP events per launch; the "
                         "algorithmic flops of a trailing launch are m^2 nb (lower half)"}
+            eng.set_block(nb_override)
+            t_auto = potrf_runs(3)
+            out["potrf_n16384_engine_block"] = {
+                "ms": min(t_auto[1:]), "gflops": wl.potrf_flops(n) / (min(t_auto[1:]) * 1e-3) / 1e9,
+                "note": "outer block chosen by the engine (512 at this size) instead of the "
+                        "config's 256"}
             eng.free(info)
         eng.free(xd)
         eng.free(Kd)
