@@ -30,7 +30,7 @@ def main():
         f = glob.glob(os.path.join(path, "**", "*_counter_collection.csv"), recursive=True)[0]
         t = pd.read_csv(f)
         t = t[t.Counter_Name == name]
-        t["short"] = t.Kernel_Name.str.extract(r"(\w+_kernel(?:<[^>]*>)?)")
+        t["short"] = t.Kernel_Name.str.extract(r"(\w+_kernel(?:<[^>]*>)?)", expand=False)
         for k, g in t.groupby("short"):
             d = out["kernels"].setdefault(k, {})
             d[name + "_bytes_avg"] = float(g.Counter_Value.mean() * 1024)
@@ -45,7 +45,7 @@ def main():
         g["FETCH_SIZE_corrected_bytes_avg"] = cshare + 2.0 * (g["FETCH_SIZE_bytes_avg"] - cshare)
         g["FETCH_SIZE_correction"] = ("C tile share (= WRITE_SIZE, 8 B/lane loads) kept, the "
                                       "LDS-DMA share (16 B/lane) doubled")
-    st["short"] = st.Name.str.extract(r"(\w+_kernel(?:<[^>]*>)?)")
+    st["short"] = st.Name.str.extract(r"(\w+_kernel(?:<[^>]*>)?)", expand=False)
     for _, r in st.iterrows():
         if r.short in out["kernels"]:
             out["kernels"][r.short]["avg_ns"] = float(r.AverageNs)

@@ -2,6 +2,7 @@
   * gram_sym_kernel<2> on the C3 points (N=4096, d=2), 10 launches
   * gram_sym_kernel<1> at N=16384, 3 launches
   * one sequential (no look-ahead) potrf at N=16384, nb=256 -> 63 trailing updates
+  * 20 passes of the C2 problem (the headline workload's slab_step_kernel)
 Used under `rocprofv3 --kernel-trace --stats` and under `rocprofv3 --pmc ...`."""
 import os
 import sys
@@ -15,7 +16,16 @@ from bayesian_quadrature_amd import workloads as wl  # noqa: E402
 
 def main():
     e = Engine(0)
+    # 20 passes of the headline problem (C2: 16 slab_step_kernel launches each)
+    c2 = wl.c2()
+    plan = e.plan(1, 1, 1024, 256)
+    plan.set_inputs(c2["x"][None], c2["y"][None], c2["xo"][None], c2["h"], c2["w"], c2["s"])
+    for _ in range(20):
+        plan.run()
+    e.sync()
+    plan.close()
     e.set_lookahead(False)
+    e.set_block(256)
     lib, ctx = e._lib, e._ctx
     c3 = wl.c3()
     pts = np.asfortranarray(c3["x"])
