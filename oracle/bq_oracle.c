@@ -23,9 +23,12 @@
  * Pinning: tests/test_oracle_known_answers.py checks this file against the
  * seven printed known answers of docs/ipynb/visual-tests.ipynb and against
  * the property contracts of the reference's own tests (tests/test_linalg_c.py,
- * tests/test_gauss_c.py).  log_lh and the noise form s^2 I have no printed
- * value anywhere in the reference: for those two items parity is UNPINNED
- * (see DESIGN.md).
+ * tests/test_gauss_c.py).  log_lh is pinned through its argmax: the printed
+ * E[Z] / V(Z) of docs/ipynb/gaussian-example.ipynb after fit_hypers(['h','w'])
+ * (tests/test_bq_object.py::test_gaussian_example_notebook, six printed
+ * digits).  The noise form s^2 I has no printed value anywhere in the
+ * reference (every fixture has s = 0): for s != 0 parity is UNPINNED (see
+ * DESIGN.md).
  *
  * Storage: every matrix is column-major (Fortran order) like the reference's
  * float64_t[::1, :] memoryviews; points are d x n (gauss_c.pyx:116-117).
