@@ -730,39 +730,102 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
                                panel_ws_len, 0);
 }
 
-// X (mrows x npad, ld ldx) <- X L^-T, L resident (npad x npad, ld ldl), dinv[npad]
-// dw: the per-block records of diag_winv_kernel (MFMA panel solve), or nullptr
-int enqueue_forward_rows(bq_ctx *c, double *X, long ldx, int mrows, const double *L, long ldl,
-                         const double *dinv, int npad, const double *dw = nullptr)
+// ---------------------------------------------------------------------------
+// Row sweeps over a RESIDENT factor (cho_solve, alpha, posterior variance, the bordered
+// acquisition update): X <- X L^-T (forward) and X <- X L^-1 (backward), right-hand sides as
+// the rows of X (mrows x npad, ld ldx).
+//
+// With 64-column steps a sweep is 2 npad / 64 dependent launches and nothing else -- 2 ms at
+// N = 4096 for 134 MB of factor.  The steps are therefore B = 256 or 512 columns wide and a
+// step's triangular solve is a product with the explicit inverse of its B x B diagonal block
+// (MAGMA's trtri-based trsm; the 16 x 16 inverses of the panel solve one level up):
+//     forward   Y_J = X_J W_J^T,   X[:, J+B:] -= Y_J L[J+B:, J]^T
+//     backward  Y_J = X_J W_J,     X[:, :J]   -= Y_J L[J, :J]
+// -- two MFMA GEMM launches per B columns, input and output in two buffers so that no step
+// copies.  NR = -W^T of every diagonal block (npad x B doubles, block J at NR + J B, ld B) is
+// built once per factor by the 64-column sweep itself applied to -I, batched over the blocks.
+// cond(W_J) <= cond(L) = sqrt(cond(K)): 1e-12 relative at the worst-conditioned configs.
+// ---------------------------------------------------------------------------
+struct WideInv {
+    const double *nr = nullptr;
+    int B = 0;
+};
+
+// the sweeps' products (few rows, a long k).  A kernel of their own with eight k-steps of
+// fragment loads in flight (instead of gemm_sub_kernel's one) was measured and gained nothing:
+// 36 us per launch at k = 512 either way -- the factor panel streams from HBM behind one
+// block of prefetch, not from L2.
+int launch_gemm_rows(bq_ctx *c, int cls, double *C, long ldc, const double *P, long ldp,
+                     const double *Q, long qsj, long qsk, int m, int n, int k)
 {
-    for (int jb = 0; jb < npad; jb += 64) {
-        const double *L11 = L + jb + (long)jb * ldl;
-        if (dw && (mrows & 15) == 0)
-            BQCHK(launch_trsm_blk(c, X + (long)jb * ldx, ldx, 0, mrows, L11, ldl, 0,
-                                  dw + (long)(jb / 64) * BQ_DINV_HALF, 0, 1));
-        else
-            BQCHK(launch_trsm<true>(c, X + (long)jb * ldx, ldx, 0, mrows, L11, ldl, 0, dinv + jb,
-                                    0, 1));
-        const int rest = npad - jb - 64;
-        if (rest > 0)
-            BQCHK(launch_gemm(c, BQ_K_GEMM, X + (long)(jb + 64) * ldx, ldx, 0,
-                              X + (long)jb * ldx, ldx, 0, L11 + 64, 1, ldl, 0, mrows, rest, 64, 0,
-                              1));
+    return launch_gemm(c, cls, C, ldc, 0, P, ldp, 0, Q, qsj, qsk, 0, m, n, k, 0, 1);
+}
+
+inline int wide_block(int npad) { return npad <= 4096 ? std::min(npad, 256) : 512; }
+inline size_t wide_doubles(int npad) { return (size_t)npad * wide_block(npad); }
+
+// dw: the per-64-block records of diag_winv_kernel (npad / 64 of them)
+int compute_wide_inverses(bq_ctx *c, const double *L, long ldl, int npad, const double *dw,
+                          double *nr)
+{
+    const int B = wide_block(npad);
+    HIPCHK(c, hipMemsetAsync(nr, 0, sizeof(double) * wide_doubles(npad), c->stream));
+    hipLaunchKernelGGL(neg_identity_kernel, dim3((npad + 255) / 256), dim3(256), 0, c->stream, nr,
+                       B, npad);
+    HIPCHK(c, hipGetLastError());
+    const int nfull = npad / B, rem = npad - nfull * B;
+    for (int part = 0; part < 2; ++part) {
+        const int batch = part == 0 ? nfull : (rem ? 1 : 0), bs = part == 0 ? B : rem;
+        const int J0 = part == 0 ? 0 : nfull * B;
+        if (batch == 0)
+            continue;
+        double *X = nr + (size_t)J0 * B; // bs x bs per block, ld B
+        const double *Ld = L + J0 + (long)J0 * ldl;
+        const long xs = (long)B * B, ls = (long)B * (1 + ldl), ds = (long)(B / 64) * BQ_DINV_HALF;
+        for (int jb = 0; jb < bs; jb += 64) {
+            const double *L11 = Ld + jb + (long)jb * ldl;
+            BQCHK(launch_trsm_blk(c, X + (long)jb * B, B, xs, bs, L11, ldl, ls,
+                                  dw + (long)((J0 + jb) / 64) * BQ_DINV_HALF, ds, batch));
+            const int rest = bs - jb - 64;
+            if (rest > 0)
+                BQCHK(launch_gemm(c, BQ_K_GEMM, X + (long)(jb + 64) * B, B, xs, X + (long)jb * B, B,
+                                  xs, L11 + 64, 1, ldl, ls, bs, rest, 64, 0, batch));
+        }
     }
     return BQ_OK;
 }
 
-// X (mrows x npad) <- X L^-1 (the L^T sweep of dpotrs in row form)
-int enqueue_backward_rows(bq_ctx *c, double *X, long ldx, int mrows, const double *L, long ldl,
-                          const double *dinv, int npad)
+// Xout (zeroed here) <- Xin L^-T; Xin is overwritten with partial sums
+int enqueue_forward_rows(bq_ctx *c, double *Xin, double *Xout, long ldx, int mrows,
+                         const double *L, long ldl, int npad, WideInv w)
 {
-    for (int jb = npad - 64; jb >= 0; jb -= 64) {
-        const double *L11 = L + jb + (long)jb * ldl;
-        BQCHK(launch_trsm<false>(c, X + (long)jb * ldx, ldx, 0, mrows, L11, ldl, 0, dinv + jb, 0,
-                                 1));
-        if (jb > 0) // X[:, 0:jb] -= X[:, jb:jb+64] * L[jb:jb+64, 0:jb]
-            BQCHK(launch_gemm(c, BQ_K_GEMM, X, ldx, 0, X + (long)jb * ldx, ldx, 0, L + jb, ldl, 1,
-                              0, mrows, jb, 64, 0, 1));
+    HIPCHK(c, hipMemsetAsync(Xout, 0, sizeof(double) * (size_t)ldx * npad, c->cur));
+    for (int J = 0; J < npad; J += w.B) {
+        const int bJ = std::min(w.B, npad - J);
+        BQCHK(launch_gemm_rows(c, BQ_K_TRSM, Xout + (long)J * ldx, ldx, Xin + (long)J * ldx, ldx,
+                               w.nr + (size_t)J * w.B, w.B, 1, mrows, bJ, bJ));
+        const int rest = npad - J - bJ;
+        if (rest > 0)
+            BQCHK(launch_gemm_rows(c, BQ_K_GEMM, Xin + (long)(J + bJ) * ldx, ldx,
+                                   Xout + (long)J * ldx, ldx, L + J + bJ + (long)J * ldl, 1, ldl,
+                                   mrows, rest, bJ));
+    }
+    return BQ_OK;
+}
+
+// Xout (zeroed here) <- Xin L^-1 (the L^T sweep of dpotrs in row form); Xin is overwritten
+int enqueue_backward_rows(bq_ctx *c, double *Xin, double *Xout, long ldx, int mrows,
+                          const double *L, long ldl, int npad, WideInv w)
+{
+    HIPCHK(c, hipMemsetAsync(Xout, 0, sizeof(double) * (size_t)ldx * npad, c->cur));
+    const int last = (npad - 1) / w.B * w.B;
+    for (int J = last; J >= 0; J -= w.B) {
+        const int bJ = std::min(w.B, npad - J);
+        BQCHK(launch_gemm_rows(c, BQ_K_TRSM, Xout + (long)J * ldx, ldx, Xin + (long)J * ldx, ldx,
+                               w.nr + (size_t)J * w.B, 1, w.B, mrows, bJ, bJ));
+        if (J > 0) // Xin[:, 0:J] -= Xout[:, J:J+bJ] L[J:J+bJ, 0:J]
+            BQCHK(launch_gemm_rows(c, BQ_K_GEMM, Xin, ldx, Xout + (long)J * ldx, ldx, L + J, ldl, 1,
+                                   mrows, J, bJ));
     }
     return BQ_OK;
 }
@@ -1159,10 +1222,17 @@ extern "C" int bq_cho_solve(bq_ctx *c, const double *L, const double *B, double 
     long ldl;
     // the strict upper triangle of L is never read by the sweeps
     BQCHK(upload_padded(c, L, (int)n, A, npad, ldl));
-    HIPCHK(c, ws.alloc(sizeof(double) * npad));
-    hipLaunchKernelGGL(diag_recip_kernel, dim3((npad + 255) / 256), dim3(256), 0, c->stream,
-                       A.d(), ldl, 0, npad, ws.d(), 0);
+    // the block inverses of the factor's diagonal: 16 x 16 (panel solve), then B wide
+    DevBuf wide, X2;
+    HIPCHK(c, ws.alloc(sizeof(double) * BQ_DINV_HALF * (size_t)(npad / 64)));
+    HIPCHK(c, wide.alloc(sizeof(double) * wide_doubles(npad)));
+    hipLaunchKernelGGL(diag_winv_kernel, dim3(npad / 64), dim3(256), 0, c->stream, A.d(), ldl,
+                       ws.d());
     HIPCHK(c, hipGetLastError());
+    BQCHK(compute_wide_inverses(c, A.d(), ldl, npad, ws.d(), wide.d()));
+    WideInv w;
+    w.nr = wide.d();
+    w.B = wide_block(npad);
     // right-hand sides as rows: X_dev is mpad x npad with X_dev[r, j] = B[j, r]
     const int mpad = (int)roundup(nrhs, 64);
     std::vector<double> host((size_t)mpad * npad, 0.0);
@@ -1170,10 +1240,11 @@ extern "C" int bq_cho_solve(bq_ctx *c, const double *L, const double *B, double 
         for (int64_t j = 0; j < n; ++j)
             host[(size_t)(r + j * mpad)] = B[j + r * n];
     HIPCHK(c, Xd.alloc(sizeof(double) * host.size()));
+    HIPCHK(c, X2.alloc(sizeof(double) * host.size()));
     HIPCHK(c, hipMemcpyAsync(Xd.p, host.data(), sizeof(double) * host.size(),
                              hipMemcpyHostToDevice, c->stream));
-    BQCHK(enqueue_forward_rows(c, Xd.d(), mpad, mpad, A.d(), ldl, ws.d(), npad));
-    BQCHK(enqueue_backward_rows(c, Xd.d(), mpad, mpad, A.d(), ldl, ws.d(), npad));
+    BQCHK(enqueue_forward_rows(c, Xd.d(), X2.d(), mpad, mpad, A.d(), ldl, npad, w));
+    BQCHK(enqueue_backward_rows(c, X2.d(), Xd.d(), mpad, mpad, A.d(), ldl, npad, w));
     HIPCHK(c, hipMemcpyAsync(host.data(), Xd.p, sizeof(double) * host.size(),
                              hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1803,7 +1874,9 @@ struct bq_fit {
     DevBuf dinv;  // npad reciprocal diagonal (+ BQ_DINV_STRIDE scratch for the factorisation)
     DevBuf panel; // scratch panel columns of the one-launch slab sweep
     DevBuf dw;    // diag_winv_kernel records of the resident factor (MFMA solves in the sweeps)
-    DevBuf wV, wx, wout, wz; // prediction workspaces, grown on demand and kept
+    DevBuf wide;  // -W^T of the B-wide diagonal blocks (row sweeps), valid if have_wide
+    bool have_wide = false;
+    DevBuf wV, wV2, wx, wout, wz; // prediction workspaces, grown on demand and kept
     DevBuf misc;  // info (int) + scal[4]
     DevBuf alpha; // npad, valid if have_alpha
     bool have_alpha = false;
@@ -1822,6 +1895,7 @@ int fit_factor(bq_ctx *c, bq_fit *f)
     double *scal = f->misc.d() + 2;
     f->valid = false;
     f->have_alpha = false;
+    f->have_wide = false;
     HIPCHK(c, hipMemcpyAsync(f->gp.p, &f->g, sizeof f->g, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(info, 0, sizeof(int), c->stream));
     BQCHK(launch_assemble(c, f->d, f->pts.d(), 0, f->y.d(), 0, static_cast<GaussParams *>(f->gp.p),
@@ -1869,19 +1943,37 @@ int check_fit(bq_ctx *c, const bq_fit *f)
     return BQ_OK;
 }
 
+// the wide block inverses of the resident factor, built on the first sweep after a (re)fit: a
+// hyper-parameter loop that only reads log-ML never pays for them
+int fit_wide(bq_ctx *c, bq_fit *f, WideInv &w)
+{
+    if (!f->have_wide) {
+        if (f->wide.bytes < sizeof(double) * wide_doubles(f->npad))
+            HIPCHK(c, f->wide.alloc(sizeof(double) * wide_doubles(f->npad)));
+        BQCHK(compute_wide_inverses(c, f->A.d(), f->ldl, f->npad, f->dw.d(), f->wide.d()));
+        f->have_wide = true;
+    }
+    w.nr = f->wide.d();
+    w.B = wide_block(f->npad);
+    return BQ_OK;
+}
+
 int fit_alpha(bq_ctx *c, bq_fit *f)
 {
     if (f->have_alpha)
         return BQ_OK;
     // row form: X (64 x npad), row 0 = z = A[yrow, 0:npad]; alpha = (X L^-1)[0, :]
-    DevBuf X;
+    WideInv w;
+    BQCHK(fit_wide(c, f, w));
+    DevBuf X, X2;
     HIPCHK(c, X.alloc(sizeof(double) * 64 * (size_t)f->npad));
+    HIPCHK(c, X2.alloc(sizeof(double) * 64 * (size_t)f->npad));
     HIPCHK(c, hipMemsetAsync(X.p, 0, X.bytes, c->stream));
     HIPCHK(c, hipMemcpy2DAsync(X.p, sizeof(double) * 64, f->A.d() + f->L.yrow,
                                sizeof(double) * f->ldl, sizeof(double), f->npad,
                                hipMemcpyDeviceToDevice, c->stream));
-    BQCHK(enqueue_backward_rows(c, X.d(), 64, 64, f->A.d(), f->ldl, f->dinv.d(), f->npad));
-    HIPCHK(c, hipMemcpy2DAsync(f->alpha.p, sizeof(double), X.p, sizeof(double) * 64,
+    BQCHK(enqueue_backward_rows(c, X.d(), X2.d(), 64, 64, f->A.d(), f->ldl, f->npad, w));
+    HIPCHK(c, hipMemcpy2DAsync(f->alpha.p, sizeof(double), X2.p, sizeof(double) * 64,
                                sizeof(double), f->npad, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     f->have_alpha = true;
@@ -2076,12 +2168,14 @@ extern "C" int bq_gp_predict(bq_ctx *c, bq_fit *f, const double *xo, int64_t M, 
         HIPCHK(c, hipGetLastError());
     } else {
         // V = K(xo, x) L^-T by a forward sweep with rows = prediction points
-        DevBuf &V = f->wV;
+        WideInv wi;
+        BQCHK(fit_wide(c, f, wi));
+        DevBuf &V0 = f->wV, &V = f->wV2;
+        HIPCHK(c, grow(V0, sizeof(double) * (size_t)Mp * npad));
         HIPCHK(c, grow(V, sizeof(double) * (size_t)Mp * npad));
-        HIPCHK(c, hipMemsetAsync(V.p, 0, sizeof(double) * (size_t)Mp * npad, c->stream));
-        BQCHK(launch_gram_cross(c, d, xod.d(), (int)M, f->pts.d(), n, g, V.d(), Mp));
-        BQCHK(enqueue_forward_rows(c, V.d(), Mp, Mp, f->A.d(), f->ldl, f->dinv.d(), npad,
-                                   f->dw.d()));
+        HIPCHK(c, hipMemsetAsync(V0.p, 0, sizeof(double) * (size_t)Mp * npad, c->stream));
+        BQCHK(launch_gram_cross(c, d, xod.d(), (int)M, f->pts.d(), n, g, V0.d(), Mp));
+        BQCHK(enqueue_forward_rows(c, V0.d(), V.d(), Mp, Mp, f->A.d(), f->ldl, npad, wi));
         // z lives in row yrow of the factor with stride ldl: gather it
         DevBuf &z = f->wz;
         HIPCHK(c, grow(z, sizeof(double) * npad));

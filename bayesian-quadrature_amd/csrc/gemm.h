@@ -615,3 +615,4 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C
         return;
     ct.store_neg(acc, lower);
 }
+

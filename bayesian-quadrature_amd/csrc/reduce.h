@@ -80,6 +80,16 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const double *__restrict__ 
     }
 }
 
+// -I on the diagonal blocks of the wide-inverse array (block J of width B at nr + J B, ld B)
+__global__ void neg_identity_kernel(double *nr, int B, int npad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x; // global row / column
+    if (i < npad) {
+        const int J = i / B * B, a = i - J;
+        nr[(size_t)J * B + a + (size_t)a * B] = -1.0;
+    }
+}
+
 // Border reductions of the acquisition loop (bq_esm_border): T = K(x_a, x_sc) K^-1 row by row
 // against the border itself, int K p and l_sc:
 //   out[3 i + 0] = sum_j T[i,j] K0[i,j],  [3 i + 1] = sum_j T[i,j] b[j],  [3 i + 2] = sum_j T[i,j] l[j]
