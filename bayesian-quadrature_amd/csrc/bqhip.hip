@@ -389,24 +389,6 @@ int launch_potf2(bq_ctx *c, double *A, long lda, long astride, int j0, double *d
     return BQ_OK;
 }
 
-template <bool TRANS>
-int launch_trsm(bq_ctx *c, double *X, long ldx, long xstride, int m, const double *L11, long ldl,
-                long lstride, const double *dinv, long dstride, int batch)
-{
-    if (m <= 0)
-        return BQ_OK;
-    Bracket br(c, BQ_K_TRSM, 64.0 * 64 * (double)m * batch);
-    // short panels: four lanes per row (latency); long ones: a row per lane (throughput)
-    if ((long)((m + 15) / 16) * batch <= 4L * c->cus)
-        hipLaunchKernelGGL(trsm_quad_kernel<TRANS>, dim3((m + 15) / 16, 1, batch), dim3(64), 0,
-                           c->cur, X, ldx, xstride, m, L11, ldl, lstride, dinv, dstride);
-    else
-        hipLaunchKernelGGL(trsm_rows_kernel<TRANS>, dim3((m + 63) / 64, 1, batch), dim3(64), 0,
-                           c->cur, X, ldx, xstride, m, L11, ldl, lstride, dinv, dstride);
-    HIPCHK(c, hipGetLastError());
-    return BQ_OK;
-}
-
 // the MFMA panel solve (trsm_blk_kernel): needs the block inverses potf2_64x4_body leaves
 // behind the 64 reciprocal pivots
 int launch_trsm_blk(bq_ctx *c, double *X, long ldx, long xstride, int m, const double *L11,
@@ -1907,9 +1889,6 @@ int fit_factor(bq_ctx *c, bq_fit *f)
         Bracket br(c, BQ_K_REDUCE);
         hipLaunchKernelGGL(finalize_kernel, dim3(1, 1, 1), dim3(256), 0, c->stream, f->A.d(),
                            f->ldl, 0L, f->L, scal, (double *)nullptr, (double *)nullptr, 1L);
-        HIPCHK(c, hipGetLastError());
-        hipLaunchKernelGGL(diag_recip_kernel, dim3((f->npad + 255) / 256), dim3(256), 0, c->stream,
-                           f->A.d(), f->ldl, 0, f->npad, f->dinv.d(), 0);
         HIPCHK(c, hipGetLastError());
         hipLaunchKernelGGL(diag_winv_kernel, dim3(f->npad / 64), dim3(256), 0, c->stream, f->A.d(),
                            f->ldl, f->dw.d());

@@ -1,286 +1,7 @@
-// trsm.h -- panel solves X <- X L11^-T / X L11^-1 (row-per-lane and quad-lane variants)
+// trsm.h -- the MFMA panel solve from 16 x 16 block inverses, and those inverses for a resident factor
 // Part of the libbqhip.so kernel set; included through kernels.h.
 #pragma once
 #include "common.h"
-
-// ---------------------------------------------------------------------------
-// Panel solve, one row per lane, 64 columns in registers; one wave per block.
-//   TRANS = true : X <- X * L11^-T   (forward substitution; Cholesky panel,
-//                                     forward solves with rows = right-hand sides)
-//   TRANS = false: X <- X * L11^-1   (backward substitution; the L^T sweep)
-// X = rows of the panel (leading dimension ldx), L11 = 64x64 lower block
-// (leading dimension ldl) with reciprocal diagonal dinv[64].  L11 is staged
-// once into LDS (TRANS: as stored; else transposed) and its entries are read
-// back as wave-wide broadcasts, two per ds_read_b128.
-// ---------------------------------------------------------------------------
-template <bool TRANS>
-__global__ __launch_bounds__(64) void trsm_rows_kernel(double *__restrict__ X, long ldx,
-                                                       long xstride, int m,
-                                                       const double *__restrict__ Lm, long ldl,
-                                                       long lstride,
-                                                       const double *__restrict__ dinv,
-                                                       long dstride)
-{
-    // T[p][j]: multiplier of x_p in the update of x_j, rows of 64 doubles
-    __shared__ __attribute__((aligned(16))) double T[64 * 64];
-    __shared__ __attribute__((aligned(16))) double di[64];
-    __builtin_amdgcn_s_setprio(3);
-    const int b = blockIdx.z;
-    const int lane = threadIdx.x;
-    const int row = blockIdx.x * 64 + lane;
-    X += (long)b * xstride;
-    const double *L11 = Lm + (long)b * lstride;
-    if (TRANS) {
-        // x_j -= L11[j][p] x_p (j > p): T[p][j] = L11[j + p ldl], coalesced copy
-#pragma unroll 8
-        for (int p = 0; p < 64; ++p)
-            T[p * 64 + lane] = L11[lane + (long)p * ldl];
-    } else {
-        // x_j -= L11[p][j] x_p (j < p): T[p][j] = L11[p + j ldl]; lane = p keeps
-        // the global read coalesced, the LDS write is strided (once per block)
-#pragma unroll 8
-        for (int j = 0; j < 64; ++j)
-            T[lane * 64 + j] = L11[lane + (long)j * ldl];
-    }
-    di[lane] = dinv[(long)b * dstride + lane];
-    const bool ok = row < m;
-    double x[64];
-    {
-        const double *pr = X + (ok ? row : 0);
-#pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            x[j] = *pr;
-            pr += ldx;
-        }
-    }
-    __syncthreads();
-    // Row p of T is fetched one column step ahead of its use (T is static), so
-    // the LDS latency hides behind the previous step's FMAs.
-    double2_t cur[32], nxt[32];
-    if (TRANS) {
-        {
-            const double2_t *t2 = reinterpret_cast<const double2_t *>(T);
-#pragma unroll
-            for (int kk = 0; kk < 32; ++kk)
-                cur[kk] = t2[kk];
-        }
-#pragma unroll
-        for (int p = 0; p < 64; ++p) {
-            if (p < 63) {
-                const double2_t *t2 = reinterpret_cast<const double2_t *>(T + (p + 1) * 64);
-#pragma unroll
-                for (int kk = (p + 2) >> 1; kk < 32; ++kk)
-                    nxt[kk] = t2[kk];
-            }
-            const double xp = x[p] * di[p];
-            x[p] = xp;
-#pragma unroll
-            for (int kk = (p + 1) >> 1; kk < 32; ++kk) {
-                if (2 * kk >= p + 1)
-                    x[2 * kk] -= cur[kk][0] * xp;
-                x[2 * kk + 1] -= cur[kk][1] * xp;
-            }
-#pragma unroll
-            for (int j = p + 1; j < 64; ++j)
-                PIN(x[j]);
-#pragma unroll
-            for (int kk = (p + 2) >> 1; kk < 32; ++kk)
-                cur[kk] = nxt[kk];
-        }
-    } else {
-        {
-            const double2_t *t2 = reinterpret_cast<const double2_t *>(T + 63 * 64);
-#pragma unroll
-            for (int kk = 0; kk < 32; ++kk)
-                cur[kk] = t2[kk];
-        }
-#pragma unroll
-        for (int p = 63; p >= 0; --p) {
-            if (p > 0) {
-                const double2_t *t2 = reinterpret_cast<const double2_t *>(T + (p - 1) * 64);
-#pragma unroll
-                for (int kk = 0; 2 * kk < p - 1; ++kk)
-                    nxt[kk] = t2[kk];
-            }
-            const double xp = x[p] * di[p];
-            x[p] = xp;
-#pragma unroll
-            for (int kk = 0; 2 * kk < p; ++kk) {
-                x[2 * kk] -= cur[kk][0] * xp;
-                if (2 * kk + 1 < p)
-                    x[2 * kk + 1] -= cur[kk][1] * xp;
-            }
-#pragma unroll
-            for (int j = 0; j < p; ++j)
-                PIN(x[j]);
-#pragma unroll
-            for (int kk = 0; 2 * kk < p - 1; ++kk)
-                cur[kk] = nxt[kk];
-        }
-    }
-    if (ok) {
-        double *pw = X + row; // opaque copy: see potf2_64_kernel
-        asm volatile("" : "+v"(pw));
-#pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            *pw = x[j];
-            pw += ldx;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Panel solve, FOUR lanes per row (a wave = 16 rows): the latency-oriented
-// variant used when the panel is short (few rows per CU).  Lane l works on row
-// l>>2 and on the 16 columns {8kk + 2g, 8kk + 2g + 1}, g = l&3, kk = 0..7, so a
-// column step costs each lane at most 16 FMAs instead of 63; the solved entry
-// x_p is handed to the other three lanes of the quad by DPP quad_perm.  The
-// multipliers come from an LDS copy of L11 whose inapplicable entries (j <= p,
-// or j >= p for the backward form) are stored as zeros, so the update needs no
-// per-lane predicate; lanes with equal g read the same address (broadcast).
-// ---------------------------------------------------------------------------
-template <int G>
-__device__ __forceinline__ double quad_bcast_f64(double v)
-{
-    constexpr int ctrl = G | (G << 2) | (G << 4) | (G << 6); // quad_perm:[G,G,G,G]
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
-template <bool TRANS, int P>
-__device__ __forceinline__ void trsm_quad_step(double (&x)[8][2], const double *T, const double *di,
-                                               int g, double2_t (&cur)[8], double2_t (&nxt)[8])
-{
-    constexpr int KK = P >> 3, GP = (P >> 1) & 3, SL = P & 1;
-    constexpr int PN = TRANS ? P + 1 : P - 1; // next column step
-    if (PN >= 0 && PN < 64) {
-        const double2_t *t2 = reinterpret_cast<const double2_t *>(T + PN * 64);
-        if (TRANS) {
-#pragma unroll
-            for (int kk = (PN >> 3); kk < 8; ++kk)
-                nxt[kk] = t2[4 * kk + g];
-        } else {
-#pragma unroll
-            for (int kk = 0; kk <= (PN >> 3); ++kk)
-                nxt[kk] = t2[4 * kk + g];
-        }
-    }
-    const double mine = x[KK][SL] * di[P];
-    const double xp = quad_bcast_f64<GP>(mine);
-    x[KK][SL] = (g == GP) ? xp : x[KK][SL];
-    if (TRANS) {
-#pragma unroll
-        for (int kk = KK; kk < 8; ++kk) {
-            x[kk][0] -= cur[kk][0] * xp;
-            x[kk][1] -= cur[kk][1] * xp;
-        }
-#pragma unroll
-        for (int kk = KK; kk < 8; ++kk) {
-            PIN(x[kk][0]);
-            PIN(x[kk][1]);
-        }
-    } else {
-#pragma unroll
-        for (int kk = 0; kk <= KK; ++kk) {
-            x[kk][0] -= cur[kk][0] * xp;
-            x[kk][1] -= cur[kk][1] * xp;
-        }
-#pragma unroll
-        for (int kk = 0; kk <= KK; ++kk) {
-            PIN(x[kk][0]);
-            PIN(x[kk][1]);
-        }
-    }
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk)
-        cur[kk] = nxt[kk];
-}
-
-template <bool TRANS, int P>
-struct TrsmQuadSteps {
-    static __device__ __forceinline__ void run(double (&x)[8][2], const double *T, const double *di,
-                                               int g, double2_t (&cur)[8], double2_t (&nxt)[8])
-    {
-        trsm_quad_step<TRANS, TRANS ? P : 63 - P>(x, T, di, g, cur, nxt);
-        TrsmQuadSteps<TRANS, P + 1>::run(x, T, di, g, cur, nxt);
-    }
-};
-template <bool TRANS>
-struct TrsmQuadSteps<TRANS, 64> {
-    static __device__ __forceinline__ void run(double (&)[8][2], const double *, const double *, int,
-                                               double2_t (&)[8], double2_t (&)[8])
-    {
-    }
-};
-
-template <bool TRANS>
-__global__ __launch_bounds__(64) void trsm_quad_kernel(double *__restrict__ X, long ldx,
-                                                       long xstride, int m,
-                                                       const double *__restrict__ Lm, long ldl,
-                                                       long lstride,
-                                                       const double *__restrict__ dinv,
-                                                       long dstride)
-{
-    __shared__ __attribute__((aligned(16))) double T[64 * 64];
-    __shared__ __attribute__((aligned(16))) double di[64];
-    __builtin_amdgcn_s_setprio(3);
-    const int b = blockIdx.z;
-    const int lane = threadIdx.x;
-    const int g = lane & 3;
-    const int row = blockIdx.x * 16 + (lane >> 2);
-    X += (long)b * xstride;
-    const double *L11 = Lm + (long)b * lstride;
-    if (TRANS) {
-        // T[p][j] = L11[j][p] for j > p, else 0
-#pragma unroll 8
-        for (int p = 0; p < 64; ++p) {
-            const double v = L11[lane + (long)p * ldl];
-            T[p * 64 + lane] = (lane > p) ? v : 0.0;
-        }
-    } else {
-        // T[p][j] = L11[p][j] for j < p, else 0 (lane = p: coalesced global read)
-#pragma unroll 8
-        for (int j = 0; j < 64; ++j) {
-            const double v = L11[lane + (long)j * ldl];
-            T[lane * 64 + j] = (j < lane) ? v : 0.0;
-        }
-    }
-    di[lane] = dinv[(long)b * dstride + lane];
-    const bool ok = row < m;
-    double x[8][2];
-    {
-        const double *pr = X + (ok ? row : 0) + (long)(2 * g) * ldx;
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            x[kk][0] = pr[0];
-            x[kk][1] = pr[ldx];
-            pr += 8 * ldx;
-        }
-    }
-    __syncthreads();
-    double2_t cur[8], nxt[8];
-    {
-        const double2_t *t2 = reinterpret_cast<const double2_t *>(T + (TRANS ? 0 : 63) * 64);
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            cur[kk] = t2[4 * kk + g];
-            nxt[kk] = cur[kk];
-        }
-    }
-    TrsmQuadSteps<TRANS, 0>::run(x, T, di, g, cur, nxt);
-    if (ok) {
-        double *pw = X + row + (long)(2 * g) * ldx;
-        asm volatile("" : "+v"(pw));
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            pw[0] = x[kk][0];
-            pw[ldx] = x[kk][1];
-            pw += 8 * ldx;
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------
 // Panel solve on the matrix cores: X (m x 64) <- X L11^-T in four 16-column block steps,
@@ -389,16 +110,6 @@ __global__ __launch_bounds__(256) void diag_winv_kernel(const double *__restrict
         for (int i = 0; i < 16; ++i)
             Wb[i] = wc[i];
     }
-}
-
-// reciprocal diagonal of a resident factor: dinv[j] = 1 / L[j0+j, j0+j]
-__global__ void diag_recip_kernel(const double *__restrict__ Lm, long ldl, long lstride, int n,
-                                  double *__restrict__ dinv, long dstride)
-{
-    const int b = blockIdx.z;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n)
-        dinv[(long)b * dstride + j] = 1.0 / Lm[(long)b * lstride + j + (long)j * ldl];
 }
 
 // ---------------------------------------------------------------------------
