@@ -777,6 +777,27 @@ int compute_wide_inverses(bq_ctx *c, const double *L, long ldl, int npad, const 
     return BQ_OK;
 }
 
+// X <- X L^-T in place, 64 columns per step from the 16 x 16 block inverses (the panel solve
+// of the factorisation): twice the launches of the wide steps, but every product is with the
+// inverse of a 16 x 16 block only.  For right-hand sides that nearly lie in the span of the
+// factor's own columns -- the borders of the acquisition update, whose Schur complement
+// k0 - |L^-1 k|^2 cancels to 1e-7 -- the 64- to 512-wide explicit inverses lose cond(L_JJ)
+// (3e-10 against 2e-12 on test_acquisition_and_posterior_vs_extended_precision).
+int enqueue_forward_rows_blk(bq_ctx *c, double *X, long ldx, int mrows, const double *L, long ldl,
+                             int npad, const double *dw)
+{
+    for (int jb = 0; jb < npad; jb += 64) {
+        const double *L11 = L + jb + (long)jb * ldl;
+        BQCHK(launch_trsm_blk(c, X + (long)jb * ldx, ldx, 0, mrows, L11, ldl, 0,
+                              dw + (long)(jb / 64) * BQ_DINV_HALF, 0, 1));
+        const int rest = npad - jb - 64;
+        if (rest > 0)
+            BQCHK(launch_gemm(c, BQ_K_GEMM, X + (long)(jb + 64) * ldx, ldx, 0, X + (long)jb * ldx,
+                              ldx, 0, L11 + 64, 1, ldl, 0, mrows, rest, 64, 0, 1));
+    }
+    return BQ_OK;
+}
+
 // Xout (zeroed here) <- Xin L^-T; Xin is overwritten with partial sums
 int enqueue_forward_rows(bq_ctx *c, double *Xin, double *Xout, long ldx, int mrows,
                          const double *L, long ldl, int npad, WideInv w)

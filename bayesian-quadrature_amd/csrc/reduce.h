@@ -90,40 +90,6 @@ __global__ void neg_identity_kernel(double *nr, int B, int npad)
     }
 }
 
-// Border reductions of the acquisition loop (bq_esm_border): T = K(x_a, x_sc) K^-1 row by row
-// against the border itself, int K p and l_sc:
-//   out[3 i + 0] = sum_j T[i,j] K0[i,j],  [3 i + 1] = sum_j T[i,j] b[j],  [3 i + 2] = sum_j T[i,j] l[j]
-__global__ __launch_bounds__(256) void border_dots_kernel(const double *__restrict__ T, long ldt,
-                                                          const double *__restrict__ K0, long ldk,
-                                                          int m, int n,
-                                                          const double *__restrict__ bvec,
-                                                          const double *__restrict__ lvec,
-                                                          double *__restrict__ out)
-{
-    const int t = threadIdx.x;
-    const int row = blockIdx.x * 64 + (t & 63);
-    const int sl = t >> 6;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    if (row < m)
-        for (int j = sl; j < n; j += 4) {
-            const double v = T[row + (long)j * ldt];
-            s0 = __builtin_fma(v, K0[row + (long)j * ldk], s0);
-            s1 = __builtin_fma(v, bvec[j], s1);
-            s2 = __builtin_fma(v, lvec[j], s2);
-        }
-    __shared__ double ps[3][4][64];
-    ps[0][sl][t & 63] = s0;
-    ps[1][sl][t & 63] = s1;
-    ps[2][sl][t & 63] = s2;
-    __syncthreads();
-    if (sl == 0 && row < m) {
-        const int r = t & 63;
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            out[3 * (long)row + k] = (ps[k][0][r] + ps[k][1][r]) + (ps[k][2][r] + ps[k][3][r]);
-    }
-}
-
 // mean_i = sum_j k(xo_i, x_j) alpha_j : fused cross-Gram x GEMV, one wave per
 // 64 outputs?  No: one block of 256 threads per output point slice would
 // starve; use one wave per output point, lanes stride over j.
