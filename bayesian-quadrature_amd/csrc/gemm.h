@@ -3,18 +3,6 @@
 #pragma once
 #include "common.h"
 
-// 1-D grid over the lower-triangular workgroup tiles of a square update:
-// t -> (bx, by), by <= bx, row by row, so no empty workgroups are launched (at
-// N=16384 the 2-D grid's early-exit workgroups cost 8 % of the trailing update)
-__device__ __forceinline__ void tri_decode(int t, int &bx, int &by)
-{
-    bx = (int)((__builtin_sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-    while ((bx + 1) * (bx + 2) / 2 <= t)
-        ++bx;
-    while (bx * (bx + 1) / 2 > t)
-        --bx;
-    by = t - bx * (bx + 1) / 2;
-}
 
 // one wave tile of C -= P Q^T (see gemm_sub_kernel); C, P, Q already point at the batch element
 template <int TM, int TN>

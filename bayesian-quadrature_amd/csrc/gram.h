@@ -4,7 +4,8 @@
 #include "common.h"
 
 // ---------------------------------------------------------------------------
-// Full symmetric Gram, K[i,j] = k(x_i,x_j) + s2 [i==j].
+// Full symmetric Gram, K[i,j] = k(x_i,x_j) + s2 [i==j], any n (the path for sizes that are
+// not whole 64 x 64 blocks; gram_tri_kernel below otherwise).
 // Block = 256 threads = a 128(i) x 64(j) tile: lane pairs two consecutive rows
 // (one 16-byte store), a wave stores 1 KiB of one column per instruction, the
 // four waves take 16 columns each.  x is d x n.
@@ -55,6 +56,64 @@ __global__ __launch_bounds__(256) void gram_sym_kernel(const double *__restrict_
             dst[0] = v0;
             if (two)
                 dst[1] = v1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The same matrix with every exp evaluated ONCE: a workgroup owns the 64 x 64 block (bi, bj),
+// bi >= bj, of the lower triangle and stores it and its transpose.  A lane holds 2 x 2
+// micro-tiles -- the two orientations of a micro-tile are both 16-byte pairs, so neither store
+// needs a shuffle -- and the 64 lanes of a wave form an 8 x 8 patch: a store instruction
+// writes 8 full 128-byte lines in either orientation (8 lanes x 16 B along the contiguous
+// direction, 8 columns).  n % 64 == 0, ldk even.  grid (T (T + 1) / 2, 1, batch), T = n / 64.
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void gram_tri_kernel(const double *__restrict__ x, long xstride,
+                                                       const GaussParams *__restrict__ gp,
+                                                       int gpstride, double *__restrict__ K,
+                                                       long ldk, long kstride, int n)
+{
+    const int b = blockIdx.z;
+    x += (long)b * xstride;
+    K += (long)b * kstride;
+    const GaussParams g = gp[(long)b * gpstride];
+    int bi, bj;
+    tri_decode(blockIdx.x, bi, bj);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 7, lj = lane >> 3;
+    // wave w sweeps the 16-column strip w of the block in four 16-row steps
+    const int j0 = 64 * bj + 16 * wave + 2 * lj;
+    double xj0[D], xj1[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        xj0[k] = x[k + (long)j0 * D];
+        xj1[k] = x[k + (long)(j0 + 1) * D];
+    }
+#pragma unroll
+    for (int si = 0; si < 4; ++si) {
+        const int i0 = 64 * bi + 16 * si + 2 * li;
+        double xi0[D], xi1[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            xi0[k] = x[k + (long)i0 * D];
+            xi1[k] = x[k + (long)(i0 + 1) * D];
+        }
+        double v00 = g.c * exp_gauss(gauss_q<D>(xi0, xj0, g));
+        double v10 = g.c * exp_gauss(gauss_q<D>(xi1, xj0, g));
+        double v01 = g.c * exp_gauss(gauss_q<D>(xi0, xj1, g));
+        double v11 = g.c * exp_gauss(gauss_q<D>(xi1, xj1, g));
+        if (i0 == j0) {
+            v00 += g.s2;
+            v11 += g.s2;
+        }
+        const double2_t c0 = {v00, v10}, c1 = {v01, v11};
+        *reinterpret_cast<double2_t *>(K + i0 + (long)j0 * ldk) = c0;
+        *reinterpret_cast<double2_t *>(K + i0 + (long)(j0 + 1) * ldk) = c1;
+        if (bi != bj) {
+            const double2_t r0 = {v00, v01}, r1 = {v10, v11};
+            *reinterpret_cast<double2_t *>(K + j0 + (long)i0 * ldk) = r0;
+            *reinterpret_cast<double2_t *>(K + j0 + (long)(i0 + 1) * ldk) = r1;
         }
     }
 }
