@@ -270,30 +270,43 @@ int launch_gram_cross(bq_ctx *c, int d, const double *x1, int n1, const double *
     return BQ_OK;
 }
 
+// fs: when set, the first launch of the slab sweep rides in the assembly (assemble_first_kernel)
+struct FirstStep {
+    double *S0 = nullptr;
+    long lds = 0, sstride = 0;
+    double *dinv = nullptr;
+    int *info = nullptr;
+};
+
 template <int D>
 void launch_assemble_d(bq_ctx *c, const double *pts, long pstride, const double *y, long ystride,
                        const GaussParams *gp, int gpstride, double *A, long lda, long astride,
-                       Layout L, int batch)
+                       Layout L, int batch, const FirstStep &fs)
 {
     dim3 grid((L.ntot + 127) / 128, (L.ntot + 63) / 64, batch);
-    hipLaunchKernelGGL(assemble_kernel<D>, grid, dim3(256), 0, c->cur, pts, pstride, y, ystride,
-                       gp, gpstride, A, lda, astride, L);
+    if (fs.S0)
+        hipLaunchKernelGGL(assemble_first_kernel<D>, grid, dim3(256), 0, c->cur, pts, pstride, y,
+                           ystride, gp, gpstride, A, lda, astride, L, fs.S0, fs.lds, fs.sstride,
+                           fs.dinv, (long)BQ_DINV_STRIDE, fs.info);
+    else
+        hipLaunchKernelGGL(assemble_kernel<D>, grid, dim3(256), 0, c->cur, pts, pstride, y, ystride,
+                           gp, gpstride, A, lda, astride, L);
 }
 
 int launch_assemble(bq_ctx *c, int d, const double *pts, long pstride, const double *y,
                     long ystride, const GaussParams *gp, int gpstride, double *A, long lda,
-                    long astride, Layout L, int batch)
+                    long astride, Layout L, int batch, const FirstStep &fs = FirstStep())
 {
     Bracket br(c, BQ_K_GRAM, 8.0 * L.ntot * (L.ntot + 1.0) / 2.0 * batch);
     switch (d) {
-    case 1: launch_assemble_d<1>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch); break;
-    case 2: launch_assemble_d<2>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch); break;
-    case 3: launch_assemble_d<3>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch); break;
-    case 4: launch_assemble_d<4>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch); break;
-    case 5: launch_assemble_d<5>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch); break;
-    case 6: launch_assemble_d<6>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch); break;
-    case 7: launch_assemble_d<7>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch); break;
-    case 8: launch_assemble_d<8>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch); break;
+    case 1: launch_assemble_d<1>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
+    case 2: launch_assemble_d<2>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
+    case 3: launch_assemble_d<3>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
+    case 4: launch_assemble_d<4>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
+    case 5: launch_assemble_d<5>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
+    case 6: launch_assemble_d<6>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
+    case 7: launch_assemble_d<7>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
+    case 8: launch_assemble_d<8>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
     default: return fail(c, BQ_ERR_BAD_ARG, "d must be in 1..%d", BQ_MAXD);
     }
     HIPCHK(c, hipGetLastError());
@@ -526,15 +539,17 @@ bool panel_ws_useful(const bq_ctx *c, int ntot, int batch)
 // col0: global column of A's first column (a sweep over the trailing block of a larger
 // factorisation reports failures in the larger matrix's numbering)
 int enqueue_slab_sweep(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
-                       int ncols, double *dinv, int *info, double *ws, int col0 = 0)
+                       int ncols, double *dinv, int *info, double *ws, int col0 = 0,
+                       bool first_done = false)
 {
     if (ntot <= 64)
         return launch_potf2(c, A - col0 - (long)col0 * lda, lda, astride, col0, dinv,
                             BQ_DINV_STRIDE, info, batch);
     const long sstride = 64L * ntot;
     double *S[2] = {ws, ws + sstride * batch};
-    {
-        // the first diagonal factor and the staging of panel 0 share a launch
+    if (!first_done) {
+        // the first diagonal factor and the staging of panel 0 share a launch (or ride in the
+        // assembly: assemble_first_kernel)
         Bracket br(c, BQ_K_POTF2, 64.0 * 64 * 64 / 3.0 * batch);
         hipLaunchKernelGGL(slab_first_kernel, dim3(ntot / 64, 1, batch), dim3(256), 0, c->cur, A,
                            lda, astride, S[0], (long)ntot, sstride, ntot, dinv,
@@ -568,14 +583,22 @@ int enqueue_slab_sweep(bq_ctx *c, double *A, long lda, long astride, int batch, 
 }
 
 // nb_forced: the outer block of the whole batch when this call factors one half of it
+// whether a factorisation of these sizes goes to the one-launch slab sweep from its first column
+bool sweep_is_slab(const bq_ctx *c, int ntot, int ncols, int batch, size_t panel_ws_len)
+{
+    return auto_nb(c, ntot, batch) == 64 && panel_ws_len >= panel_ws_doubles(ntot, batch) &&
+           ncols >= 64 && ntot > 64;
+}
+
 int enqueue_potrf_group(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
                         int ncols, double *dinv, int *info, double *panel_ws, size_t panel_ws_len,
-                        int nb_forced)
+                        int nb_forced, bool first_done = false)
 {
     const int NB = nb_forced > 0 ? nb_forced : auto_nb(c, ntot, batch);
     double *ws = (panel_ws && panel_ws_len >= panel_ws_doubles(ntot, batch)) ? panel_ws : nullptr;
     if (NB == 64 && ws && ncols >= 64)
-        return enqueue_slab_sweep(c, A, lda, astride, batch, ntot, ncols, dinv, info, ws);
+        return enqueue_slab_sweep(c, A, lda, astride, batch, ntot, ncols, dinv, info, ws, 0,
+                                  first_done);
     const bool la = c->lookahead && c->aux && NB >= 128 && ncols > NB;
     int K0 = 0;
     bool panel_done = false; // panel K0 was already factored by the look-ahead phase
@@ -693,7 +716,7 @@ int enqueue_potrf_group(bq_ctx *c, double *A, long lda, long astride, int batch,
 // use the second stream for the look-ahead instead, small ones the one-launch steps.)
 int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
                           int ncols, double *dinv, int *info, double *panel_ws = nullptr,
-                          size_t panel_ws_len = 0)
+                          size_t panel_ws_len = 0, bool first_done = false)
 {
     if ((ntot & 63) || (ncols & 63) || ncols > ntot)
         return fail(c, BQ_ERR_BAD_ARG, "potrf: sizes must be multiples of 64");
@@ -717,7 +740,7 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
         return BQ_OK;
     }
     return enqueue_potrf_group(c, A, lda, astride, batch, ntot, ncols, dinv, info, panel_ws,
-                               panel_ws_len, 0);
+                               panel_ws_len, 0, first_done);
 }
 
 // ---------------------------------------------------------------------------
@@ -1572,13 +1595,26 @@ namespace {
 
 int plan_enqueue(bq_ctx *c, bq_plan *p)
 {
-    HIPCHK(c, hipMemsetAsync(p->info.p, 0, sizeof(int) * p->nprob, c->stream));
+    // a small system's first sweep launch (and the clearing of the failure flags) rides in
+    // the assembly
+    FirstStep fs;
+    const bool fuse = sweep_is_slab(c, p->L.ntot, p->L.npad, p->nprob,
+                                    p->panel.bytes / sizeof(double));
+    if (fuse) {
+        fs.S0 = p->panel.d();
+        fs.lds = p->L.ntot;
+        fs.sstride = 64L * p->L.ntot;
+        fs.dinv = p->dinv.d();
+        fs.info = p->info.i();
+    } else {
+        HIPCHK(c, hipMemsetAsync(p->info.p, 0, sizeof(int) * p->nprob, c->stream));
+    }
     BQCHK(launch_assemble(c, p->d, p->pts.d(), (long)p->d * p->L.ntot, p->y.d(), p->L.npad,
                           static_cast<GaussParams *>(p->gp.p), 1, p->A.d(), p->lda, p->astride,
-                          p->L, p->nprob));
+                          p->L, p->nprob, fs));
     BQCHK(enqueue_potrf_partial(c, p->A.d(), p->lda, p->astride, p->nprob, p->L.ntot, p->L.npad,
                                 p->dinv.d(), p->info.i(), p->panel.d(),
-                                p->panel.bytes / sizeof(double)));
+                                p->panel.bytes / sizeof(double), fuse));
     {
         Bracket br(c, BQ_K_REDUCE, 8.0 * (p->n + 2.0 * p->M) * p->nprob);
         hipLaunchKernelGGL(finalize_kernel, dim3(1, 1, p->nprob), dim3(256), 0, c->stream,
@@ -1908,12 +1944,22 @@ int fit_factor(bq_ctx *c, bq_fit *f)
     f->have_alpha = false;
     f->have_wide = false;
     HIPCHK(c, hipMemcpyAsync(f->gp.p, &f->g, sizeof f->g, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(info, 0, sizeof(int), c->stream));
-    BQCHK(launch_assemble(c, f->d, f->pts.d(), 0, f->y.d(), 0, static_cast<GaussParams *>(f->gp.p),
-                          0, f->A.d(), f->ldl, 0, f->L, 1));
     double *scratch = f->dinv.d() + f->npad;
+    FirstStep fs;
+    const bool fuse = sweep_is_slab(c, ntot, f->npad, 1, f->panel.bytes / sizeof(double));
+    if (fuse) {
+        fs.S0 = f->panel.d();
+        fs.lds = ntot;
+        fs.sstride = 64L * ntot;
+        fs.dinv = scratch;
+        fs.info = info;
+    } else {
+        HIPCHK(c, hipMemsetAsync(info, 0, sizeof(int), c->stream));
+    }
+    BQCHK(launch_assemble(c, f->d, f->pts.d(), 0, f->y.d(), 0, static_cast<GaussParams *>(f->gp.p),
+                          0, f->A.d(), f->ldl, 0, f->L, 1, fs));
     BQCHK(enqueue_potrf_partial(c, f->A.d(), f->ldl, 0, 1, ntot, f->npad, scratch, info,
-                                f->panel.d(), f->panel.bytes / sizeof(double)));
+                                f->panel.d(), f->panel.bytes / sizeof(double), fuse));
     {
         Bracket br(c, BQ_K_REDUCE);
         hipLaunchKernelGGL(finalize_kernel, dim3(1, 1, 1), dim3(256), 0, c->stream, f->A.d(),

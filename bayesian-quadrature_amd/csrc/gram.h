@@ -163,23 +163,19 @@ struct Layout {
     int n, npad, M, yrow, ntot; // yrow < 0: no y row
 };
 
+// One 128 x 64 tile of the bordered system (pts, y, A: this problem's).  S0 != nullptr: the
+// tile's entries of rows >= 64 of column block 0 -- the unsolved first panel of the one-launch
+// slab sweep -- go to the sweep's scratch column as well (slab.h).
 template <int D>
-__global__ __launch_bounds__(256) void assemble_kernel(const double *__restrict__ pts,
-                                                       long pstride, const double *__restrict__ y,
-                                                       long ystride,
-                                                       const GaussParams *__restrict__ gp,
-                                                       int gpstride, double *__restrict__ A,
-                                                       long lda, long astride, Layout L)
+__device__ __forceinline__ void assemble_tile(const double *__restrict__ pts,
+                                              const double *__restrict__ y, const GaussParams &g,
+                                              double *__restrict__ A, long lda, const Layout &L,
+                                              double *__restrict__ S0, long lds)
 {
-    const int b = blockIdx.z;
     const int t = threadIdx.x;
     const int ib = blockIdx.x * 128, jb = blockIdx.y * 64;
     if (jb > ib + 127) // whole tile strictly above the diagonal
         return;
-    pts += (long)b * pstride;
-    y += (long)b * ystride;
-    A += (long)b * astride;
-    const GaussParams g = gp[(long)b * gpstride];
     const int i = ib + (t & 63) * 2;
     const int jbase = jb + (t >> 6) * 16;
     if (i >= L.ntot)
@@ -221,5 +217,20 @@ __global__ __launch_bounds__(256) void assemble_kernel(const double *__restrict_
         }
         double2_t vv = {v[0], v[1]};
         *reinterpret_cast<double2_t *>(A + i + (long)j * lda) = vv; // ntot, lda even
+        if (S0 && jb == 0 && i >= 64)
+            *reinterpret_cast<double2_t *>(S0 + i + (long)j * lds) = vv;
     }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void assemble_kernel(const double *__restrict__ pts,
+                                                       long pstride, const double *__restrict__ y,
+                                                       long ystride,
+                                                       const GaussParams *__restrict__ gp,
+                                                       int gpstride, double *__restrict__ A,
+                                                       long lda, long astride, Layout L)
+{
+    const int b = blockIdx.z;
+    assemble_tile<D>(pts + (long)b * pstride, y + (long)b * ystride, gp[(long)b * gpstride],
+                     A + (long)b * astride, lda, L, nullptr, 0);
 }

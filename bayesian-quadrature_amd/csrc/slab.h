@@ -241,6 +241,32 @@ __global__ __launch_bounds__(256, 2) void slab_step_kernel(double *__restrict__ 
 #undef BQ_SSTAMP
 }
 
+// The assembly of the bordered system with the first launch of the slab sweep folded in: the
+// tiles of column block 0 also fill the sweep's scratch column, and the workgroup of tile
+// (0, 0) clears the failure flag and factors the leading 64 x 64 block once its own stores are
+// out -- one launch, one memset and 12 us less per pass of a small problem.
+template <int D>
+__global__ __launch_bounds__(256) void assemble_first_kernel(
+    const double *__restrict__ pts, long pstride, const double *__restrict__ y, long ystride,
+    const GaussParams *__restrict__ gp, int gpstride, double *__restrict__ A, long lda,
+    long astride, Layout L, double *__restrict__ S0, long lds, long sstride,
+    double *__restrict__ dinv, long dstride, int *__restrict__ info)
+{
+    __shared__ __attribute__((aligned(16))) double plds[BQ_POTF2_LDS_DOUBLES];
+    const int b = blockIdx.z;
+    A += (long)b * astride;
+    assemble_tile<D>(pts + (long)b * pstride, y + (long)b * ystride, gp[(long)b * gpstride], A,
+                     lda, L, S0 + (long)b * sstride, lds);
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (threadIdx.x == 0)
+            info[b] = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // the block's 64 x 64 entries (rows 0..63 of this tile) are in memory
+        __builtin_amdgcn_s_setprio(3);
+        potf2_body(A, lda, 0, dinv + (long)b * dstride, info + b, plds);
+    }
+}
+
 // first launch of a slab sweep: workgroup 0 factors the leading diagonal block, the others
 // copy panel column 0 (rows >= 64) into the scratch column -- one launch instead of two
 __global__ __launch_bounds__(256) void slab_first_kernel(double *__restrict__ A, long lda,

@@ -53,7 +53,7 @@ def main():
     with open(os.path.join(root, "profiles", "%s_pmc_traffic.json" % tag), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print(json.dumps(out["kernels"].get("gemm_lds_kernel"), indent=1))
-    print(json.dumps(out["kernels"].get("gram_sym_kernel<2>"), indent=1))
+    print(json.dumps(out["kernels"].get("gram_tri_kernel<2>"), indent=1))
 
 
 if __name__ == "__main__":
