@@ -65,6 +65,16 @@ __device__ __forceinline__ void slab_solve16(const double (&t)[4][4], const doub
     }
 }
 
+// The ten lower 16 x 16 blocks (rb, cb) of a diagonal tile dealt to the four waves:
+//   wave 0: (0,0) (1,0) (1,1)   wave 1: (2,0) (2,1) (2,2)   wave 2: (3,0) (3,1)   wave 3: (3,2) (3,3)
+// Every wave issues THREE MFMAs per k-step: waves 2 and 3 repeat their second block into an
+// accumulator that is never stored.  (A third MFMA under `if (wave < 2)` was miscompiled into
+// a wrong block (3, 1): an MFMA ignores EXEC, so it must never sit under anything but a scalar
+// branch, and the redundant one costs nothing -- the other two waves issue three anyway.)
+#define DIAG_NB(w) ((w) < 2 ? 3 : 2)
+#define DIAG_RB(w, s) ((w) == 0 ? ((s) > 0 ? 1 : 0) : ((w) == 1 ? 2 : 3))
+#define DIAG_CB(w, s) ((w) == 0 ? ((s) == 2 ? 1 : 0) : (((w) == 3 ? 2 : 0) + ((w) >= 2 && (s) == 2 ? 1 : (s))))
+
 // STAMP: a profiling instantiation (tools/c2_timeline.py) whose workgroup 0 records s_memtime
 // at its phase boundaries; the shipped launches use STAMP = false and carry no stamp code.
 template <bool STAMP>
@@ -138,13 +148,30 @@ __global__ __launch_bounds__(256, 2) void slab_step_kernel(double *__restrict__ 
             if (bx != by)
                 slab_load16(Sin + Cb + 16 * wave + l15 + (long)l4 * lds, lds, tq);
             slab_load16(Sin + Rb + 16 * wave + l15 + (long)l4 * lds, lds, tp);
-            // C tile rows 16 wave .. +15, four 16-column blocks (negated: the MFMAs add Q P^T)
-            const double *Cin = A + Rb + 16 * wave + l15 + (long)(Cb + l4) * lda;
+            // C tile (negated: the MFMAs add Q P^T).  Off-diagonal tiles: rows 16 wave .. +15,
+            // four 16-column blocks.  Diagonal tiles need only their ten lower 16 x 16 blocks
+            // and deal them 3 / 3 / 2 / 2 to the waves (DIAG_RB / DIAG_CB): 48 MFMAs on the
+            // longest wave instead of 64 -- for workgroup (0, 0) this update sits between the
+            // launch's start and the diagonal factor.
+            if (bx == by) {
+                acc[2] = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
+                for (int sb = 0; sb < 3; ++sb)
+                    if (sb < DIAG_NB(wave)) {
+                        const double *Cin = A + Rb + 16 * DIAG_RB(wave, sb) + l15 +
+                                            (long)(Cb + 16 * DIAG_CB(wave, sb) + l4) * lda;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[cb][r] = -Cin[(long)(16 * cb + 4 * r) * lda];
+                        for (int r = 0; r < 4; ++r)
+                            acc[sb][r] = -Cin[(long)(4 * r) * lda];
+                    }
+            } else {
+                const double *Cin = A + Rb + 16 * wave + l15 + (long)(Cb + l4) * lda;
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[cb][r] = -Cin[(long)(16 * cb + 4 * r) * lda];
+            }
 #pragma unroll
             for (int q = 0; q < 6; ++q)
                 Fs[256 * q + t] = f[q];
@@ -199,27 +226,50 @@ __global__ __launch_bounds__(256, 2) void slab_step_kernel(double *__restrict__ 
     // D[n][i] = sum_k Q[n][k] P[i][k] (A operand = Q fragment from LDS, B operand = P as it
     // stands), C -= D^T
     __syncthreads();
-    BQ_SSTAMP(3, acc[3][3] + acc[0][0])
+    BQ_SSTAMP(3, acc[1][3] + acc[0][0])
+    if (bx == by) {
+        // both operands from LDS (Q = P here): block (rb, cb) += X_cb X_rb^T in D^T form
+        const int rb0 = DIAG_RB(wave, 0), rb1 = DIAG_RB(wave, 1), rb2 = DIAG_RB(wave, 2);
+        const int cb0 = DIAG_CB(wave, 0), cb1 = DIAG_CB(wave, 1), cb2 = DIAG_CB(wave, 2);
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double pf = xp[c][r];
-            const double *qrow = Qs + (16 * c + l4 + 4 * r) * 64 + l15;
+            for (int r = 0; r < 4; ++r) {
+                const double *qrow = Qs + (16 * c + l4 + 4 * r) * 64 + l15;
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(qrow[16 * cb0], qrow[16 * rb0], acc[0],
+                                                              0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(qrow[16 * cb1], qrow[16 * rb1], acc[1],
+                                                              0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(qrow[16 * cb2], qrow[16 * rb2],
+                                                              acc[2], 0, 0, 0);
+            }
+    } else {
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
-                acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(qrow[16 * cb], pf, acc[cb], 0, 0, 0);
-        }
-    BQ_SSTAMP(4, acc[3][3] + acc[0][0])
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double pf = xp[c][r];
+                const double *qrow = Qs + (16 * c + l4 + 4 * r) * 64 + l15;
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[cb] =
+                        __builtin_amdgcn_mfma_f64_16x16x4f64(qrow[16 * cb], pf, acc[cb], 0, 0, 0);
+            }
+    }
+    BQ_SSTAMP(4, acc[1][3] + acc[0][0])
     // tile column 0 is the next panel: it goes to the scratch column (the diagonal tile,
     // which workgroup 0 factors in place, and the Schur complement of the last step stay in A)
     if (blockIdx.x == 0 && factor_next) {
         // the next diagonal block never touches memory between its update and its factor
+        // (only the ten lower blocks: the factor never reads a lane above its column's own)
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+        for (int sb = 0; sb < 3; ++sb)
+            if (sb < DIAG_NB(wave)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                Ts[16 * wave + l15 + 64 * (16 * cb + l4 + 4 * r)] = -acc[cb][r];
+                for (int r = 0; r < 4; ++r)
+                    Ts[16 * DIAG_RB(wave, sb) + l15 +
+                       64 * (16 * DIAG_CB(wave, sb) + l4 + 4 * r)] = -acc[sb][r];
+            }
         __syncthreads();
         // (col0: the global column of this sweep's first column, for the failure report)
         potf2_body(A + r0 + (long)r0 * lda, lda, col0 + r0, dout, info + b, plds, Ts, 64,
@@ -230,13 +280,22 @@ __global__ __launch_bounds__(256, 2) void slab_step_kernel(double *__restrict__ 
     double *Cout = to_s ? Sout + Rb + 16 * wave + l15 + (long)l4 * lds
                         : A + Rb + 16 * wave + l15 + (long)(Cb + l4) * lda;
     const long ldo = to_s ? lds : lda;
+    if (bx == by) {
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        if (bx == by && cb > wave)
-            continue; // above the diagonal of a diagonal tile
+        for (int sb = 0; sb < 3; ++sb)
+            if (sb < DIAG_NB(wave)) {
+                double *Cd = A + Rb + 16 * DIAG_RB(wave, sb) + l15 +
+                             (long)(Cb + 16 * DIAG_CB(wave, sb) + l4) * lda;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            Cout[(long)(16 * cb + 4 * r) * ldo] = -acc[cb][r];
+                for (int r = 0; r < 4; ++r)
+                    Cd[(long)(4 * r) * lda] = -acc[sb][r];
+            }
+    } else {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Cout[(long)(16 * cb + 4 * r) * ldo] = -acc[cb][r];
     }
 #undef BQ_SSTAMP
 }
