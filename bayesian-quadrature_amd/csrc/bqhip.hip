@@ -760,7 +760,11 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
 // cond(W_J) <= cond(L) = sqrt(cond(K)): 1e-12 relative at the worst-conditioned configs.
 // ---------------------------------------------------------------------------
 struct WideInv {
-    const double *nr = nullptr;
+    const double *nr = nullptr; // -W^T of every block
+    // the single-vector sweeps (trsv.h):
+    const double *nt = nullptr; // -W (the transposes)
+    const double *tt = nullptr; // T_J^T, T_J = W_J L[J, J-B] (blocks J >= B)
+    const double *uu = nullptr; // U_J = L[J+B, J] W_J (all blocks but the last)
     int B = 0;
 };
 
@@ -774,8 +778,20 @@ int launch_gemm_rows(bq_ctx *c, int cls, double *C, long ldc, const double *P, l
     return launch_gemm(c, cls, C, ldc, 0, P, ldp, 0, Q, qsj, qsk, 0, m, n, k, 0, 1);
 }
 
-inline int wide_block(int npad) { return npad <= 4096 ? std::min(npad, 256) : 512; }
+inline int wide_block(int npad) { return npad < 2048 ? std::min(npad, 256) : 512; }
 inline size_t wide_doubles(int npad) { return (size_t)npad * wide_block(npad); }
+inline size_t wide_alloc_doubles(int npad) { return 4 * wide_doubles(npad); } // NR, NT, TT, UU
+inline WideInv wide_views(const double *base, int npad)
+{
+    WideInv w;
+    const size_t n = wide_doubles(npad);
+    w.nr = base;
+    w.nt = base + n;
+    w.tt = base + 2 * n;
+    w.uu = base + 3 * n;
+    w.B = wide_block(npad);
+    return w;
+}
 
 // dw: the per-64-block records of diag_winv_kernel (npad / 64 of them)
 int compute_wide_inverses(bq_ctx *c, const double *L, long ldl, int npad, const double *dw,
@@ -804,6 +820,96 @@ int compute_wide_inverses(bq_ctx *c, const double *L, long ldl, int npad, const 
                 BQCHK(launch_gemm(c, BQ_K_GEMM, X + (long)(jb + 64) * B, B, xs, X + (long)jb * B, B,
                                   xs, L11 + 64, 1, ldl, ls, bs, rest, 64, 0, batch));
         }
+    }
+    // NT = the blocks' transposes, behind NR
+    double *nt = nr + wide_doubles(npad), *tt = nt + wide_doubles(npad),
+           *uu = tt + wide_doubles(npad);
+    for (int part = 0; part < 2; ++part) {
+        const int batch = part == 0 ? nfull : (rem ? 1 : 0), bs = part == 0 ? B : rem;
+        if (batch == 0)
+            continue;
+        const size_t off = part == 0 ? 0 : (size_t)nfull * B * B;
+        hipLaunchKernelGGL(transpose_blocks_kernel, dim3(bs / 64, bs / 64, batch), dim3(256), 0,
+                           c->stream, nr + off, nt + off, B, (long)B * B);
+        HIPCHK(c, hipGetLastError());
+    }
+    // The couplings of neighbouring blocks for the one-launch steps of trsv.h:
+    //   T_J = W_J L[J, J-B]  (bJ x B; kept transposed)   and   U_J = L[J+B, J] W_J  (bn x B).
+    const int nblk = nfull + (rem ? 1 : 0);
+    if (nblk > 1) {
+        DevBuf tmp; // T before its transposition: a full B x B per block
+        HIPCHK(c, tmp.alloc(sizeof(double) * (size_t)nblk * B * B));
+        HIPCHK(c, hipMemsetAsync(tmp.p, 0, tmp.bytes, c->stream));
+        HIPCHK(c, hipMemsetAsync(uu, 0, sizeof(double) * wide_doubles(npad), c->stream));
+        const long bb = (long)B * B, ls = (long)B * (1 + ldl);
+        // full blocks J = B .. (nfull - 1) B, then the partial last one
+        if (nfull > 1)
+            BQCHK(launch_gemm(c, BQ_K_GEMM, tmp.d() + bb, B, bb, nt + bb, B, bb, L + B, ldl, 1, ls,
+                              B, B, B, 0, nfull - 1));
+        if (rem) {
+            const long J = (long)nfull * B;
+            BQCHK(launch_gemm(c, BQ_K_GEMM, tmp.d() + nfull * bb, B, 0, nt + J * B, B, 0,
+                              L + J + (J - B) * ldl, ldl, 1, 0, rem, B, rem, 0, 1));
+        }
+        for (int part = 0; part < 2; ++part) {
+            const int batch = part == 0 ? nfull - 1 : (rem ? 1 : 0), bs = part == 0 ? B : rem;
+            if (batch <= 0)
+                continue;
+            const size_t off = (part == 0 ? 1 : (size_t)nfull) * bb;
+            hipLaunchKernelGGL(transpose_blocks_kernel, dim3(bs / 64, B / 64, batch), dim3(256), 0,
+                               c->stream, tmp.d() + off, tt + off, B, bb);
+            HIPCHK(c, hipGetLastError());
+        }
+        // U_J for the blocks with a full neighbour below, then the one above the partial block
+        if (nfull > 1)
+            BQCHK(launch_gemm(c, BQ_K_GEMM, uu, B, bb, L + B, ldl, ls, nr, 1, B, bb, B, B, B, 0,
+                              nfull - 1));
+        if (rem) {
+            const long J = (long)(nfull - 1) * B;
+            BQCHK(launch_gemm(c, BQ_K_GEMM, uu + J * B, B, 0, L + J + B + J * ldl, ldl, 0,
+                              nr + J * B, 1, B, 0, rem, B, B, 0, 1));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream)); // tmp goes out of scope
+    }
+    return BQ_OK;
+}
+
+// One right-hand side: x (npad, consumed) -> y = L^-1 x, one launch per B columns (trsv.h)
+int enqueue_forward_vec(bq_ctx *c, double *x, double *y, const double *L, long ldl, int npad,
+                        WideInv w)
+{
+    for (int J = 0; J < npad; J += w.B) {
+        const int bJ = std::min(w.B, npad - J);
+        const int nupd = J > 0 ? (npad - J - bJ) / 64 : 0;
+        Bracket br(c, BQ_K_GEMM, (double)bJ * bJ + 2.0 * w.B * (J > 0 ? bJ + 64.0 * nupd : 0));
+#define BQ_TRSV_FWD(NB_)                                                                           \
+    hipLaunchKernelGGL((trsv_fwd_step_kernel<NB_>), dim3(bJ / 16 + nupd), dim3(1024), 0, c->cur,  \
+                       L, ldl, J, bJ, w.B, w.nr + (size_t)J * w.B, w.tt + (size_t)J * w.B, x, y)
+        if (w.B == 512)
+            BQ_TRSV_FWD(8);
+        else if (w.B == 256)
+            BQ_TRSV_FWD(4);
+        else
+            BQ_TRSV_FWD(0);
+#undef BQ_TRSV_FWD
+        HIPCHK(c, hipGetLastError());
+    }
+    return BQ_OK;
+}
+
+// x (npad, consumed) -> y = L^-T x
+int enqueue_backward_vec(bq_ctx *c, double *x, double *y, const double *L, long ldl, int npad,
+                         WideInv w)
+{
+    const int last = (npad - 1) / w.B * w.B;
+    for (int J = last; J >= 0; J -= w.B) {
+        const int bJ = std::min(w.B, npad - J);
+        const int bn = J < last ? std::min(w.B, npad - J - w.B) : 0;
+        const int nupd = bn > 0 ? J / 64 : 0;
+        Bracket br(c, BQ_K_GEMM, (double)bJ * bJ + 2.0 * bn * (bJ + 64.0 * nupd));
+        hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(bJ / 16 + nupd), dim3(1024), 0, c->cur, L, ldl,
+                           J, bJ, w.B, bn, w.nt + (size_t)J * w.B, w.uu + (size_t)J * w.B, x, y);
+        HIPCHK(c, hipGetLastError());
     }
     return BQ_OK;
 }
@@ -1259,14 +1365,24 @@ extern "C" int bq_cho_solve(bq_ctx *c, const double *L, const double *B, double 
     // the block inverses of the factor's diagonal: 16 x 16 (panel solve), then B wide
     DevBuf wide, X2;
     HIPCHK(c, ws.alloc(sizeof(double) * BQ_DINV_HALF * (size_t)(npad / 64)));
-    HIPCHK(c, wide.alloc(sizeof(double) * wide_doubles(npad)));
+    HIPCHK(c, wide.alloc(sizeof(double) * wide_alloc_doubles(npad)));
     hipLaunchKernelGGL(diag_winv_kernel, dim3(npad / 64), dim3(256), 0, c->stream, A.d(), ldl,
                        ws.d());
     HIPCHK(c, hipGetLastError());
     BQCHK(compute_wide_inverses(c, A.d(), ldl, npad, ws.d(), wide.d()));
-    WideInv w;
-    w.nr = wide.d();
-    w.B = wide_block(npad);
+    const WideInv w = wide_views(wide.d(), npad);
+    if (nrhs == 1) {
+        // one right-hand side: the GEMV sweeps (trsv.h)
+        HIPCHK(c, Xd.alloc(sizeof(double) * 2 * (size_t)npad));
+        HIPCHK(c, hipMemsetAsync(Xd.p, 0, Xd.bytes, c->stream));
+        HIPCHK(c, hipMemcpyAsync(Xd.p, B, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        double *x = Xd.d(), *y = Xd.d() + npad;
+        BQCHK(enqueue_forward_vec(c, x, y, A.d(), ldl, npad, w));
+        BQCHK(enqueue_backward_vec(c, y, x, A.d(), ldl, npad, w));
+        HIPCHK(c, hipMemcpyAsync(X, x, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return BQ_OK;
+    }
     // right-hand sides as rows: X_dev is mpad x npad with X_dev[r, j] = B[j, r]
     const int mpad = (int)roundup(nrhs, 64);
     std::vector<double> host((size_t)mpad * npad, 0.0);
@@ -1927,6 +2043,22 @@ struct bq_fit {
     DevBuf misc;  // info (int) + scal[4]
     DevBuf alpha; // npad, valid if have_alpha
     bool have_alpha = false;
+    // the single-vector sweeps (trsv.h): x | y, 2 npad doubles, and their captured launch
+    // chains -- [0] solve (forward + backward), [1] backward into alpha, [2] forward; the
+    // pointers survive a refit, so the graphs do too
+    DevBuf vec;
+    hipGraph_t vgraph[3] = {nullptr, nullptr, nullptr};
+    hipGraphExec_t vgexec[3] = {nullptr, nullptr, nullptr};
+    bool vg_failed[3] = {false, false, false};
+    ~bq_fit()
+    {
+        for (int i = 0; i < 3; ++i) {
+            if (vgexec[i])
+                (void)hipGraphExecDestroy(vgexec[i]);
+            if (vgraph[i])
+                (void)hipGraphDestroy(vgraph[i]);
+        }
+    }
     // false from the start of a (re)factorisation until it has succeeded: a refit that hits a
     // non-positive pivot leaves L, dinv, dw and the scalars overwritten with garbage
     bool valid = false;
@@ -2002,33 +2134,72 @@ int check_fit(bq_ctx *c, const bq_fit *f)
 int fit_wide(bq_ctx *c, bq_fit *f, WideInv &w)
 {
     if (!f->have_wide) {
-        if (f->wide.bytes < sizeof(double) * wide_doubles(f->npad))
-            HIPCHK(c, f->wide.alloc(sizeof(double) * wide_doubles(f->npad)));
+        if (f->wide.bytes < sizeof(double) * wide_alloc_doubles(f->npad))
+            HIPCHK(c, f->wide.alloc(sizeof(double) * wide_alloc_doubles(f->npad)));
         BQCHK(compute_wide_inverses(c, f->A.d(), f->ldl, f->npad, f->dw.d(), f->wide.d()));
         f->have_wide = true;
     }
-    w.nr = f->wide.d();
-    w.B = wide_block(f->npad);
+    w = wide_views(f->wide.d(), f->npad);
     return BQ_OK;
+}
+
+// the single-vector workspace of a fit (x at vec, y at vec + npad)
+int fit_vec(bq_ctx *c, bq_fit *f)
+{
+    if (f->vec.bytes < sizeof(double) * 2 * (size_t)f->npad)
+        HIPCHK(c, f->vec.alloc(sizeof(double) * 2 * (size_t)f->npad));
+    return BQ_OK;
+}
+
+// Replays a chain of sweep launches over a fit's own buffers from a captured hipGraph (a
+// sweep is 2 npad / B launches of 2-8 us each: enqueued one by one the host is the
+// bottleneck); eager when graphs are off, under the launch profiler, or if capture fails.
+template <class F>
+int fit_replay(bq_ctx *c, bq_fit *f, int slot, F &&enqueue)
+{
+    if (!c->use_graph || c->prof || !c->own_stream || c->cur != c->stream)
+        return enqueue();
+    if (!f->vgexec[slot] && !f->vg_failed[slot]) {
+        f->vg_failed[slot] = true;
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
+            const int st = enqueue();
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(c->stream, &g);
+            if (st == BQ_OK && e == hipSuccess && g &&
+                hipGraphInstantiate(&f->vgexec[slot], g, nullptr, nullptr, 0) == hipSuccess) {
+                f->vgraph[slot] = g;
+                f->vg_failed[slot] = false;
+            } else {
+                if (g)
+                    (void)hipGraphDestroy(g);
+                f->vgexec[slot] = nullptr;
+                (void)hipGetLastError();
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (f->vgexec[slot]) {
+        HIPCHK(c, hipGraphLaunch(f->vgexec[slot], c->stream));
+        return BQ_OK;
+    }
+    return enqueue();
 }
 
 int fit_alpha(bq_ctx *c, bq_fit *f)
 {
     if (f->have_alpha)
         return BQ_OK;
-    // row form: X (64 x npad), row 0 = z = A[yrow, 0:npad]; alpha = (X L^-1)[0, :]
+    // alpha = L^-T z, z = A[yrow, 0:npad] (the forward-solved y of the bordered system)
     WideInv w;
     BQCHK(fit_wide(c, f, w));
-    DevBuf X, X2;
-    HIPCHK(c, X.alloc(sizeof(double) * 64 * (size_t)f->npad));
-    HIPCHK(c, X2.alloc(sizeof(double) * 64 * (size_t)f->npad));
-    HIPCHK(c, hipMemsetAsync(X.p, 0, X.bytes, c->stream));
-    HIPCHK(c, hipMemcpy2DAsync(X.p, sizeof(double) * 64, f->A.d() + f->L.yrow,
-                               sizeof(double) * f->ldl, sizeof(double), f->npad,
-                               hipMemcpyDeviceToDevice, c->stream));
-    BQCHK(enqueue_backward_rows(c, X.d(), X2.d(), 64, 64, f->A.d(), f->ldl, f->npad, w));
-    HIPCHK(c, hipMemcpy2DAsync(f->alpha.p, sizeof(double), X2.p, sizeof(double) * 64,
-                               sizeof(double), f->npad, hipMemcpyDeviceToDevice, c->stream));
+    BQCHK(fit_vec(c, f));
+    BQCHK(fit_replay(c, f, 1, [&]() -> int {
+        HIPCHK(c, hipMemcpy2DAsync(f->vec.p, sizeof(double), f->A.d() + f->L.yrow,
+                                   sizeof(double) * f->ldl, sizeof(double), f->npad,
+                                   hipMemcpyDeviceToDevice, c->stream));
+        return enqueue_backward_vec(c, f->vec.d(), f->alpha.d(), f->A.d(), f->ldl, f->npad, w);
+    }));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     f->have_alpha = true;
     return BQ_OK;

@@ -9,6 +9,7 @@
 #include "gram.h"    // gram_sym_kernel, gram_cross_kernel, assemble_kernel
 #include "potf2.h"   // potf2_64_kernel, potf2_64x4_kernel (+ body, fusable into gemm)
 #include "trsm.h"    // trsm_blk_kernel, diag_winv_kernel
+#include "trsv.h"    // trsv_diag/fwd/bwd_kernel: single right-hand-side sweeps (GEMV form)
 #include "gemm.h"    // gemm_sub_kernel, gemm_k64_kernel, gemm_lds_kernel
 #include "slab.h"    // slab_step_kernel: one launch per 64-column step of a small system
 #include "reduce.h"  // finalize_kernel, rowdot_kernel, predict_mean_kernel, logdet_kernel, ...

@@ -142,6 +142,31 @@ def test_cho_solve(engine, oracle, n):
     assert np.allclose(A.dot(X), B)
 
 
+@pytest.mark.parametrize("n", [513, 1100, 2048, 2500, 4097])
+def test_cho_solve_vec_multi_block(engine, n):
+    """One right-hand side through several B-wide steps of the GEMV sweeps (trsv.h): full and
+    partial last blocks at B = 256 (npad < 2048) and B = 512, against LAPACK-style
+    substitution in numpy on the same factor (residual and forward error), and the same
+    answer from the row-form sweeps (the matrix entry point with two columns)."""
+    import scipy.linalg as sla
+    from bayesian_quadrature_amd import la
+    rs = np.random.RandomState(n)
+    G = rs.randn(n, 24)
+    A = np.asfortranarray(G.dot(G.T) / 24 + np.eye(n))
+    L = np.asfortranarray(np.linalg.cholesky(A))
+    b = rs.randn(n)
+    x = np.empty(n)
+    la.cho_solve_vec(L, b, x)
+    ref = sla.cho_solve((L, True), b)
+    assert relmax(x, ref) < 1e-12
+    assert np.abs(A.dot(x) - b).max() < 1e-12 * np.abs(b).max() * n
+    B2 = np.asfortranarray(np.stack([b, -2.0 * b], axis=1))
+    X2 = np.empty_like(B2, order="F")
+    engine.cho_solve(L, B2, X2, 2)
+    assert relmax(X2[:, 0], x) < 1e-12
+    assert relmax(X2[:, 1], -2.0 * x) < 1e-12
+
+
 @pytest.mark.parametrize("n", [1, 3, 10, 77, 640])
 def test_logdet(engine, oracle, n):
     from bayesian_quadrature_amd import la
@@ -624,6 +649,12 @@ def test_device_moments_vs_oracle(engine, oracle, ns, nc):
     assert relmax(f1.solve(b), oracle.cho_solve(L1, b)) < 1e-9
     B = rs.randn(ns, 3)
     assert relmax(f1.solve(B), oracle.cho_solve(L1, B)) < 1e-9
+    # the single-vector sweeps replay a captured launch chain: a second call and a call after
+    # a refit (same buffers, new factor) must follow the data, not the capture
+    assert relmax(f1.solve(2.0 * b), 2.0 * oracle.cho_solve(L1, b)) < 1e-9
+    f1.refit(h1, 0.8 * w1, s1)
+    L1b, _, _ = oracle.gp_fit(xs, np.log(ls), h1, 0.8 * w1, s1)
+    assert relmax(f1.solve(b), oracle.cho_solve(L1b, b)) < 1e-9
     f1.close(), f2.close()
 
 
