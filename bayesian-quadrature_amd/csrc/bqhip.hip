@@ -775,6 +775,15 @@ struct WideInv {
 int launch_gemm_rows(bq_ctx *c, int cls, double *C, long ldc, const double *P, long ldp,
                      const double *Q, long qsj, long qsk, int m, int n, int k)
 {
+    // small products (posterior variance at C2 size): split-k tiles, gemm_splitk_kernel
+    if ((m % 32) == 0 && (n % 32) == 0 && (k % 64) == 0 && k <= 2048 &&
+        (long)(m / 32) * (n / 32) <= 4L * c->cus) {
+        Bracket br(c, cls, 2.0 * (double)m * n * k);
+        hipLaunchKernelGGL(gemm_splitk_kernel, dim3(m / 32, n / 32), dim3(256), 0, c->cur, C, ldc,
+                           P, ldp, Q, qsj, qsk, k);
+        HIPCHK(c, hipGetLastError());
+        return BQ_OK;
+    }
     return launch_gemm(c, cls, C, ldc, 0, P, ldp, 0, Q, qsj, qsk, 0, m, n, k, 0, 1);
 }
 
@@ -942,8 +951,9 @@ int enqueue_forward_rows(bq_ctx *c, double *Xin, double *Xout, long ldx, int mro
     HIPCHK(c, hipMemsetAsync(Xout, 0, sizeof(double) * (size_t)ldx * npad, c->cur));
     for (int J = 0; J < npad; J += w.B) {
         const int bJ = std::min(w.B, npad - J);
+        // (NR[k, j] read through its transposed copy: unit stride across the output columns)
         BQCHK(launch_gemm_rows(c, BQ_K_TRSM, Xout + (long)J * ldx, ldx, Xin + (long)J * ldx, ldx,
-                               w.nr + (size_t)J * w.B, w.B, 1, mrows, bJ, bJ));
+                               w.nt + (size_t)J * w.B, 1, w.B, mrows, bJ, bJ));
         const int rest = npad - J - bJ;
         if (rest > 0)
             BQCHK(launch_gemm_rows(c, BQ_K_GEMM, Xin + (long)(J + bJ) * ldx, ldx,
@@ -2409,7 +2419,7 @@ extern "C" int bq_gp_predict(bq_ctx *c, bq_fit *f, const double *xo, int64_t M, 
                                    hipMemcpyDeviceToDevice, c->stream));
         {
             Bracket br(c, BQ_K_REDUCE);
-            hipLaunchKernelGGL(rowdot_kernel, dim3(Mp / 64), dim3(256), 0, c->stream, V.d(),
+            hipLaunchKernelGGL(rowdot_kernel, dim3(Mp / 16), dim3(1024), 0, c->stream, V.d(),
                                (long)Mp, (int)M, npad, z.d(), g.c, out.d(), out.d() + Mp);
             HIPCHK(c, hipGetLastError());
         }

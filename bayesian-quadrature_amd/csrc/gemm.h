@@ -604,3 +604,69 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C
     ct.store_neg(acc, lower);
 }
 
+
+// ---------------------------------------------------------------------------
+// C (m x n) -= P (m x k) Q for the SMALL products of the row sweeps over a resident factor
+// (posterior variance at C2 size: m = 256 prediction points, n <= 768, k = 256): the 64 x 64
+// tiles of gemm_sub_kernel leave 16-48 workgroups that each walk 64 dependent k-steps with
+// one step of prefetch -- 16 us per launch, seven launches per prediction.  Here a workgroup
+// owns a 32 x 32 tile and its four waves SPLIT k (a quarter each, four k-steps of fragments
+// in flight), meet in LDS, and wave w subtracts 16 x 16 block w: 4x the workgroups, 1/4 of
+// the dependent steps.  Works on transposes like the other kernels (A operand = Q fragment,
+// B operand = P fragment, so that a D register holds 16 consecutive rows of C).
+// m, n multiples of 32, k of 16, k <= 2048.  grid (m / 32, n / 32).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_splitk_kernel(double *__restrict__ C, long ldc,
+                                                          const double *__restrict__ P, long ldp,
+                                                          const double *__restrict__ Q, long qsj,
+                                                          long qsk, int k)
+{
+    __shared__ double red[4][4][4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int kq = k >> 2, kb = wave * kq;
+    const double *pp = P + (long)blockIdx.x * 32 + l15 + (long)(kb + l4) * ldp;
+    const double *qq = Q + ((long)blockIdx.y * 32 + l15) * qsj + (long)(kb + l4) * qsk;
+    double4_t acc[2][2];
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+            acc[jb][ib] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int ks = 0; ks < kq; ks += 16) {
+        double a[4][2], b[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                a[u][h] = pp[16 * h + (long)(ks + 4 * u) * ldp];
+                b[u][h] = qq[(long)(16 * h) * qsj + (long)(ks + 4 * u) * qsk];
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib)
+                    acc[jb][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][jb], a[u][ib],
+                                                                       acc[jb][ib], 0, 0, 0);
+    }
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[wave][2 * jb + ib][r][lane] = acc[jb][ib][r];
+    __syncthreads();
+    const int jb = wave >> 1, ib = wave & 1;
+    double *cp = C + (long)blockIdx.x * 32 + 16 * ib + l15 +
+                 ((long)blockIdx.y * 32 + 16 * jb + l4) * ldc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double s = (red[0][wave][r][lane] + red[1][wave][r][lane]) +
+                         (red[2][wave][r][lane] + red[3][wave][r][lane]);
+        cp[(long)(4 * r) * ldc] -= s;
+    }
+}
