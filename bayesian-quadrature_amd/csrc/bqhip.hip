@@ -317,15 +317,21 @@ int launch_assemble(bq_ctx *c, int d, const double *pts, long pstride, const dou
 // fuse_j0 >= 0: also factor the leading 64x64 block of C (global column fuse_j0) in the
 // same launch (see gemm_sub_kernel); dinv / info as for launch_potf2
 // whether C(m x n) -= P Q^T with unit-stride Q rows goes to the LDS-staged 128 x 128 kernel:
-// enough workgroup tiles to fill the chip, whole 64 x 64 wave tiles, k in chunks of 32.
+// whole 64 x 64 wave tiles, k in chunks of 32, and at least BQ_LDS_MIN_TILES workgroup tiles.
+// (Round 1 asked for a full chip of tiles, 256.  The look-ahead's update of the next panel --
+// m x 512 columns, 100-250 tiles, on the second stream BESIDE the bulk update -- then went to
+// the register-streaming kernel at ~12 TFLOP/s and sat on the panel chain: with the LDS
+// kernel N = 16384 takes 26.5 instead of 27.1 ms, 12288 13.17 instead of 13.35; the smaller
+// sizes and the batched configs do not move.)
 // Such an update never carries the fused diagonal factor (the factor would ride on the
 // register-streaming kernel, which is slower by more than a potf2 launch costs).
+#define BQ_LDS_MIN_TILES 96
 static bool gemm_uses_lds(const bq_ctx *c, int m, int n, int k, int lower, int batch)
 {
     long a = (long)((m + 127) / 128) * ((n + 127) / 128) * batch;
     if (lower)
         a = a / 2 + 1;
-    return c->gemm_lds && a >= c->cus && n >= 128 && (m % 64) == 0 &&
+    return c->gemm_lds && a >= BQ_LDS_MIN_TILES && n >= 128 && (m % 64) == 0 &&
            (n % 64) == 0 && (k % 32) == 0;
 }
 
@@ -372,14 +378,12 @@ int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const dou
                                mode, fuse_j0, dinv, dstride, info);                                \
     } while (0)
     // a 64-column slab has no use for 128-column workgroup tiles (half of their waves idle)
-    if (tiles(128) >= cu && n >= 128) {
-        if (f444 && fuse_j0 < 0 && gemm_uses_lds(c, m, n, k, lower, batch)) {
-            dim3 g = grid_for(128);
-            hipLaunchKernelGGL(gemm_lds_kernel, g, dim3(256), BQ_LDS_BYTES, c->cur,
-                               C, ldc, cstride, P, ldp, pstride, Q, qsk, qstride, m, n, k, mode);
-        } else {
-            BQ_GEMM_SUB(4, 4, 128);
-        }
+    if (f444 && fuse_j0 < 0 && n >= 128 && gemm_uses_lds(c, m, n, k, lower, batch)) {
+        dim3 g = grid_for(128);
+        hipLaunchKernelGGL(gemm_lds_kernel, g, dim3(256), BQ_LDS_BYTES, c->cur, C, ldc, cstride, P,
+                           ldp, pstride, Q, qsk, qstride, m, n, k, mode);
+    } else if (tiles(128) >= cu && n >= 128) {
+        BQ_GEMM_SUB(4, 4, 128);
     } else if (tiles(64) >= cu / 2) {
         if (k == 64)
             hipLaunchKernelGGL((gemm_k64_kernel<2, 2>), grid_for(64), dim3(256), 0, c->cur, C, ldc,
