@@ -58,7 +58,9 @@ def pmc_traffic(kernel):
     if not files:
         return None, None
     with open(files[-1]) as f:
-        k = json.load(f)["kernels"].get(kernel)
+        ks = json.load(f)["kernels"]
+    # (the headline kernel: its launches inside the C2 passes alone, if the summary has them)
+    k = ks.get(kernel + " [C2 passes]") or ks.get(kernel)
     if not k:
         return None, None
     # FETCH_SIZE_corrected_bytes_avg: the guide's x2 for 16-B-per-lane reads applied to the
@@ -67,6 +69,29 @@ def pmc_traffic(kernel):
     return (fetch + k.get("WRITE_SIZE_bytes_avg", 0.0),
             "profiles/%s (separate rocprofv3 --pmc passes, not this run)"
             % os.path.basename(files[-1]))
+
+
+def _trsv_traffic():
+    """HBM bytes of one N=16384 single-vector solve from the committed PMC summary: the
+    totals of the trsv step kernels over tools/roofline_run.py's 4 solves, per solve (the
+    loads are 8 B per lane: FETCH_SIZE kept raw)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        ks = json.load(f)["kernels"]
+    tot, solves = 0.0, None
+    for name in ("trsv_fwd_step_kernel<8>", "trsv_bwd_step_kernel"):
+        k = ks.get(name)
+        if not k:
+            return None
+        tot += (k.get("FETCH_SIZE_corrected_bytes_total", k.get("FETCH_SIZE_bytes_total", 0.0))
+                + k.get("WRITE_SIZE_bytes_total", 0.0))
+        solves = k["launches"] / 32.0
+    return {"bytes_per_solve": tot / solves, "from": "profiles/%s (separate rocprofv3 --pmc "
+            "passes, not this run; FETCH_SIZE x 2: it tallies these coalesced 512-byte wave "
+            "loads at half)" % os.path.basename(files[-1])}
 
 
 def parse():
@@ -485,9 +510,10 @@ def solve_predict_rooflines(eng):
         t1 = min(dev, wall)
         out["cho_solve_n%d_rhs1" % n] = {
             "bound": "hbm", "achieved": byt / (t1 * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
-            "unit": "GB/s", "frac": byt / (t1 * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+            "unit": "GB/s", "frac": byt / (t1 * 1e-3) / 1e9 / PEAK_HBM_GBS,
             "ms": t1, "ms_event_brackets": dev, "ms_call_host_buffers": wall, "class_ms": cls,
             "algorithmic_bytes": byt,
+            "traffic": _trsv_traffic() if n == 16384 else None,
             "note": "bq_gp_solve on a resident factor, one right-hand side: the GEMV sweeps "
                     "of trsv.h, one launch per 512 columns (forward + backward), replayed "
                     "from a hipGraph; ms = min(event brackets, wall time of the whole call)"}

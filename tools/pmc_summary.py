@@ -36,6 +36,25 @@ def main():
             d[name + "_bytes_avg"] = float(g.Counter_Value.mean() * 1024)
             d[name + "_bytes_total"] = float(g.Counter_Value.sum() * 1024)
             d["launches"] = int(len(g))
+    # the headline workload's launches alone: roofline_run.py runs its 20 C2 passes first (16
+    # slab steps each); later slab steps belong to the tails of the N=16384 factorisations
+    for path, name in ((pw, "WRITE_SIZE"), (pf, "FETCH_SIZE")):
+        f = glob.glob(os.path.join(path, "**", "*_counter_collection.csv"), recursive=True)[0]
+        t = pd.read_csv(f)
+        t = t[(t.Counter_Name == name) & t.Kernel_Name.str.contains("slab_step_kernel<false>",
+                                                                      regex=False)]
+        t = t.sort_values("Dispatch_Id").head(320)
+        d = out["kernels"].setdefault("slab_step_kernel<false> [C2 passes]", {})
+        d[name + "_bytes_avg"] = float(t.Counter_Value.mean() * 1024)
+        d["launches"] = int(len(t))
+    # the trsv step kernels read the factor with fully coalesced 512-byte wave loads (8 B per
+    # lane): FETCH_SIZE tallies them at half like the guide's wide reads -- 1.085 GB raw per
+    # N=16384 solve against 2.147 GB that the two sweeps must read; corrected = 2 x raw
+    for kn in ("trsv_fwd_step_kernel<8>", "trsv_bwd_step_kernel"):
+        g = out["kernels"].get(kn)
+        if g and "FETCH_SIZE_bytes_total" in g:
+            g["FETCH_SIZE_corrected_bytes_total"] = 2.0 * g["FETCH_SIZE_bytes_total"]
+            g["FETCH_SIZE_correction"] = "coalesced 512-B wave loads tallied at half: x2"
     # gemm_lds_kernel reads its C tile with 8-B-per-lane loads -- every tile once, exactly
     # what it writes -- and stages P / Q by LDS-DMA, 16 B per lane, which FETCH_SIZE tallies
     # at half (MI355X_MICROARCH.md, HBM): corrected fetch = C share + 2 x the rest.

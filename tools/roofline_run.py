@@ -3,6 +3,7 @@
   * gram_sym_kernel<1> at N=16384, 3 launches
   * one sequential (no look-ahead) potrf at N=16384, nb=256 -> 63 trailing updates
   * 20 passes of the C2 problem (the headline workload's slab_step_kernel)
+  * a resident N=16384 fit and 4 single-vector solves (32 + 32 trsv step launches each)
 Used under `rocprofv3 --kernel-trace --stats` and under `rocprofv3 --pmc ...`."""
 import os
 import sys
@@ -51,6 +52,16 @@ def main():
     h = np.zeros(1, dtype=np.int32)
     e.download(h, info)
     print("potrf info", h[0])
+    e.free(xd), e.free(Kd), e.free(info)
+    # the GEMV sweeps of one right-hand side over a resident N=16384 factor
+    e.set_lookahead(True)
+    e.set_block(0)
+    fit = e.gp_fit(c4["x"], wl.norm_logpdf(c4["x"]), c4["h"], c4["w"], c4["s"])
+    b = np.random.RandomState(5).randn(n)
+    for _ in range(4):
+        fit.solve(b)
+    e.sync()
+    fit.close()
     e.close()
 
 
