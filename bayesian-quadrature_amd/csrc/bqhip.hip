@@ -455,11 +455,41 @@ int auto_nb(const bq_ctx *c, int ntot, int batch)
         // update (N = 8192: 5.43 / 5.56 ms with 256 / 512, 12288: 13.55 / 13.11, 16384: 28.0 / 26.9)
         return ntot < 12000 ? 256 : 512;
     }
+    // (batches of mid-sized matrices, recursive panels: C5 shard 6.55 / 6.42 / 6.70 / 6.57 ms
+    // with 256 / 320 / 384 / 512)
     if (ntot >= 1024 && mb >= 100.0)
-        return 256;
+        return ntot >= 2048 ? 320 : 256;
     if (ntot >= 512 && mb >= 30.0)
         return 128;
     return 64;
+}
+
+// Columns [j0, j0 + w) of a panel, recursively: the left half, ONE update of the right half's
+// columns with the whole left half, the right half.  Same flops as the left-looking slab
+// order (each 64-column slab updated with everything before it, n = 64 per launch), but two
+// thirds of a 256-wide panel's update flops are then ONE n = 128, k = 128 product -- wide
+// enough for the LDS-staged kernel -- instead of two n = 64 launches that re-stream the panel
+// (a batch's panel does not fit in L2: the n = 64 updates ran at 12 TFLOP/s; C5 shard
+// 6.8 -> see DESIGN).  A 64-column slab: its diagonal factor (unless the launch that last
+// updated it carried it: diag_done) and the solve of the rows below.
+int enqueue_panel_rec(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot, int j0,
+                      int w, double *dinv, int *info, bool diag_done)
+{
+    if (w <= 64) {
+        double *Ajj = A + j0 + (long)j0 * lda;
+        if (!diag_done)
+            BQCHK(launch_potf2(c, A, lda, astride, j0, dinv, BQ_DINV_STRIDE, info, batch));
+        return launch_trsm_blk(c, Ajj + 64, lda, astride, ntot - j0 - 64, Ajj, lda, astride, dinv,
+                               BQ_DINV_STRIDE, batch);
+    }
+    const int wl = ((w / 64 + 1) / 2) * 64, wr = w - wl;
+    BQCHK(enqueue_panel_rec(c, A, lda, astride, batch, ntot, j0, wl, dinv, info, diag_done));
+    const int r0 = j0 + wl;
+    const double *P = A + r0 + (long)j0 * lda;
+    const int fj = gemm_uses_lds(c, ntot - r0, wr, wl, 1, batch) ? -1 : r0;
+    BQCHK(launch_gemm(c, BQ_K_GEMM, A + r0 + (long)r0 * lda, lda, astride, P, lda, astride, P, 1,
+                      lda, astride, ntot - r0, wr, wl, 1, batch, fj, dinv, BQ_DINV_STRIDE, info));
+    return enqueue_panel_rec(c, A, lda, astride, batch, ntot, r0, wr, dinv, info, fj >= 0);
 }
 
 // the 64-column slabs of one outer block [K0, K0+KB): left-looking update, diagonal
@@ -500,22 +530,7 @@ int enqueue_panel(bq_ctx *c, double *A, long lda, long astride, int batch, int n
         }
         return BQ_OK;
     }
-    for (int j0 = K0; j0 < K0 + KB; j0 += 64) {
-        double *Ajj = A + j0 + (long)j0 * lda;
-        if (j0 > K0) {
-            const int fj = j0;
-            BQCHK(launch_gemm(c, BQ_K_GEMM, Ajj, lda, astride, A + j0 + (long)K0 * lda, lda,
-                              astride, A + j0 + (long)K0 * lda, 1, lda, astride, ntot - j0, 64,
-                              j0 - K0, 0, batch, fj, dinv, BQ_DINV_STRIDE, info));
-            if (fj < 0)
-                BQCHK(launch_potf2(c, A, lda, astride, j0, dinv, BQ_DINV_STRIDE, info, batch));
-        } else if (!diag_done) {
-            BQCHK(launch_potf2(c, A, lda, astride, j0, dinv, BQ_DINV_STRIDE, info, batch));
-        }
-        BQCHK(launch_trsm_blk(c, Ajj + 64, lda, astride, ntot - j0 - 64, Ajj, lda, astride, dinv,
-                              BQ_DINV_STRIDE, batch));
-    }
-    return BQ_OK;
+    return enqueue_panel_rec(c, A, lda, astride, batch, ntot, K0, KB, dinv, info, diag_done);
 }
 
 // Eliminate the first ncols columns (multiple of 64) of the ntot x ntot lower
