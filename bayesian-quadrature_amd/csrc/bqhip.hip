@@ -456,9 +456,9 @@ int auto_nb(const bq_ctx *c, int ntot, int batch)
         return ntot < 12000 ? 256 : 512;
     }
     // (batches of mid-sized matrices, recursive panels: C5 shard 6.55 / 6.42 / 6.70 / 6.57 ms
-    // with 256 / 320 / 384 / 512)
+    // with 256 / 320 / 384 / 512; 256 x C2 5.72 / 5.47 / 5.64 ms with 256 / 320 / 448)
     if (ntot >= 1024 && mb >= 100.0)
-        return ntot >= 2048 ? 320 : 256;
+        return 320;
     if (ntot >= 512 && mb >= 30.0)
         return 128;
     return 64;
