@@ -2068,6 +2068,7 @@ struct bq_fit {
     DevBuf dw;    // diag_winv_kernel records of the resident factor (MFMA solves in the sweeps)
     DevBuf wide;  // -W^T of the B-wide diagonal blocks (row sweeps), valid if have_wide
     bool have_wide = false;
+    bool have_dw = false; // dw is built on its first use: a loop that reads log-ML never pays
     DevBuf wV, wV2, wx, wout, wz; // prediction workspaces, grown on demand and kept
     DevBuf misc;  // info (int) + scal[4]
     DevBuf alpha; // npad, valid if have_alpha
@@ -2104,6 +2105,7 @@ int fit_factor(bq_ctx *c, bq_fit *f)
     f->valid = false;
     f->have_alpha = false;
     f->have_wide = false;
+    f->have_dw = false;
     HIPCHK(c, hipMemcpyAsync(f->gp.p, &f->g, sizeof f->g, hipMemcpyHostToDevice, c->stream));
     double *scratch = f->dinv.d() + f->npad;
     FirstStep fs;
@@ -2126,15 +2128,14 @@ int fit_factor(bq_ctx *c, bq_fit *f)
         hipLaunchKernelGGL(finalize_kernel, dim3(1, 1, 1), dim3(256), 0, c->stream, f->A.d(),
                            f->ldl, 0L, f->L, scal, (double *)nullptr, (double *)nullptr, 1L);
         HIPCHK(c, hipGetLastError());
-        hipLaunchKernelGGL(diag_winv_kernel, dim3(f->npad / 64), dim3(256), 0, c->stream, f->A.d(),
-                           f->ldl, f->dw.d());
-        HIPCHK(c, hipGetLastError());
     }
-    int hinfo = 0;
-    double hs[4];
-    HIPCHK(c, hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(hs, scal, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+    // one read-back: misc = [info (int, 8 bytes) | pad | scal[4]]
+    double hm[6];
+    HIPCHK(c, hipMemcpyAsync(hm, f->misc.p, sizeof hm, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    int hinfo = 0;
+    std::memcpy(&hinfo, hm, sizeof hinfo);
+    const double *hs = hm + 2;
     f->have_alpha = false;
     if (hinfo != 0)
         return fail(c, BQ_ERR_NOT_PD, "matrix is not positive definite");
@@ -2158,11 +2159,25 @@ int check_fit(bq_ctx *c, const bq_fit *f)
     return BQ_OK;
 }
 
+// the 16 x 16 block inverses of the resident factor's diagonal (the record trsm_blk_kernel
+// wants), built on their first use after a (re)fit
+int fit_dw(bq_ctx *c, bq_fit *f)
+{
+    if (!f->have_dw) {
+        hipLaunchKernelGGL(diag_winv_kernel, dim3(f->npad / 64), dim3(256), 0, c->stream, f->A.d(),
+                           f->ldl, f->dw.d());
+        HIPCHK(c, hipGetLastError());
+        f->have_dw = true;
+    }
+    return BQ_OK;
+}
+
 // the wide block inverses of the resident factor, built on the first sweep after a (re)fit: a
 // hyper-parameter loop that only reads log-ML never pays for them
 int fit_wide(bq_ctx *c, bq_fit *f, WideInv &w)
 {
     if (!f->have_wide) {
+        BQCHK(fit_dw(c, f));
         if (f->wide.bytes < sizeof(double) * wide_alloc_doubles(f->npad))
             HIPCHK(c, f->wide.alloc(sizeof(double) * wide_alloc_doubles(f->npad)));
         BQCHK(compute_wide_inverses(c, f->A.d(), f->ldl, f->npad, f->dw.d(), f->wide.d()));
