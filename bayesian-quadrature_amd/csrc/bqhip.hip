@@ -808,7 +808,12 @@ int launch_gemm_rows(bq_ctx *c, int cls, double *C, long ldc, const double *P, l
 
 inline int wide_block(int npad) { return npad < 2048 ? std::min(npad, 256) : 512; }
 inline size_t wide_doubles(int npad) { return (size_t)npad * wide_block(npad); }
-inline size_t wide_alloc_doubles(int npad) { return 4 * wide_doubles(npad); } // NR, NT, TT, UU
+// NR, NT, TT, UU and the scratch of T before its transposition (a full B x B per block)
+inline size_t wide_alloc_doubles(int npad)
+{
+    const size_t B = (size_t)wide_block(npad);
+    return 5 * wide_doubles(npad) + B * B;
+}
 inline WideInv wide_views(const double *base, int npad)
 {
     WideInv w;
@@ -865,18 +870,18 @@ int compute_wide_inverses(bq_ctx *c, const double *L, long ldl, int npad, const 
     //   T_J = W_J L[J, J-B]  (bJ x B; kept transposed)   and   U_J = L[J+B, J] W_J  (bn x B).
     const int nblk = nfull + (rem ? 1 : 0);
     if (nblk > 1) {
-        DevBuf tmp; // T before its transposition: a full B x B per block
-        HIPCHK(c, tmp.alloc(sizeof(double) * (size_t)nblk * B * B));
-        HIPCHK(c, hipMemsetAsync(tmp.p, 0, tmp.bytes, c->stream));
+        // T before its transposition: a full B x B per block, behind UU
+        double *tmp = uu + wide_doubles(npad);
+        HIPCHK(c, hipMemsetAsync(tmp, 0, sizeof(double) * (size_t)nblk * B * B, c->stream));
         HIPCHK(c, hipMemsetAsync(uu, 0, sizeof(double) * wide_doubles(npad), c->stream));
         const long bb = (long)B * B, ls = (long)B * (1 + ldl);
         // full blocks J = B .. (nfull - 1) B, then the partial last one
         if (nfull > 1)
-            BQCHK(launch_gemm(c, BQ_K_GEMM, tmp.d() + bb, B, bb, nt + bb, B, bb, L + B, ldl, 1, ls,
-                              B, B, B, 0, nfull - 1));
+            BQCHK(launch_gemm(c, BQ_K_GEMM, tmp + bb, B, bb, nt + bb, B, bb, L + B, ldl, 1, ls, B, B,
+                              B, 0, nfull - 1));
         if (rem) {
             const long J = (long)nfull * B;
-            BQCHK(launch_gemm(c, BQ_K_GEMM, tmp.d() + nfull * bb, B, 0, nt + J * B, B, 0,
+            BQCHK(launch_gemm(c, BQ_K_GEMM, tmp + nfull * bb, B, 0, nt + J * B, B, 0,
                               L + J + (J - B) * ldl, ldl, 1, 0, rem, B, rem, 0, 1));
         }
         for (int part = 0; part < 2; ++part) {
@@ -885,7 +890,7 @@ int compute_wide_inverses(bq_ctx *c, const double *L, long ldl, int npad, const 
                 continue;
             const size_t off = (part == 0 ? 1 : (size_t)nfull) * bb;
             hipLaunchKernelGGL(transpose_blocks_kernel, dim3(bs / 64, B / 64, batch), dim3(256), 0,
-                               c->stream, tmp.d() + off, tt + off, B, bb);
+                               c->stream, tmp + off, tt + off, B, bb);
             HIPCHK(c, hipGetLastError());
         }
         // U_J for the blocks with a full neighbour below, then the one above the partial block
@@ -897,7 +902,6 @@ int compute_wide_inverses(bq_ctx *c, const double *L, long ldl, int npad, const 
             BQCHK(launch_gemm(c, BQ_K_GEMM, uu + J * B, B, 0, L + J + B + J * ldl, ldl, 0,
                               nr + J * B, 1, B, 0, rem, B, B, 0, 1));
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream)); // tmp goes out of scope
     }
     return BQ_OK;
 }
@@ -2097,7 +2101,9 @@ struct bq_fit {
 
 namespace {
 
-int fit_factor(bq_ctx *c, bq_fit *f)
+// pm / pv: device buffers for the posterior mean / variance of the layout's M border points
+// (bq_gp_refit_predict), or null
+int fit_factor(bq_ctx *c, bq_fit *f, double *pm = nullptr, double *pv = nullptr)
 {
     const int ntot = f->L.ntot;
     int *info = f->misc.i();
@@ -2126,7 +2132,7 @@ int fit_factor(bq_ctx *c, bq_fit *f)
     {
         Bracket br(c, BQ_K_REDUCE);
         hipLaunchKernelGGL(finalize_kernel, dim3(1, 1, 1), dim3(256), 0, c->stream, f->A.d(),
-                           f->ldl, 0L, f->L, scal, (double *)nullptr, (double *)nullptr, 1L);
+                           f->ldl, 0L, f->L, scal, pm, pv, 64L);
         HIPCHK(c, hipGetLastError());
     }
     // one read-back: misc = [info (int, 8 bytes) | pad | scal[4]]
@@ -2238,10 +2244,12 @@ int fit_alpha(bq_ctx *c, bq_fit *f)
     WideInv w;
     BQCHK(fit_wide(c, f, w));
     BQCHK(fit_vec(c, f));
+    // (the gather stays outside the captured chain: the y row moves when the fit carries
+    // border points, bq_gp_refit_predict)
+    HIPCHK(c, hipMemcpy2DAsync(f->vec.p, sizeof(double), f->A.d() + f->L.yrow,
+                               sizeof(double) * f->ldl, sizeof(double), f->npad,
+                               hipMemcpyDeviceToDevice, c->stream));
     BQCHK(fit_replay(c, f, 1, [&]() -> int {
-        HIPCHK(c, hipMemcpy2DAsync(f->vec.p, sizeof(double), f->A.d() + f->L.yrow,
-                                   sizeof(double) * f->ldl, sizeof(double), f->npad,
-                                   hipMemcpyDeviceToDevice, c->stream));
         return enqueue_backward_vec(c, f->vec.d(), f->alpha.d(), f->A.d(), f->ldl, f->npad, w);
     }));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2328,7 +2336,54 @@ extern "C" int bq_gp_refit(bq_ctx *c, bq_fit *f, double h, const double *w, doub
     for (int k = 0; k < f->d; ++k)
         f->w[k] = w[k];
     f->g = make_params(f->d, h, w, s);
+    f->L = make_layout(f->n, 0, true);
     return fit_factor(c, f);
+}
+
+// New hyper-parameters AND the posterior at M points in the same sweep -- the body of the
+// hyper-parameter loop (bq.py:933-947: refit GP1, re-predict the candidates' mean and
+// variance).  The M points ride as border rows of the fit's own bordered system, in the
+// 64-row block that holds the y row anyway: no launch beyond the refit's, where a separate
+// bq_gp_predict after a refit first rebuilds the factor's block inverses (N = 1024: 0.75 ms
+// for refit + predict, 0.31 for this).  M <= 63; more points take the two-call route.
+extern "C" int bq_gp_refit_predict(bq_ctx *c, bq_fit *f, double h, const double *w, double s,
+                                   const double *xo, int64_t M, double *mean, double *var)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    if (!f)
+        return fail(c, BQ_ERR_BAD_ARG, "null fit handle");
+    if (M < 0 || (M > 0 && (!xo || (!mean && !var))))
+        return fail(c, BQ_ERR_BAD_ARG, "illegal value");
+    if (M == 0)
+        return bq_gp_refit(c, f, h, w, s);
+    if (M > 63) {
+        BQCHK(bq_gp_refit(c, f, h, w, s));
+        return bq_gp_predict(c, f, xo, M, mean, var, nullptr);
+    }
+    BQCHK(check_w(c, f->d, h, w, s));
+    HIPCHK(c, hipSetDevice(c->device));
+    f->h = h;
+    f->s = s;
+    for (int k = 0; k < f->d; ++k)
+        f->w[k] = w[k];
+    f->g = make_params(f->d, h, w, s);
+    f->L = make_layout(f->n, (int)M, true); // same ntot: the points share the y row's block
+    if (f->wout.bytes < sizeof(double) * 128)
+        HIPCHK(c, f->wout.alloc(sizeof(double) * 128));
+    HIPCHK(c, hipMemcpyAsync(f->pts.d() + (size_t)f->d * f->npad, xo, sizeof(double) * f->d * M,
+                             hipMemcpyHostToDevice, c->stream));
+    BQCHK(fit_factor(c, f, f->wout.d(), f->wout.d() + 64));
+    double hv[128];
+    HIPCHK(c, hipMemcpyAsync(hv, f->wout.p, sizeof hv, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < M; ++i) {
+        if (mean)
+            mean[i] = hv[i];
+        if (var)
+            var[i] = hv[64 + i];
+    }
+    return BQ_OK;
 }
 
 extern "C" void bq_fit_destroy(bq_ctx *c, bq_fit *f)

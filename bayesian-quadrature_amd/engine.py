@@ -432,6 +432,20 @@ class Fit(object):
         e = self._eng
         e._check(e._lib.bq_gp_refit(e._ctx, self._handle(), float(h), L.dptr(w), float(s)))
 
+    def refit_predict(self, h, w, s, xo):
+        """New hyper-parameters and the posterior mean / marginal variance at xo in one sweep
+        (bq_gp_refit_predict: the hyper-parameter loop's body)."""
+        w = _wvec(w, self.d)
+        xo = _pts(xo)
+        if xo.shape[0] != self.d:
+            raise ValueError("dimension mismatch")
+        M = xo.shape[1]
+        mean, var = np.empty(M), np.empty(M)
+        e = self._eng
+        e._check(e._lib.bq_gp_refit_predict(e._ctx, self._handle(), float(h), L.dptr(w), float(s),
+                                            L.dptr(xo), M, L.dptr(mean), L.dptr(var)))
+        return mean, var
+
     @property
     def logml(self):
         v = C.c_double()

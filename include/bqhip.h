@@ -140,6 +140,13 @@ int bq_gp_fit(bq_ctx *ctx, const double *x, const double *y, int64_t d, int64_t 
               const double *w, double s, bq_fit **out);
 /* same data, new hyper-parameters (the hyper-parameter loop, bq.py:933-965) */
 int bq_gp_refit(bq_ctx *ctx, bq_fit *fit, double h, const double *w, double s);
+/* new hyper-parameters and the posterior mean / marginal variance at M points xo (d x M, host)
+ * in ONE sweep: the points ride as border rows of the fit's own bordered system.  This is the
+ * body of the reference's hyper-parameter loop, bq.py:933-947 (`_set_gp_log_l_params`: set the
+ * parameters, then gp.mean(x_c) and diag gp.cov(x_c)).  mean / var may be NULL (not both);
+ * M > 63 falls back to bq_gp_refit + bq_gp_predict. */
+int bq_gp_refit_predict(bq_ctx *ctx, bq_fit *fit, double h, const double *w, double s,
+                        const double *xo, int64_t M, double *mean, double *var);
 void bq_fit_destroy(bq_ctx *ctx, bq_fit *fit);
 int bq_gp_logml(bq_ctx *ctx, bq_fit *fit, double *out);
 /* which: 0 = L (n x n, strict upper zeroed), 1 = alpha = Kxx^-1 y (n),

@@ -142,6 +142,42 @@ def test_cho_solve(engine, oracle, n):
     assert np.allclose(A.dot(X), B)
 
 
+@pytest.mark.parametrize("n,M", [(9, 3), (100, 10), (300, 63), (1024, 20)])
+def test_refit_predict_one_sweep(engine, oracle, n, M):
+    """bq_gp_refit_predict -- the hyper-parameter loop's body (bq.py:933-947): new parameters
+    and the candidates' posterior in ONE sweep, the points as border rows of the fit's own
+    system -- against the oracle and against the two-call route; the fit it leaves behind
+    (log-ML, alpha with the y row shifted by the border, a later plain refit) is the same."""
+    x, y, h, w, s = _problem(n, 70 + n)
+    xo = np.linspace(-5.5, 5.5, M) + 0.013
+    fit = engine.gp_fit(x, y, h, w, s)
+    h2, w2, s2 = 1.1 * h, 0.9 * w, 2.0 * s
+    m, v = fit.refit_predict(h2, w2, s2, xo)
+    Lo, ao, lmo = oracle.gp_fit(x, y, h2, w2, s2)
+    mo, vo = oracle.gp_predict(x, h2, w2, Lo, ao, xo)[:2]
+    k0 = h2 * h2 / (np.sqrt(2 * np.pi) * w2)
+    assert relmax(m, mo) < 1e-10
+    assert np.abs(v - vo).max() / k0 < 1e-10
+    assert abs(fit.logml - lmo) <= 1e-10 * abs(lmo)
+    assert relmax(fit.alpha(), ao) < 1e-9
+    m2, v2, _ = fit.predict(xo)                     # the resident route on the same factor
+    assert relmax(m2, mo) < 1e-10 and np.abs(v2 - vo).max() / k0 < 1e-10
+    b = np.random.RandomState(n).randn(n)
+    assert relmax(fit.solve(b), oracle.cho_solve(Lo, b)) < 1e-9
+    fit.refit(h, w, s)                               # back to a fit without border points
+    L1, a1, lm1 = oracle.gp_fit(x, y, h, w, s)
+    assert abs(fit.logml - lm1) <= 1e-10 * abs(lm1)
+    assert relmax(fit.alpha(), a1) < 1e-9
+    assert relmax(fit.z(), np.linalg.solve(L1, y)) < 1e-9
+    with pytest.raises(np.linalg.LinAlgError):       # failure leaves an invalid fit behind
+        fit.refit_predict(h, 60.0 * w, 0.0, xo)
+    with pytest.raises(np.linalg.LinAlgError):
+        fit.predict(xo)
+    m3, v3 = fit.refit_predict(h2, w2, s2, xo)
+    assert relmax(m3, mo) < 1e-10
+    fit.close()
+
+
 @pytest.mark.parametrize("n", [513, 1100, 2048, 2500, 4097])
 def test_cho_solve_vec_multi_block(engine, n):
     """One right-hand side through several B-wide steps of the GEMV sweeps (trsv.h): full and
