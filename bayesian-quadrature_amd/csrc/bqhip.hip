@@ -784,6 +784,7 @@ struct WideInv {
     const double *nt = nullptr; // -W (the transposes)
     const double *tt = nullptr; // T_J^T, T_J = W_J L[J, J-B] (blocks J >= B)
     const double *uu = nullptr; // U_J = L[J+B, J] W_J (all blocks but the last)
+    const double *t = nullptr;  // T_J itself (rows of T contiguous: the fused row-sweep step)
     int B = 0;
 };
 
@@ -822,6 +823,7 @@ inline WideInv wide_views(const double *base, int npad)
     w.nt = base + n;
     w.tt = base + 2 * n;
     w.uu = base + 3 * n;
+    w.t = base + 4 * n;
     w.B = wide_block(npad);
     return w;
 }
@@ -967,10 +969,54 @@ int enqueue_forward_rows_blk(bq_ctx *c, double *X, long ldx, int mrows, const do
     return BQ_OK;
 }
 
-// Xout (zeroed here) <- Xin L^-T; Xin is overwritten with partial sums
+// Xout <- Xin L^-T; Xin is overwritten with partial sums
 int enqueue_forward_rows(bq_ctx *c, double *Xin, double *Xout, long ldx, int mrows,
                          const double *L, long ldl, int npad, WideInv w)
 {
+    // small systems: one launch per step (rows_step_kernel), every entry of Xout written
+    if ((mrows % 32) == 0 && (w.B % 64) == 0 &&
+        (long)(mrows / 32) * (npad / 32) <= 4L * c->cus) {
+        for (int J = 0; J < npad; J += w.B) {
+            const int bJ = std::min(w.B, npad - J), rest = npad - J - bJ;
+            RowsJob a{}, b{};
+            a.C = Xout + (long)J * ldx;
+            a.ldc = ldx;
+            a.P1 = Xin + (long)J * ldx;
+            a.ldp1 = ldx;
+            a.Q1 = w.nt + (size_t)J * w.B;
+            a.qsj1 = 1;
+            a.qsk1 = w.B;
+            a.k1 = bJ;
+            a.ny = bJ / 32;
+            a.write = 1;
+            // (unused operand pairs point at valid memory: k2 = 0 never dereferences them)
+            a.P2 = a.P1, a.Q2 = a.Q1, a.ldp2 = ldx, a.qsj2 = 1, a.qsk2 = w.B;
+            b = a;
+            b.ny = 0;
+            if (J > 0) {
+                a.P2 = Xout + (long)(J - w.B) * ldx;
+                a.Q2 = w.t + (size_t)J * w.B;
+                a.k2 = w.B;
+                if (rest > 0) {
+                    b.C = Xin + (long)(J + bJ) * ldx;
+                    b.P1 = a.P2;
+                    b.Q1 = L + J + bJ + (long)(J - w.B) * ldl;
+                    b.qsj1 = 1;
+                    b.qsk1 = ldl;
+                    b.k1 = w.B;
+                    b.k2 = 0;
+                    b.ny = rest / 32;
+                    b.write = 0;
+                }
+            }
+            Bracket br(c, BQ_K_GEMM,
+                       2.0 * mrows * ((double)bJ * (a.k1 + a.k2) + (double)b.ny * 32 * b.k1));
+            hipLaunchKernelGGL(rows_step_kernel, dim3(mrows / 32, a.ny + b.ny), dim3(256), 0, c->cur,
+                               a, b);
+            HIPCHK(c, hipGetLastError());
+        }
+        return BQ_OK;
+    }
     HIPCHK(c, hipMemsetAsync(Xout, 0, sizeof(double) * (size_t)ldx * npad, c->cur));
     for (int J = 0; J < npad; J += w.B) {
         const int bJ = std::min(w.B, npad - J);

@@ -670,3 +670,87 @@ __global__ __launch_bounds__(256) void gemm_splitk_kernel(double *__restrict__ C
         cp[(long)(4 * r) * ldc] -= s;
     }
 }
+
+// ---------------------------------------------------------------------------
+// One forward step of the row sweep over a resident factor in ONE launch, for the small
+// systems gemm_splitk_kernel serves.  With T_J = W_J L[J, J-B] (trsv.h) the step's two products
+//     Y_J            = X_J W_J^T - Y_{J-B} T_J^T          (job a: written, k = bJ + B)
+//     X[:, J + bJ:] -= Y_{J-B} L[J + bJ:, J-B .. J)^T     (job b: accumulated, k = B)
+// depend only on the previous step, not on each other: a posterior variance at N = 1024 is 4
+// launches instead of 7.  A job: C tile 32 x 32 per workgroup, the four waves split the
+// concatenated k range [P1 Q1 | P2 Q2] (k1, k2 multiples of 64), meet in LDS, wave w owns
+// 16 x 16 block w.  grid (rows / 32, a.ny + b.ny).
+// ---------------------------------------------------------------------------
+struct RowsJob {
+    double *C;
+    long ldc;
+    const double *P1, *Q1, *P2, *Q2;
+    long ldp1, qsj1, qsk1, ldp2, qsj2, qsk2;
+    int k1, k2;
+    int ny;    // tile columns of this job
+    int write; // 1: C = -(products); 0: C -= products
+};
+
+__global__ __launch_bounds__(256) void rows_step_kernel(RowsJob ja, RowsJob jb)
+{
+    __shared__ double red[4][4][4][64];
+    const bool first = (int)blockIdx.y < ja.ny;
+    const RowsJob &j = first ? ja : jb;
+    const int by = first ? blockIdx.y : blockIdx.y - ja.ny;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int kq = (j.k1 + j.k2) >> 2;
+    double4_t acc[2][2];
+#pragma unroll
+    for (int jb2 = 0; jb2 < 2; ++jb2)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+            acc[jb2][ib] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int ks = wave * kq; ks < (wave + 1) * kq; ks += 16) {
+        // a 16-column chunk lies in one of the two operand pairs (k1 is a multiple of 16)
+        const bool p1 = ks < j.k1;
+        const int kk = p1 ? ks : ks - j.k1;
+        const double *pp = (p1 ? j.P1 : j.P2) + (long)blockIdx.x * 32 + l15 +
+                           (long)(kk + l4) * (p1 ? j.ldp1 : j.ldp2);
+        const long qsj = p1 ? j.qsj1 : j.qsj2, qsk = p1 ? j.qsk1 : j.qsk2;
+        const long ldp = p1 ? j.ldp1 : j.ldp2;
+        const double *qq = (p1 ? j.Q1 : j.Q2) + ((long)by * 32 + l15) * qsj + (long)(kk + l4) * qsk;
+        double a[4][2], b[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                a[u][h] = pp[16 * h + (long)(4 * u) * ldp];
+                b[u][h] = qq[(long)(16 * h) * qsj + (long)(4 * u) * qsk];
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int jb2 = 0; jb2 < 2; ++jb2)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib)
+                    acc[jb2][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][jb2], a[u][ib],
+                                                                        acc[jb2][ib], 0, 0, 0);
+    }
+#pragma unroll
+    for (int jb2 = 0; jb2 < 2; ++jb2)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[wave][2 * jb2 + ib][r][lane] = acc[jb2][ib][r];
+    __syncthreads();
+    const int jq = wave >> 1, iq = wave & 1;
+    double *cp = j.C + (long)blockIdx.x * 32 + 16 * iq + l15 +
+                 ((long)by * 32 + 16 * jq + l4) * j.ldc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double s = (red[0][wave][r][lane] + red[1][wave][r][lane]) +
+                         (red[2][wave][r][lane] + red[3][wave][r][lane]);
+        if (j.write)
+            cp[(long)(4 * r) * j.ldc] = -s;
+        else
+            cp[(long)(4 * r) * j.ldc] -= s;
+    }
+}
