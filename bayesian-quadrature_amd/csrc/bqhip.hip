@@ -1049,6 +1049,34 @@ int enqueue_backward_rows(bq_ctx *c, double *Xin, double *Xout, long ldx, int mr
     return BQ_OK;
 }
 
+// (L L^T) X = B for nrhs host columns through the row-form sweeps: the columns go up as they
+// are, a device transposition puts them into the rows of the sweep buffers (mpad x npad,
+// X_dev[r, j] = B[j, r]) and the solution back
+int solve_rows_host(bq_ctx *c, const double *L, long ldl, int n, int npad, WideInv w,
+                    const double *B, int64_t nrhs, double *X)
+{
+    const int mpad = (int)roundup(nrhs, 64);
+    DevBuf Bd, Xd, X2;
+    HIPCHK(c, Bd.alloc(sizeof(double) * (size_t)n * nrhs));
+    HIPCHK(c, Xd.alloc(sizeof(double) * (size_t)mpad * npad));
+    HIPCHK(c, X2.alloc(sizeof(double) * (size_t)mpad * npad));
+    HIPCHK(c, hipMemcpyAsync(Bd.p, B, Bd.bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(Xd.p, 0, Xd.bytes, c->stream));
+    const dim3 g((n + 63) / 64, (unsigned)((nrhs + 63) / 64));
+    hipLaunchKernelGGL(transpose_pad_kernel, g, dim3(256), 0, c->stream, Bd.d(), (long)n, n,
+                       (int)nrhs, Xd.d(), (long)mpad);
+    HIPCHK(c, hipGetLastError());
+    BQCHK(enqueue_forward_rows(c, Xd.d(), X2.d(), mpad, mpad, L, ldl, npad, w));
+    BQCHK(enqueue_backward_rows(c, X2.d(), Xd.d(), mpad, mpad, L, ldl, npad, w));
+    const dim3 gb((unsigned)((nrhs + 63) / 64), (n + 63) / 64);
+    hipLaunchKernelGGL(transpose_pad_kernel, gb, dim3(256), 0, c->stream, Xd.d(), (long)mpad,
+                       (int)nrhs, n, Bd.d(), (long)n);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(X, Bd.p, Bd.bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BQ_OK;
+}
+
 int check_dims(bq_ctx *c, int64_t d, int64_t n)
 {
     if (!c)
@@ -1462,25 +1490,7 @@ extern "C" int bq_cho_solve(bq_ctx *c, const double *L, const double *B, double 
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return BQ_OK;
     }
-    // right-hand sides as rows: X_dev is mpad x npad with X_dev[r, j] = B[j, r]
-    const int mpad = (int)roundup(nrhs, 64);
-    std::vector<double> host((size_t)mpad * npad, 0.0);
-    for (int64_t r = 0; r < nrhs; ++r)
-        for (int64_t j = 0; j < n; ++j)
-            host[(size_t)(r + j * mpad)] = B[j + r * n];
-    HIPCHK(c, Xd.alloc(sizeof(double) * host.size()));
-    HIPCHK(c, X2.alloc(sizeof(double) * host.size()));
-    HIPCHK(c, hipMemcpyAsync(Xd.p, host.data(), sizeof(double) * host.size(),
-                             hipMemcpyHostToDevice, c->stream));
-    BQCHK(enqueue_forward_rows(c, Xd.d(), X2.d(), mpad, mpad, A.d(), ldl, npad, w));
-    BQCHK(enqueue_backward_rows(c, X2.d(), Xd.d(), mpad, mpad, A.d(), ldl, npad, w));
-    HIPCHK(c, hipMemcpyAsync(host.data(), Xd.p, sizeof(double) * host.size(),
-                             hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int64_t r = 0; r < nrhs; ++r)
-        for (int64_t j = 0; j < n; ++j)
-            X[j + r * n] = host[(size_t)(r + j * mpad)];
-    return BQ_OK;
+    return solve_rows_host(c, A.d(), ldl, (int)n, npad, w, B, nrhs, X);
 }
 
 extern "C" int bq_logdet(bq_ctx *c, const double *L, int64_t n, double *out)
