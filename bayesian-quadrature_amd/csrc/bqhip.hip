@@ -1441,16 +1441,19 @@ extern "C" int bq_cho_factor(bq_ctx *c, const double *C, double *L, int64_t n, i
     }
     // copy back only the lower triangle; the strict upper part of L keeps what
     // the caller had there (C's values after the reference's C -> L copy)
+    if (C != L) {
+        // straight into L, then the caller's strict upper triangle over what the device left there
+        HIPCHK(c, hipMemcpy2D(L, sizeof(double) * n, A.p, sizeof(double) * lda, sizeof(double) * n,
+                              n, hipMemcpyDeviceToHost));
+        for (int64_t j = 1; j < n; ++j)
+            std::memcpy(L + j * n, C + j * n, sizeof(double) * (size_t)j);
+        return BQ_OK;
+    }
     std::vector<double> tmp((size_t)n * n);
     HIPCHK(c, hipMemcpy2D(tmp.data(), sizeof(double) * n, A.p, sizeof(double) * lda,
                           sizeof(double) * n, n, hipMemcpyDeviceToHost));
-    for (int64_t j = 0; j < n; ++j) {
-        if (C != L)
-            for (int64_t i = 0; i < j; ++i)
-                L[i + j * n] = C[i + j * n];
-        for (int64_t i = j; i < n; ++i)
-            L[i + j * n] = tmp[(size_t)(i + j * n)];
-    }
+    for (int64_t j = 0; j < n; ++j)
+        std::memcpy(L + j + j * n, tmp.data() + j + j * n, sizeof(double) * (size_t)(n - j));
     return BQ_OK;
 }
 
