@@ -414,7 +414,7 @@ int launch_potf2(bq_ctx *c, double *A, long lda, long astride, int j0, double *d
     return BQ_OK;
 }
 
-// the MFMA panel solve (trsm_blk_kernel): needs the block inverses potf2_64x4_body leaves
+// the MFMA panel solve (trsm_blk_kernel): needs the block inverses potf2f_body leaves
 // behind the 64 reciprocal pivots
 int launch_trsm_blk(bq_ctx *c, double *X, long ldx, long xstride, int m, const double *L11,
                     long ldl, long lstride, const double *dinv, long dstride, int batch)

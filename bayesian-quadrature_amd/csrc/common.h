@@ -12,7 +12,7 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 
 // Per-problem scratch of the 64-column panel step: 64 reciprocal pivots of the current
 // diagonal block, then the inverses of its four 16 x 16 diagonal sub-blocks (column-major,
-// 256 doubles each) -- written by potf2_64x4_body, read by trsm_blk_kernel.
+// 256 doubles each) -- written by potf2f_body, read by trsm_blk_kernel.
 #define BQ_DINV_HALF (64 + 4 * 256)
 // two halves: the one-launch slab step (slab.h) writes the next block's half while this
 // block's is still being read

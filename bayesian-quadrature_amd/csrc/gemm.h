@@ -287,7 +287,7 @@ __device__ __forceinline__ void gemm444_tile(double *__restrict__ C, long ldc,
 // Fused diagonal factor: when fuse_j0 >= 0 the launch also factors the leading 64x64
 // block of C (the next diagonal block of the Cholesky) right after updating it.
 // Workgroup 0 owns every workgroup tile that intersects that block, updates them,
-// and runs potf2_64x4_body on the result; the other workgroups of the block exit.
+// and runs potf2f_body on the result; the other workgroups of the block exit.
 // This removes one dependent launch (and the block's trip through L2) per 64 columns.
 template <int TM, int TN, int MF> // MF = 0: v_mfma_f64_16x16x4_f64, 1: v_mfma_f64_4x4x4_4b_f64
 __global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C, long ldc,

@@ -7,7 +7,7 @@
 #pragma once
 #include "common.h"
 #include "gram.h"    // gram_sym_kernel, gram_cross_kernel, assemble_kernel
-#include "potf2.h"   // potf2_64_kernel, potf2_64x4_kernel (+ body, fusable into gemm)
+#include "potf2.h"   // potf2_kernel, potf2f_body (the 4-wave diagonal factor, fusable into the step kernels)
 #include "trsm.h"    // trsm_blk_kernel, diag_winv_kernel
 #include "trsv.h"    // trsv_diag/fwd/bwd_kernel: single right-hand-side sweeps (GEMV form)
 #include "gemm.h"    // gemm_sub_kernel, gemm_k64_kernel, gemm_lds_kernel

@@ -161,9 +161,9 @@ struct Potf2FSteps<16> {
     static __device__ __forceinline__ void run(Potf2F &, double *, int, int, long long *) {}
 };
 
-// lds: BQ_POTF2F_LDS_DOUBLES doubles.  src / lsrc as for potf2_64x4_body; when src lies in
-// the slots' LDS (the slab step's Ts), pass src_in_slots so that nobody publishes before
-// every wave has its columns.
+// lds: BQ_POTF2F_LDS_DOUBLES doubles.  src (leading dimension lsrc): where the block is read
+// from when it is not in place; when src lies in the slots' LDS (the slab step's Ts), pass
+// src_in_slots so that nobody publishes before every wave has its columns.
 __device__ __forceinline__ void potf2f_body(double *__restrict__ Ab, long lda, int j0,
                                             double *__restrict__ dinv_b,
                                             int *__restrict__ info_b, double *lds,

@@ -5,7 +5,7 @@
 
 // ---------------------------------------------------------------------------
 // Panel solve on the matrix cores: X (m x 64) <- X L11^-T in four 16-column block steps,
-//   X_c = (A_c - sum_{b<c} X_b L_cb^T) W_cc^T,   W_cc = L_cc^-1 (from potf2_64x4_body),
+//   X_c = (A_c - sum_{b<c} X_b L_cb^T) W_cc^T,   W_cc = L_cc^-1 (from potf2f_body),
 // instead of 64 dependent column steps.  A wave owns 16 rows and works on transposes, so
 // that every intermediate stays in MFMA operand form: with D = A B on
 // v_mfma_f64_16x16x4_f64, register r of the D tile IS the B fragment of k-step r, so
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void trsm_blk_kernel(double *__restrict__ X, l
 // the inverses of the four 16 x 16 diagonal sub-blocks -- of every 64 x 64 diagonal block,
 // BQ_DINV_HALF doubles per block, so that the row-form sweeps over the factor (predictions,
 // solves) can use the MFMA panel solve too.  One workgroup per diagonal block, wave w inverts
-// sub-block w exactly as potf2_64x4_body does.
+// sub-block w exactly as potf2f_body does.
 __global__ __launch_bounds__(256) void diag_winv_kernel(const double *__restrict__ Lm, long ldl,
                                                         double *__restrict__ dw)
 {
