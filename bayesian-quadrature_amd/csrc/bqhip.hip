@@ -338,8 +338,9 @@ static bool gemm_uses_lds(const bq_ctx *c, int m, int n, int k, int lower, int b
 int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const double *P, long ldp,
                 long pstride, const double *Q, long qsj, long qsk, long qstride, int m, int n,
                 int k, int lower, int batch, int fuse_j0 = -1, double *dinv = nullptr,
-                long dstride = 0, int *info = nullptr)
+                long dstride = 0, int *info = nullptr, int ccut = 0)
 {
+    // ccut > 0: columns >= ccut of C need no update (honoured by the LDS-staged kernel only)
     if (m <= 0 || n <= 0 || k <= 0)
         return BQ_OK;
     if ((m & 15) || (n & 15) || (k & 7))
@@ -381,7 +382,8 @@ int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const dou
     if (f444 && fuse_j0 < 0 && n >= 128 && gemm_uses_lds(c, m, n, k, lower, batch)) {
         dim3 g = grid_for(128);
         hipLaunchKernelGGL(gemm_lds_kernel, g, dim3(256), BQ_LDS_BYTES, c->cur, C, ldc, cstride, P,
-                           ldp, pstride, Q, qsk, qstride, m, n, k, mode);
+                           ldp, pstride, Q, qsk, qstride, m, n, k, mode,
+                           ccut > 0 ? ccut : 0x7fffffff);
     } else if (tiles(128) >= cu && n >= 128) {
         BQ_GEMM_SUB(4, 4, 128);
     } else if (tiles(64) >= cu / 2) {
@@ -609,9 +611,11 @@ bool sweep_is_slab(const bq_ctx *c, int ntot, int ncols, int batch, size_t panel
            ncols >= 64 && ntot > 64;
 }
 
+// skip_border: the caller reads its results off the border ROWS (plan_readout_kernel), so the
+// trailing updates leave the border x border block alone
 int enqueue_potrf_group(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
                         int ncols, double *dinv, int *info, double *panel_ws, size_t panel_ws_len,
-                        int nb_forced, bool first_done = false)
+                        int nb_forced, bool first_done = false, bool skip_border = false)
 {
     const int NB = nb_forced > 0 ? nb_forced : auto_nb(c, ntot, batch);
     double *ws = (panel_ws && panel_ws_len >= panel_ws_doubles(ntot, batch)) ? panel_ws : nullptr;
@@ -678,7 +682,8 @@ int enqueue_potrf_group(bq_ctx *c, double *A, long lda, long astride, int batch,
                     const double *P1 = A + r1 + (long)K0 * lda;
                     st = launch_gemm(c, BQ_K_SYRK, A + r1 + (long)r1 * lda, lda, astride, P1, lda,
                                      astride, P1, 1, lda, astride, ntot - r1, ntot - r1, KB, 1,
-                                     batch);
+                                     batch, -1, nullptr, 0, nullptr,
+                                     skip_border ? ncols - r1 : 0);
                     HIPCHK(c, hipEventRecord(c->ev_next, c->stream));
                     have_b = true;
                 }
@@ -716,7 +721,7 @@ int enqueue_potrf_group(bq_ctx *c, double *A, long lda, long astride, int batch,
                                : -1;
             BQCHK(launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda, astride,
                               P, 1, lda, astride, ntot - r0, ntot - r0, KB, 1, batch, fj, dinv,
-                              BQ_DINV_STRIDE, info));
+                              BQ_DINV_STRIDE, info, skip_border ? ncols - r0 : 0));
             diag_done = fj >= 0;
         }
         if (to_slab)
@@ -735,7 +740,8 @@ int enqueue_potrf_group(bq_ctx *c, double *A, long lda, long astride, int batch,
 // use the second stream for the look-ahead instead, small ones the one-launch steps.)
 int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
                           int ncols, double *dinv, int *info, double *panel_ws = nullptr,
-                          size_t panel_ws_len = 0, bool first_done = false)
+                          size_t panel_ws_len = 0, bool first_done = false,
+                          bool skip_border = false)
 {
     if ((ntot & 63) || (ncols & 63) || ncols > ntot)
         return fail(c, BQ_ERR_BAD_ARG, "potrf: sizes must be multiples of 64");
@@ -749,17 +755,19 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
         HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
         c->cur = c->aux;
         int st = enqueue_potrf_group(c, A + (long)b0 * astride, lda, astride, b1, ntot, ncols,
-                                     dinv + (long)b0 * BQ_DINV_STRIDE, info + b0, nullptr, 0, NB);
+                                     dinv + (long)b0 * BQ_DINV_STRIDE, info + b0, nullptr, 0, NB,
+                                     false, skip_border);
         c->cur = c->stream;
         if (st != BQ_OK)
             return st;
         HIPCHK(c, hipEventRecord(c->ev_panel, c->aux));
-        BQCHK(enqueue_potrf_group(c, A, lda, astride, b0, ntot, ncols, dinv, info, nullptr, 0, NB));
+        BQCHK(enqueue_potrf_group(c, A, lda, astride, b0, ntot, ncols, dinv, info, nullptr, 0, NB,
+                                  false, skip_border));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_panel, 0));
         return BQ_OK;
     }
     return enqueue_potrf_group(c, A, lda, astride, batch, ntot, ncols, dinv, info, panel_ws,
-                               panel_ws_len, 0, first_done);
+                               panel_ws_len, 0, first_done, skip_border);
 }
 
 // ---------------------------------------------------------------------------
@@ -1820,10 +1828,21 @@ int plan_enqueue(bq_ctx *c, bq_plan *p)
     BQCHK(launch_assemble(c, p->d, p->pts.d(), (long)p->d * p->L.ntot, p->y.d(), p->L.npad,
                           static_cast<GaussParams *>(p->gp.p), 1, p->A.d(), p->lda, p->astride,
                           p->L, p->nprob, fs));
+    // A blocked sweep (outer block >= 128) reads its results off the border rows and skips the
+    // border x border block in its trailing updates; the one-launch steps of small systems
+    // update everything and read the Schur complement.
+    const bool by_rows = !fuse && p->L.yrow >= 0 && auto_nb(c, p->L.ntot, p->nprob) >= 128;
     BQCHK(enqueue_potrf_partial(c, p->A.d(), p->lda, p->astride, p->nprob, p->L.ntot, p->L.npad,
                                 p->dinv.d(), p->info.i(), p->panel.d(),
-                                p->panel.bytes / sizeof(double), fuse));
-    {
+                                p->panel.bytes / sizeof(double), fuse, by_rows));
+    if (by_rows) {
+        Bracket br(c, BQ_K_REDUCE, 8.0 * (p->M + 1.0) * p->L.npad * p->nprob);
+        hipLaunchKernelGGL(plan_readout_kernel, dim3((p->M + 16) / 16, 1, p->nprob), dim3(1024), 0,
+                           c->stream, p->A.d(), p->lda, p->astride, p->L,
+                           static_cast<const GaussParams *>(p->gp.p), p->scal.d(), p->mean.d(),
+                           p->var.d(), (long)std::max(p->M, 1));
+        HIPCHK(c, hipGetLastError());
+    } else {
         Bracket br(c, BQ_K_REDUCE, 8.0 * (p->n + 2.0 * p->M) * p->nprob);
         hipLaunchKernelGGL(finalize_kernel, dim3(1, 1, p->nprob), dim3(256), 0, c->stream,
                            p->A.d(), p->lda, p->astride, p->L, p->scal.d(), p->mean.d(),

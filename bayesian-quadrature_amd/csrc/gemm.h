@@ -504,8 +504,10 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C
                                                           long ldp, long pstride,
                                                           const double *__restrict__ Q, long ldq,
                                                           long qstride, int m, int n, int k,
-                                                          int lower)
+                                                          int lower, int ncut)
 {
+    // ncut: columns >= ncut of C are left alone (the border x border block of a bordered
+    // system, which nothing reads: see plan_readout_kernel)
     // [buffer][P rows 0..15 | Q rows 16..31][128 doubles + pad]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.z;
@@ -518,9 +520,11 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C
     P += (long)b * pstride;
     Q += (long)b * qstride;
     const int R0 = bx * 128, C0 = by * 128;
+    if (C0 >= ncut)
+        return; // (the whole workgroup, before any barrier)
     const int wr = (wave & 1) * 64, wc = (wave >> 1) * 64; // this wave's 64 x 64 sub-tile
     const int row0 = R0 + wr, col0 = C0 + wc;
-    const bool active = row0 < m && col0 < n && !(lower && col0 >= row0 + 64);
+    const bool active = row0 < m && col0 < n && col0 < ncut && !(lower && col0 >= row0 + 64);
 
     // staging: a chunk is 32 k rows (16 of P, 16 of Q); wave w moves rows 8w .. 8w+7, one
     // LDS-DMA per row, lane i carrying rows 2i, 2i+1 of the operand's 128-row block

@@ -205,3 +205,89 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const double *__rest
         if (c0 + lane < cols && r0 + rr < rows)
             dst[c0 + lane + (long)(r0 + rr) * ldd] = tile[lane][rr];
 }
+
+// Read-out of a bordered elimination WITHOUT its border x border block (one launch per batch).
+// After the npad columns are eliminated the border rows hold V = K(xo, x) L^-T and, as row
+// yrow = npad + M, z = L^-1 y:
+//   mean_i = v_i . z,   var_i = k(xo_i, xo_i) - |v_i|^2,   qf = |z|^2,
+//   logdet = 2 sum log L_ii,   logml = -qf/2 - logdet/2 - n/2 log 2 pi
+// -- the same numbers the Schur complement's diagonal and y row carry, so the trailing updates
+// of a batch can skip that block (gemm_lds_kernel's ncut: 6-13 % of a C5 update's tiles).
+// Block = 16 rows x 64 column slices like rowdot_kernel; rows npad .. npad + M (the y row is
+// the last); the block that holds the y row also reduces the diagonal.  grid (ceil((M+1)/16),
+// 1, batch).  scal[b*4 + {0,1,2}] = logml, logdet, qf.
+__global__ __launch_bounds__(1024) void plan_readout_kernel(const double *__restrict__ A, long lda,
+                                                            long astride, Layout L,
+                                                            const GaussParams *__restrict__ gp,
+                                                            double *__restrict__ scal,
+                                                            double *__restrict__ mean,
+                                                            double *__restrict__ var, long mstride)
+{
+    const int b = blockIdx.z;
+    A += (long)b * astride;
+    const int t = threadIdx.x, r = t & 15, sl = t >> 4;
+    const int i = blockIdx.x * 16 + r; // border row index, M = the y row
+    const double *zrow = A + L.yrow;
+    double sm = 0.0, sv = 0.0;
+    if (i <= L.M) {
+        const double *p = A + L.npad + i;
+        int j = sl;
+        for (; j + 64 * 7 < L.npad; j += 64 * 8) {
+            double v[8], z[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[u] = p[(long)(j + 64 * u) * lda];
+                z[u] = zrow[(long)(j + 64 * u) * lda];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                sm = fma(v[u], z[u], sm);
+                sv = fma(v[u], v[u], sv);
+            }
+        }
+        for (; j < L.npad; j += 64) {
+            const double v = p[(long)j * lda];
+            sm = fma(v, zrow[(long)j * lda], sm);
+            sv = fma(v, v, sv);
+        }
+    }
+    __shared__ double pm[64][17], pv[64][17];
+    __shared__ double part[16];
+    pm[sl][r] = sm;
+    pv[sl][r] = sv;
+    __syncthreads();
+    double a = 0.0, q = 0.0;
+    if (t < 16 && i <= L.M) {
+        for (int w = 0; w < 64; ++w) {
+            a += pm[w][r];
+            q += pv[w][r];
+        }
+        if (i < L.M) {
+            if (mean)
+                mean[(long)b * mstride + i] = a;
+            if (var)
+                var[(long)b * mstride + i] = gp[b].c - q;
+        }
+    }
+    // the block of the y row: log-det and the scalars
+    if ((int)blockIdx.x * 16 <= L.M && L.M < (int)blockIdx.x * 16 + 16) {
+        double s = 0.0;
+        for (int k = t; k < L.n; k += 1024)
+            s += log(A[k + (long)k * lda]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            s += __shfl_down(s, off, 64);
+        if ((t & 63) == 0)
+            part[t >> 6] = s;
+        __syncthreads();
+        if (t == (L.M & 15)) { // the thread that holds the y row's sums (q = |z|^2)
+            double ld = 0.0;
+            for (int w = 0; w < 16; ++w)
+                ld += part[w];
+            ld *= 2.0;
+            scal[b * 4 + 0] = -0.5 * q - 0.5 * ld - 0.5 * (double)L.n * 1.8378770664093453;
+            scal[b * 4 + 1] = ld;
+            scal[b * 4 + 2] = q;
+        }
+    }
+}
