@@ -894,6 +894,26 @@ def test_bq_expected_moments_gpu_vs_double(engine, oracle):
     assert np.allclose(d[5], g[5], rtol=1e-6, atol=1e-13)
 
 
+def test_one_shot_plan_vs_resident_fit_large(engine):
+    """N = 6144, M = 200 through the one-shot bordered plan -- the two-stream look-ahead sweep
+    whose bulk updates skip the border x border block, results read off the border rows -- and
+    through a resident fit + bq_gp_predict (full updates of its own system, row sweeps with
+    the explicit block inverses): two different routes to the same posterior and log-ML."""
+    n, M = 6144, 200
+    c = wl.c4(n)
+    rs = np.random.RandomState(11)
+    y = wl.norm_logpdf(c["x"]) + 0.01 * rs.randn(n)
+    xo = np.sort(rs.uniform(-5.2, 5.2, M))
+    m1, v1, lm1 = engine.fit_predict(c["x"], y, c["h"], c["w"], c["s"], xo)
+    fit = engine.gp_fit(c["x"], y, c["h"], c["w"], c["s"])
+    m2, v2, _ = fit.predict(xo)
+    k0 = c["h"] ** 2 / (np.sqrt(2 * np.pi) * float(np.atleast_1d(c["w"])[0]))
+    assert relmax(m1, m2) < 1e-10
+    assert np.abs(v1 - v2).max() / k0 < 1e-10
+    assert abs(lm1 - fit.logml) <= 1e-12 * abs(fit.logml)
+    fit.close()
+
+
 def test_large_fit_properties(engine):
     """N = 8192 (wide outer block, look-ahead) through the GP object path: the factor,
     z, alpha and the log-ML must satisfy their defining identities."""
