@@ -381,6 +381,23 @@ def test_batch_fit_predict(engine, oracle):
         assert abs(logml[i] - lmo) <= RTOL * abs(lmo)
 
 
+def test_batch_fit_predict_mid_block(engine, oracle):
+    """24 x (N = 600, M = 40): the batch regime with outer block 128 (recursive panels, results
+    read off the border rows, most updates too small for the kernel that skips the border
+    block) -- between the one-launch steps of small systems and the C5-sized batches."""
+    probs = list(range(24))
+    c = wl.c5(probs, n=600, m=40)
+    mean, var, logml, status = engine.batch_fit_predict(c["x"], c["y"], c["h"], c["w"] * 3,
+                                                        c["s"], c["xo"])
+    assert (status == 0).all()
+    for i in (0, 11, 23):
+        Lo, ao, lmo = oracle.gp_fit(c["x"][i], c["y"][i], c["h"], c["w"] * 3, c["s"])
+        mo, vo = oracle.gp_predict(c["x"][i], c["h"], c["w"] * 3, Lo, ao, c["xo"][i])
+        assert relmax(mean[i], mo) < RTOL
+        assert relmax(var[i], vo, scale=oracle.kernel_scale(1, c["h"], c["w"] * 3)) < RTOL
+        assert abs(logml[i] - lmo) <= RTOL * abs(lmo)
+
+
 def test_batched_workspace_is_reused_and_trimmed(engine):
     """The batched entry points keep their workspace in the context: the same call again
     (same shapes, other hyper-parameters), a call of another shape, and a call after
