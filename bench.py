@@ -452,6 +452,7 @@ def extras(eng, nb_override):
         eng.free(xd)
         eng.free(Kd)
     out.update(solve_predict_rooflines(eng))
+    out.update(hyper_loop_body(eng))
     out.update(batched_configs(eng))
     # the same C2 problem through the host-buffer entry point (allocation, PCIe both
     # ways, synchronisation inside every call): never the headline `value`
@@ -550,6 +551,38 @@ def solve_predict_rooflines(eng):
             "note": "fused cross-Gram x alpha (predict_mean_kernel): M N exp evaluations, "
                     "8 (N + M + N) algorithmic bytes -- a single short launch"}
     fit.close()
+    return out
+
+
+def hyper_loop_body(eng):
+    """the body of the hyper-parameter loop (bq.py:536-550, 933-965) on
+    resident fits -- GP1: new parameters and the posterior of the candidates (one sweep,
+    bq_gp_refit_predict); GP2: refit on samples + candidates; the two log-MLs.  Wall time per
+    iteration, host buffers and read-backs included (a latency chain: report only)."""
+    from bayesian_quadrature_amd import workloads as wl
+    out = {}
+    for n, nc in ((19, 10), (1024, 10)):
+        dx = 10.0 / (n - 1)
+        x = np.linspace(-5.0, 5.0, n)
+        xc = np.linspace(-5.5, 5.5, nc) + 0.37 * dx
+        g1 = eng.gp_fit(x, wl.norm_logpdf(x), 15.0, 1.3 * dx, 1e-3)
+        xsc = np.concatenate([x, xc])
+        g2 = eng.gp_fit(xsc, np.exp(wl.norm_logpdf(xsc)), 0.2, 1.3 * dx, 1e-3)
+        ts = []
+        for rep in range(5):
+            t0 = time.perf_counter()
+            for it in range(20):
+                wi = (1.3 + 0.001 * it) * dx
+                m, v = g1.refit_predict(15.0, wi, 1e-3, xc)
+                g2.refit(0.2, wi, 1e-3)
+                _ = g1.logml + g2.logml
+            ts.append((time.perf_counter() - t0) / 20 * 1e3)
+        out["hyper_loop_body_n%d_nc%d" % (n, nc)] = {
+            "ms_per_iteration": sorted(ts)[2], "bound": "latency",
+            "note": "GP1 refit + candidates' mean/variance in one sweep, GP2 refit, both "
+                    "log-MLs; wall time with host buffers"}
+        g1.close()
+        g2.close()
     return out
 
 
