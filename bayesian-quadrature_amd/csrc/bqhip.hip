@@ -80,6 +80,8 @@ struct bq_ctx {
     int split_batch = 1; // halves of a mid-sized batch on the two streams (BQ_SPLIT=0: lock-step)
     int la_min = 4096;   // look-ahead only while the bulk update has at least this many rows (BQ_LA_MIN)
     DevBuf panel_ws;     // scratch panel columns of the eager linalg entry points
+    DevBuf scratch;      // per-call temporaries of the acquisition / moment entry points, kept
+                         // between calls (hipFree synchronises the device); bq_ctx_trim frees it
     int gemm_lds = 1;    // LDS-staged 128x128 trailing update (BQ_GEMM_LDS)
     int use_graph = 1;   // replay plans from a captured hipGraph (BQ_GRAPH=0 disables)
     bool own_stream = false;
@@ -1085,6 +1087,29 @@ int solve_rows_host(bq_ctx *c, const double *L, long ldl, int n, int npad, WideI
     return BQ_OK;
 }
 
+// Carves the per-call temporaries of one entry point out of the context's scratch buffer:
+// sizes first (take), then one commit that grows the buffer if it must, then the pointers.
+struct Scratch {
+    bq_ctx *c;
+    size_t total = 0;
+    explicit Scratch(bq_ctx *ctx) : c(ctx) {}
+    size_t take(size_t doubles)
+    {
+        const size_t off = total;
+        total += (doubles + 31) & ~(size_t)31; // 256-byte granules
+        return off;
+    }
+    int commit()
+    {
+        if (c->scratch.bytes < total * sizeof(double)) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, c->scratch.alloc(total * sizeof(double)));
+        }
+        return BQ_OK;
+    }
+    double *at(size_t off) const { return c->scratch.d() + off; }
+};
+
 int check_dims(bq_ctx *c, int64_t d, int64_t n)
 {
     if (!c)
@@ -1761,6 +1786,8 @@ extern "C" int bq_ctx_trim(bq_ctx *c)
         bq_plan_destroy(c, c->plan_cache);
         c->plan_cache = nullptr;
     }
+    (void)hipStreamSynchronize(c->stream);
+    c->scratch.release();
     return BQ_OK;
 }
 
