@@ -2179,7 +2179,8 @@ struct bq_fit {
     bool have_wide = false;
     bool have_dw = false; // dw is built on its first use: a loop that reads log-ML never pays
     DevBuf wV, wV2, wx, wout, wz; // prediction workspaces, grown on demand and kept
-    DevBuf misc;  // info (int) + scal[4]
+    DevBuf misc;  // info (int) + scal[4], then 2 x 64 doubles: the posterior of the border points
+                  // of bq_gp_refit_predict (one read-back for all of it)
     DevBuf alpha; // npad, valid if have_alpha
     bool have_alpha = false;
     // the single-vector sweeps (trsv.h): x | y, 2 npad doubles, and their captured launch
@@ -2208,7 +2209,8 @@ namespace {
 
 // pm / pv: device buffers for the posterior mean / variance of the layout's M border points
 // (bq_gp_refit_predict), or null
-int fit_factor(bq_ctx *c, bq_fit *f, double *pm = nullptr, double *pv = nullptr)
+int fit_factor(bq_ctx *c, bq_fit *f, double *pm = nullptr, double *pv = nullptr,
+               double *hpost = nullptr) // hpost: host copy of misc[8 .. 8 + 128) on return
 {
     const int ntot = f->L.ntot;
     int *info = f->misc.i();
@@ -2240,10 +2242,13 @@ int fit_factor(bq_ctx *c, bq_fit *f, double *pm = nullptr, double *pv = nullptr)
                            f->ldl, 0L, f->L, scal, pm, pv, 64L);
         HIPCHK(c, hipGetLastError());
     }
-    // one read-back: misc = [info (int, 8 bytes) | pad | scal[4]]
-    double hm[6];
-    HIPCHK(c, hipMemcpyAsync(hm, f->misc.p, sizeof hm, hipMemcpyDeviceToHost, c->stream));
+    // one read-back: misc = [info (int, 8 bytes) | pad | scal[4] | pad | mean[64] | var[64]]
+    double hm[8 + 128];
+    HIPCHK(c, hipMemcpyAsync(hm, f->misc.p, sizeof(double) * (hpost ? 8 + 128 : 6),
+                             hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (hpost)
+        std::memcpy(hpost, hm + 8, sizeof(double) * 128);
     int hinfo = 0;
     std::memcpy(&hinfo, hm, sizeof hinfo);
     const double *hs = hm + 2;
@@ -2401,7 +2406,7 @@ extern "C" int bq_gp_fit(bq_ctx *c, const double *x, const double *y, int64_t d,
     A(f->panel, panel_ws_useful(c, f->L.ntot, 1) ? sizeof(double) * panel_ws_doubles(f->L.ntot, 1)
                                                  : 0);
     A(f->dw, sizeof(double) * BQ_DINV_HALF * (size_t)(f->npad / 64));
-    A(f->misc, sizeof(double) * 8);
+    A(f->misc, sizeof(double) * (8 + 128));
     A(f->alpha, sizeof(double) * (size_t)f->npad);
     if (e != hipSuccess) {
         delete f;
@@ -2474,14 +2479,10 @@ extern "C" int bq_gp_refit_predict(bq_ctx *c, bq_fit *f, double h, const double 
         f->w[k] = w[k];
     f->g = make_params(f->d, h, w, s);
     f->L = make_layout(f->n, (int)M, true); // same ntot: the points share the y row's block
-    if (f->wout.bytes < sizeof(double) * 128)
-        HIPCHK(c, f->wout.alloc(sizeof(double) * 128));
     HIPCHK(c, hipMemcpyAsync(f->pts.d() + (size_t)f->d * f->npad, xo, sizeof(double) * f->d * M,
                              hipMemcpyHostToDevice, c->stream));
-    BQCHK(fit_factor(c, f, f->wout.d(), f->wout.d() + 64));
     double hv[128];
-    HIPCHK(c, hipMemcpyAsync(hv, f->wout.p, sizeof hv, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    BQCHK(fit_factor(c, f, f->misc.d() + 8, f->misc.d() + 8 + 64, hv));
     for (int64_t i = 0; i < M; ++i) {
         if (mean)
             mean[i] = hv[i];
