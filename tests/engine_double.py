@@ -24,6 +24,13 @@ class FitDouble(object):
         self.h, self.w, self.s = float(h), np.atleast_1d(np.asarray(w, dtype=np.float64)), float(s)
         self._L, self._alpha, self.logml = self.o.gp_fit(self.x, self.y, self.h, self.w, self.s)
 
+    def refit_predict(self, h, w, s, xo):
+        """The device engine's one-sweep route (bq_gp_refit_predict), here as its two halves."""
+        self.refit(h, w, s)
+        self.refit_predicts = getattr(self, "refit_predicts", 0) + 1
+        m, v, _ = self.predict(xo)
+        return m, v
+
     def close(self):
         pass
 

@@ -239,3 +239,39 @@ def test_slice_sample_zero_probability_start():
     from bayesian_quadrature_amd import util
     with pytest.raises(RuntimeError):
         util.slice_sample(lambda x: -np.inf, 5, np.array([1.0]), xval=np.array([0.0]))
+
+
+def test_gp_mean_var_takes_the_one_sweep_route_when_a_refit_is_pending(pkg):
+    """gp.GP.mean_var: with a parameter change pending and at most 63 points the refit and the
+    posterior are ONE engine call (Fit.refit_predict, the hyper-parameter loop's body,
+    bq.py:933-947); otherwise refit-on-demand + predict.  Same numbers either way, and a failed
+    refit leaves the object ready for the next parameter set."""
+    x = np.linspace(-3, 3, 12)
+    y = -0.5 * x ** 2
+    g = pkg.GP(pkg.GaussianKernel(1.0, 0.8), x, y, s=1e-3)
+    xo = np.linspace(-2.5, 2.5, 7)
+    g.mean_var(xo)                                # first use: plain fit, then predict
+    fit = g._device_fit()
+    calls = []
+    inner = fit.refit_predict
+    fit.refit_predict = lambda *a: (calls.append(1), inner(*a))[1]
+    g.set_param("w", 0.9)
+    m1, v1 = g.mean_var(xo)                       # pending refit: the one-sweep route
+    assert len(calls) == 1
+    ref = pkg.GP(pkg.GaussianKernel(1.0, 0.9), x, y, s=1e-3)
+    assert np.allclose(m1, ref.mean(xo), rtol=1e-10, atol=1e-13)
+    assert np.allclose(v1, ref.var(xo), rtol=1e-8, atol=1e-13)
+    assert abs(g.log_lh - ref.log_lh) <= 1e-11 * abs(ref.log_lh)
+    m2, _ = g.mean_var(xo)                        # nothing pending: no refit
+    assert len(calls) == 1 and np.allclose(m1, m2, rtol=1e-9, atol=1e-12)
+    g.set_param("w", 1.0)
+    g.mean_var(np.linspace(-2, 2, 64))            # too many points for the border block
+    assert len(calls) == 1
+    g.set_param("w", 400.0)                       # numerically singular without the noise term
+    g.set_param("s", 0.0)
+    with pytest.raises(np.linalg.LinAlgError):
+        g.mean_var(xo)
+    g.set_param("w", 0.9)
+    g.set_param("s", 1e-3)
+    m3, _ = g.mean_var(xo)
+    assert np.allclose(m3, m1, rtol=1e-10, atol=1e-13)
