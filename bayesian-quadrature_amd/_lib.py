@@ -57,6 +57,7 @@ SIGNATURES = {
     "bq_potrf_dev": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "bq_gp_fit": (C.c_int, [_vp, _dp, _dp, _i64, _i64, _dbl, _dp, _dbl, C.POINTER(_vp)]),
     "bq_gp_refit": (C.c_int, [_vp, _vp, _dbl, _dp, _dbl]),
+    "bq_gp_set_y": (C.c_int, [_vp, _vp, _dp]),
     "bq_gp_refit_predict": (C.c_int, [_vp, _vp, _dbl, _dp, _dbl, _dp, _i64, _dp, _dp]),
     "bq_fit_destroy": (None, [_vp, _vp]),
     "bq_gp_logml": (C.c_int, [_vp, _vp, _dp]),

@@ -432,6 +432,14 @@ class Fit(object):
         e = self._eng
         e._check(e._lib.bq_gp_refit(e._ctx, self._handle(), float(h), L.dptr(w), float(s)))
 
+    def set_y(self, y):
+        """New targets for the same points; the fit must be refitted before its next use."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if y.shape != (self.n,):
+            raise ValueError("y has invalid shape")
+        e = self._eng
+        e._check(e._lib.bq_gp_set_y(e._ctx, self._handle(), L.dptr(y)))
+
     def refit_predict(self, h, w, s, xo):
         """New hyper-parameters and the posterior mean / marginal variance at xo in one sweep
         (bq_gp_refit_predict: the hyper-parameter loop's body)."""

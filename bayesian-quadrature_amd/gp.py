@@ -146,7 +146,19 @@ class GP(object):
             raise ValueError("y must be one-dimensional")
         if self._y is not None and val.shape == self._y.shape and (val == self._y).all():
             return
-        self._invalidate()
+        fit = getattr(self, "_fit", None)
+        if (fit is not None and self._y is not None and val.shape == self._y.shape
+                and hasattr(fit, "set_y")):
+            # same points, new targets (the hyper-parameter loop gives GP2 new targets on every
+            # evaluation, bq.py:948-954): the device fit stays and is re-factored on next use
+            try:
+                fit.set_y(val)
+            except Exception:
+                self._invalidate()
+            else:
+                self._invalidate(data_changed=False)
+        else:
+            self._invalidate()
         self._y = val
 
     @property

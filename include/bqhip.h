@@ -140,6 +140,10 @@ int bq_gp_fit(bq_ctx *ctx, const double *x, const double *y, int64_t d, int64_t 
               const double *w, double s, bq_fit **out);
 /* same data, new hyper-parameters (the hyper-parameter loop, bq.py:933-965) */
 int bq_gp_refit(bq_ctx *ctx, bq_fit *fit, double h, const double *w, double s);
+/* same points, new targets y (n entries, host): the hyper-parameter loop gives GP2 new targets
+ * on every evaluation, `self.gp_l.y = self.l_sc`, bq.py:948-954.  The fit holds no valid factor
+ * until its next bq_gp_refit / bq_gp_refit_predict. */
+int bq_gp_set_y(bq_ctx *ctx, bq_fit *fit, const double *y);
 /* new hyper-parameters and the posterior mean / marginal variance at M points xo (d x M, host)
  * in ONE sweep: the points ride as border rows of the fit's own bordered system.  This is the
  * body of the reference's hyper-parameter loop, bq.py:933-947 (`_set_gp_log_l_params`: set the

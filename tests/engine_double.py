@@ -24,6 +24,10 @@ class FitDouble(object):
         self.h, self.w, self.s = float(h), np.atleast_1d(np.asarray(w, dtype=np.float64)), float(s)
         self._L, self._alpha, self.logml = self.o.gp_fit(self.x, self.y, self.h, self.w, self.s)
 
+    def set_y(self, y):
+        self.y = np.ascontiguousarray(y, dtype=np.float64)
+        self._L = self._alpha = self.logml = None   # invalid until the next refit
+
     def refit_predict(self, h, w, s, xo):
         """The device engine's one-sweep route (bq_gp_refit_predict), here as its two halves."""
         self.refit(h, w, s)

@@ -178,6 +178,34 @@ def test_refit_predict_one_sweep(engine, oracle, n, M):
     fit.close()
 
 
+@pytest.mark.parametrize("n", [11, 300])
+def test_set_y_keeps_the_fit(engine, oracle, n):
+    """bq_gp_set_y: same points, new targets (what the hyper-parameter loop does to GP2 on every
+    evaluation, bq.py:948-954).  The fit refuses its consumers until it is refitted, then
+    equals a fresh fit on the new data."""
+    x, y, h, w, s = _problem(n, 5 + n)
+    fit = engine.gp_fit(x, y, h, w, s)
+    y2 = np.cos(x) + 0.1 * y
+    fit.set_y(y2)
+    with pytest.raises(np.linalg.LinAlgError):
+        fit.alpha()
+    fit.refit(h, 1.05 * w, s)
+    Lo, ao, lmo = oracle.gp_fit(x, y2, h, 1.05 * w, s)
+    assert abs(fit.logml - lmo) <= 1e-10 * abs(lmo)
+    assert relmax(fit.alpha(), ao) < 1e-9
+    xo = np.linspace(-4, 4, 9)
+    mo, vo = oracle.gp_predict(x, h, 1.05 * w, Lo, ao, xo)
+    m, v, _ = fit.predict(xo)
+    assert relmax(m, mo) < 1e-9
+    fit.set_y(y)
+    m3, v3 = fit.refit_predict(h, w, s, xo)         # new targets straight into the one-sweep route
+    L1, a1, _ = oracle.gp_fit(x, y, h, w, s)
+    assert relmax(m3, oracle.gp_predict(x, h, w, L1, a1, xo)[0]) < 1e-9
+    with pytest.raises(ValueError):
+        fit.set_y(y[:-1])
+    fit.close()
+
+
 @pytest.mark.parametrize("n", [513, 1100, 2048, 2500, 4097])
 def test_cho_solve_vec_multi_block(engine, n):
     """One right-hand side through several B-wide steps of the GEMV sweeps (trsv.h): full and
