@@ -295,6 +295,33 @@ def test_gaussian_example_notebook(pkg):
     assert abs(before.Z_mean() - g["expected"]["Z_mean"]["value"]) > 1e-4
 
 
+def test_active_sampling_example_notebook(pkg):
+    """docs/ipynb/active-sampling-example.ipynb of the reference (code cells 1, 3, 6, 8, 9,
+    10): ONE sample at x = -5, three candidates; the first ``add(bq)`` prints
+    ``E[Z] = 1.81816144454e-05`` / ``V(Z) = 4.95413041126e-09`` after ``choose_next`` has
+    restored the state (bq.py:622,655).  Unlike the 9-point fixture, V(Z) is no difference
+    of nearly equal terms here: all 12 printed digits pin the variance chain (L_tl, the
+    quadratic form of bq_c.pyx:264-355) and the ns = 1 edge case."""
+    g = known_answers()["active_sampling_example"]
+    fx = g["fixture"]
+    np.random.seed(fx["seed"])
+    x = np.random.uniform(fx["x_low"], fx["x_high"], fx["n"])
+    assert x.shape == (1,) and x[0] == -5.0
+    bq = pkg.BQ(x, f_x(x), kernel=pkg.GaussianKernel, n_candidate=fx["n_candidate"],
+                x_mean=fx["x_mean"], x_var=fx["x_var"],
+                candidate_thresh=fx["candidate_thresh"], optim_method=fx["optim_method"])
+    bq.init(params_tl=tuple(fx["params_tl"]), params_l=tuple(fx["params_l"]))
+    assert bq.ns == 1 and bq.nc == fx["nc"]
+    for name, got in (("Z_mean", bq.Z_mean()), ("Z_var", bq.Z_var())):
+        e = g["expected"][name]
+        # all printed digits: half a unit of the 12th significant digit
+        assert abs(got - e["value"]) <= 0.5 * 10.0 ** (np.floor(np.log10(e["value"])) - 11), \
+            (name, got, e["printed"])
+    # the state survives marginalize, as the notebook's print order requires
+    bq.marginalize([bq.Z_mean], 2, ["h", "w"])
+    assert abs(bq.Z_mean() - g["expected"]["Z_mean"]["value"]) < 1e-16
+
+
 def test_sample_hypers(pkg):
     npseed()
     bq = make_bq(pkg)

@@ -979,3 +979,71 @@ def test_large_fit_properties(engine):
     assert np.max(np.abs(m - y[::64])) < 1e-3
     assert (v > -1e-9).all() and v.max() < 1e-3 * fit.K()[0, 0]
     fit.close()
+
+
+# ---- the sizes bench.py prints rooflines for ---------------------
+@pytest.mark.parametrize("n", [4096, 16384])
+def test_fit_solve_at_benched_sizes(engine, n):
+    """``rooflines.cho_solve_n{4096,16384}_rhs{1,256}`` of bench.py: ``fit.solve`` on the
+    resident factor of the C4-style problem with ONE right-hand side (GEMV sweeps, 512-column
+    steps from a hipGraph) and with 256 (wide row sweeps on the MFMA kernels), against LAPACK's
+    ``dpotrs`` on the downloaded factor (linalg_c.pyx:96-179 semantics): forward error <= 1e-10
+    relative, and the residual ``K X - B`` with the device's own Gram matrix."""
+    import scipy.linalg as sla
+    c = wl.c4(n)
+    y = wl.norm_logpdf(c["x"])
+    fit = engine.gp_fit(c["x"], y, c["h"], c["w"], c["s"])
+    rs = np.random.RandomState(n)
+    L = fit.L()
+    K = fit.K()
+    b1 = rs.randn(n)
+    B = np.asfortranarray(rs.randn(n, 256))
+    x1 = fit.solve(b1)
+    X = fit.solve(B)
+    fit.close()
+    Lt = np.tril(L)
+    r1 = sla.cho_solve((Lt, True), b1)
+    R = sla.cho_solve((Lt, True), B)
+    assert relmax(x1, r1) < 1e-10
+    assert relmax(X, R) < 1e-10
+    # column by column: no column may hide behind the largest one
+    colerr = np.abs(X - R).max(axis=0) / np.abs(R).max(axis=0)
+    assert colerr.max() < 1e-10
+    assert np.abs(K.dot(x1) - b1).max() < 1e-11 * np.abs(K).max() * np.abs(x1).max() * np.sqrt(n)
+    assert np.abs(K.dot(X) - B).max() < 1e-11 * np.abs(K).max() * np.abs(X).max() * np.sqrt(n)
+
+
+def test_predict_m1000_at_benched_size(engine, oracle):
+    """``rooflines.predict_mean_var_n1024_m{256,1000}``: ``fit.predict`` at C2's N = 1024
+    with M = 1000 points (the reference's own plotting grid, bq.py:993) against the oracle."""
+    c = wl.c2()
+    fit = engine.gp_fit(c["x"], c["y"], c["h"], c["w"], c["s"])
+    Lo, ao, _ = oracle.gp_fit(c["x"], c["y"], c["h"], c["w"], c["s"])
+    k0 = oracle.kernel_scale(1, c["h"], c["w"])
+    for M in (256, 1000):
+        xo = np.linspace(-5.0, 5.0, M) + 1e-3       # bench.py's points
+        mo, vo = oracle.gp_predict(c["x"], c["h"], c["w"], Lo, ao, xo)
+        m, v, _ = fit.predict(xo)
+        assert relmax(m, mo) < RTOL
+        assert relmax(v, vo, scale=k0) < RTOL
+        m2 = fit.predict(xo, want_var=False)[0]
+        assert relmax(m2, mo) < RTOL
+    fit.close()
+
+
+def test_cho_solve_mat_square_multi_block(engine, oracle):
+    """``la.cho_solve_mat`` as the reference uses it -- B square (linalg_c.pyx:166) -- at
+    n = 1100: several 256-column steps of the row sweeps AND many right-hand sides (a partial
+    last block both ways), against the oracle's substitution and the residual."""
+    from bayesian_quadrature_amd import la
+    n = 1100
+    rs = np.random.RandomState(n)
+    A = rand_spd(rs, n)
+    L = oracle.cho_factor(A)
+    B = np.asfortranarray(rs.rand(n, n))
+    X = np.empty_like(B, order="F")
+    la.cho_solve_mat(L, B, X)
+    assert relmax(X, oracle.cho_solve(L, B)) < 1e-12
+    assert np.abs(A.dot(X) - B).max() < 1e-12 * n * np.abs(A).max() * np.abs(X).max()
+    la.cho_solve_mat(L, B, B)   # aliased (linalg_c.pyx:171)
+    assert (B == X).all()
