@@ -5,27 +5,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define BQ_MAXD 8
+#include "types.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
-
-// Per-problem scratch of the 64-column panel step: 64 reciprocal pivots of the current
-// diagonal block, then the inverses of its four 16 x 16 diagonal sub-blocks (column-major,
-// 256 doubles each) -- written by potf2f_body, read by trsm_blk_kernel.
-#define BQ_DINV_HALF (64 + 4 * 256)
-// two halves: the one-launch slab step (slab.h) writes the next block's half while this
-// block's is still being read
-#define BQ_DINV_STRIDE (2 * BQ_DINV_HALF)
-
-// Gaussian kernel parameters of one batch element:
-//   k(p,q) = c * exp( sum_k nh[k] (p_k - q_k)^2 ),  c = h^2 / prod(sqrt(2 pi) w_k),
-//   nh[k] = -1 / (2 w_k^2);  s2 = s^2 is added on the diagonal of Kxx.
-struct GaussParams {
-    double c;
-    double s2;
-    double nh[BQ_MAXD];
-};
 
 // Pins a value's computation at this point of the program: without it LLVM
 // sinks the rank-1 updates of the right-looking factorisations down to their
@@ -66,6 +49,21 @@ __device__ __forceinline__ double exp_gauss(double x)
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
     return __builtin_amdgcn_ldexp(p, (int)k);
+}
+
+// quad rotation of a 16-lane row (the four-block MFMA kernels, gemm.h)
+template <int S>
+__device__ __forceinline__ double row_ror_quads(double v)
+{
+    if (S == 0)
+        return v;
+    constexpr int ctrl = 0x120 + 4 * S; // row_ror:4S: lane l reads lane (l - 4S) mod 16 of its row
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    // every lane is written (full row and bank masks), so no "old" value is needed:
+    // mov_dpp avoids the zero-initialising v_mov that update_dpp(0, ...) costs
+    lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
 }
 
 // 1-D grid over the lower-triangular workgroup tiles of a square update:

@@ -1,0 +1,332 @@
+// ctx.hip -- contexts, device memory, timers and the launch profiler of the C ABI.
+#include "host.h"
+
+namespace bqh {
+
+int prof_collect(bq_ctx *c)
+{
+    if (c->prof_events.empty())
+        return BQ_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->aux)
+        HIPCHK(c, hipStreamSynchronize(c->aux));
+    for (auto &e : c->prof_events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            c->prof_ms[e.cls] += ms;
+            c->prof_n[e.cls] += 1;
+            c->prof_work[e.cls] += e.work;
+        }
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    c->prof_events.clear();
+    return BQ_OK;
+}
+
+int check_dims(bq_ctx *c, int64_t d, int64_t n)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    if (d < 1 || d > BQ_MAXD)
+        return fail(c, BQ_ERR_BAD_ARG, "d must be in 1..%d", BQ_MAXD);
+    if (n < 1 || n > (1 << 20))
+        return fail(c, BQ_ERR_BAD_ARG, "n out of range");
+    return BQ_OK;
+}
+
+int check_w(bq_ctx *c, int64_t d, double h, const double *w, double s)
+{
+    if (!w)
+        return fail(c, BQ_ERR_BAD_ARG, "w is NULL");
+    if (!(std::isfinite(h)) || !(std::isfinite(s)))
+        return fail(c, BQ_ERR_BAD_ARG, "h and s must be finite");
+    for (int k = 0; k < d; ++k)
+        if (!(w[k] > 0.0) || !std::isfinite(w[k]))
+            return fail(c, BQ_ERR_BAD_ARG, "w must be positive and finite");
+    return BQ_OK;
+}
+
+
+} // namespace bqh
+
+using namespace bqh;
+
+// ===========================================================================
+// contexts
+// ===========================================================================
+extern "C" int bq_device_count(int *count)
+{
+    if (!count)
+        return BQ_ERR_BAD_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        n = 0;
+    *count = n;
+    return BQ_OK;
+}
+
+static int ctx_init(bq_ctx *c, int device)
+{
+    HIPCHK(c, hipSetDevice(device));
+    c->device = device;
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, device));
+    c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIPCHK(c, hipEventCreate(&c->t0));
+    HIPCHK(c, hipEventCreate(&c->t1));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_next, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    int lo = 0, hi = 0;
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(c, hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, hi));
+    BQCHK(gemm_init(c));
+    if (const char *e = std::getenv("BQ_LOOKAHEAD"))
+        c->lookahead = std::atoi(e);
+    if (const char *e = std::getenv("BQ_SPLIT"))
+        c->split_batch = std::atoi(e);
+    if (const char *e = std::getenv("BQ_LA_MIN"))
+        c->la_min = std::atoi(e);
+    if (const char *e = std::getenv("BQ_GEMM_LDS"))
+        c->gemm_lds = std::atoi(e);
+    if (const char *e = std::getenv("BQ_GRAPH"))
+        c->use_graph = std::atoi(e);
+    return BQ_OK;
+}
+
+extern "C" int bq_ctx_create(int device, bq_ctx **out)
+{
+    if (!out)
+        return BQ_ERR_BAD_ARG;
+    *out = nullptr;
+    bq_ctx *c = new (std::nothrow) bq_ctx();
+    if (!c)
+        return BQ_ERR_NOMEM;
+    int st = ctx_init(c, device);
+    if (st == BQ_OK) {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess)
+            st = fail(c, BQ_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        c->own_stream = true;
+        c->cur = c->stream;
+    }
+    if (st != BQ_OK) {
+        fprintf(stderr, "bq_ctx_create: %s\n", c->err);
+        delete c;
+        return st;
+    }
+    *out = c;
+    return BQ_OK;
+}
+
+extern "C" int bq_ctx_create_on_stream(int device, void *hip_stream, bq_ctx **out)
+{
+    if (!out)
+        return BQ_ERR_BAD_ARG;
+    *out = nullptr;
+    bq_ctx *c = new (std::nothrow) bq_ctx();
+    if (!c)
+        return BQ_ERR_NOMEM;
+    int st = ctx_init(c, device);
+    if (st != BQ_OK) {
+        delete c;
+        return st;
+    }
+    c->stream = static_cast<hipStream_t>(hip_stream);
+    c->cur = c->stream;
+    c->own_stream = false;
+    *out = c;
+    return BQ_OK;
+}
+
+extern "C" void bq_ctx_destroy(bq_ctx *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->plan_cache) {
+        bq_plan_destroy(c, c->plan_cache);
+        c->plan_cache = nullptr;
+    }
+    for (auto &e : c->prof_events) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    if (c->t0)
+        (void)hipEventDestroy(c->t0);
+    if (c->t1)
+        (void)hipEventDestroy(c->t1);
+    for (hipEvent_t e : {c->ev_panel, c->ev_next, c->ev_fork})
+        if (e)
+            (void)hipEventDestroy(e);
+    if (c->aux) {
+        (void)hipStreamSynchronize(c->aux);
+        (void)hipStreamDestroy(c->aux);
+    }
+    if (c->own_stream && c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int bq_ctx_sync(bq_ctx *c)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BQ_OK;
+}
+
+extern "C" const char *bq_last_error(const bq_ctx *c) { return c ? c->err : "null context"; }
+
+extern "C" int bq_device_info(bq_ctx *c, char *name, int *cus, size_t *hbm_bytes, int *clock_khz)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+    if (name) {
+        std::snprintf(name, 64, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (cus)
+        *cus = prop.multiProcessorCount;
+    if (hbm_bytes)
+        *hbm_bytes = prop.totalGlobalMem;
+    if (clock_khz)
+        *clock_khz = prop.clockRate;
+    return BQ_OK;
+}
+
+extern "C" int bq_set_block(bq_ctx *c, int nb)
+{
+    if (!c || nb < 0 || (nb & 63))
+        return c ? fail(c, BQ_ERR_BAD_ARG, "block must be a multiple of 64") : BQ_ERR_BAD_ARG;
+    c->nb_override = nb;
+    return BQ_OK;
+}
+
+extern "C" int bq_set_lookahead(bq_ctx *c, int on)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    c->lookahead = on ? 1 : 0;
+    return BQ_OK;
+}
+
+extern "C" int bq_set_lookahead_rows(bq_ctx *c, int min_rows)
+{
+    if (!c || min_rows < 0)
+        return c ? fail(c, BQ_ERR_BAD_ARG, "min_rows must be >= 0") : BQ_ERR_BAD_ARG;
+    c->la_min = min_rows;
+    return BQ_OK;
+}
+
+// ===========================================================================
+// memory, timers, profiling
+// ===========================================================================
+extern "C" int bq_dev_alloc(bq_ctx *c, size_t bytes, void **dptr)
+{
+    if (!c || !dptr)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(dptr, bytes ? bytes : 8));
+    return BQ_OK;
+}
+
+extern "C" int bq_dev_free(bq_ctx *c, void *dptr)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    if (dptr) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(dptr));
+    }
+    return BQ_OK;
+}
+
+extern "C" int bq_upload(bq_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c || (!dst && bytes) || (!src && bytes))
+        return BQ_ERR_BAD_ARG;
+    if (bytes == 0)
+        return BQ_OK;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BQ_OK;
+}
+
+extern "C" int bq_download(bq_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c || (!dst && bytes) || (!src && bytes))
+        return BQ_ERR_BAD_ARG;
+    if (bytes == 0)
+        return BQ_OK;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BQ_OK;
+}
+
+extern "C" int bq_memset(bq_ctx *c, void *dst, int byte, size_t bytes)
+{
+    if (!c || !dst)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipMemsetAsync(dst, byte, bytes, c->stream));
+    return BQ_OK;
+}
+
+extern "C" int bq_timer_start(bq_ctx *c)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipEventRecord(c->t0, c->stream));
+    return BQ_OK;
+}
+
+extern "C" int bq_timer_stop_ms(bq_ctx *c, float *ms)
+{
+    if (!c || !ms)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipEventRecord(c->t1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->t1));
+    HIPCHK(c, hipEventElapsedTime(ms, c->t0, c->t1));
+    return BQ_OK;
+}
+
+extern "C" int bq_profile_enable(bq_ctx *c, int on)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    BQCHK(prof_collect(c));
+    c->prof = on != 0;
+    return BQ_OK;
+}
+
+extern "C" int bq_profile_reset(bq_ctx *c)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    BQCHK(prof_collect(c));
+    for (int k = 0; k < BQ_K_NCLASS; ++k) {
+        c->prof_ms[k] = 0;
+        c->prof_n[k] = 0;
+        c->prof_work[k] = 0;
+    }
+    return BQ_OK;
+}
+
+extern "C" int bq_profile_read(bq_ctx *c, double *ms, int64_t *launches, double *work)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    BQCHK(prof_collect(c));
+    for (int k = 0; k < BQ_K_NCLASS; ++k) {
+        if (ms)
+            ms[k] = c->prof_ms[k];
+        if (launches)
+            launches[k] = c->prof_n[k];
+        if (work)
+            work[k] = c->prof_work[k];
+    }
+    return BQ_OK;
+}

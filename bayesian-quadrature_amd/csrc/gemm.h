@@ -1,7 +1,8 @@
 // gemm.h -- C -= P Q^T on v_mfma_f64_16x16x4_f64 (panel and trailing updates)
-// Part of the libbqhip.so kernel set; included through kernels.h.
+// Part of the libbqhip.so kernel set; compiled into k_gemm.hip (host.h lists the units).
 #pragma once
 #include "common.h"
+#include "potf2.h"
 
 
 // one wave tile of C -= P Q^T (see gemm_sub_kernel); C, P, Q already point at the batch element
@@ -137,20 +138,6 @@ __device__ __forceinline__ void gemm_sub_tile(double *__restrict__ C, long ldc,
 // store runs.)  Q must be unit-stride in its row index (qsj == 1) and m, n multiples
 // of the wave tile (true for every padded system here).
 // ---------------------------------------------------------------------------
-template <int S>
-__device__ __forceinline__ double row_ror_quads(double v)
-{
-    if (S == 0)
-        return v;
-    constexpr int ctrl = 0x120 + 4 * S; // row_ror:4S: lane l reads lane (l - 4S) mod 16 of its row
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    // every lane is written (full row and bank masks), so no "old" value is needed:
-    // mov_dpp avoids the zero-initialising v_mov that update_dpp(0, ...) costs
-    lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-
 // C tile access of a (16 TM) x (16 TN) wave tile held as acc[TM][TN][4] in the rotated-quad
 // layout (gemm444_tile / gemm_lds_kernel).  Written as `*dst -= acc` at the end of the
 // kernel, the compiler must assume that the store of one element aliases the load of the
@@ -685,16 +672,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_kernel(double *__restrict__ C
 // concatenated k range [P1 Q1 | P2 Q2] (k1, k2 multiples of 64), meet in LDS, wave w owns
 // 16 x 16 block w.  grid (rows / 32, a.ny + b.ny).
 // ---------------------------------------------------------------------------
-struct RowsJob {
-    double *C;
-    long ldc;
-    const double *P1, *Q1, *P2, *Q2;
-    long ldp1, qsj1, qsk1, ldp2, qsj2, qsk2;
-    int k1, k2;
-    int ny;    // tile columns of this job
-    int write; // 1: C = -(products); 0: C -= products
-};
-
+// (struct RowsJob: types.h)
 __global__ __launch_bounds__(256) void rows_step_kernel(RowsJob ja, RowsJob jb)
 {
     __shared__ double red[4][4][4][64];

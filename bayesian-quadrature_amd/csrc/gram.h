@@ -1,5 +1,5 @@
 // gram.h -- Gaussian-kernel Gram matrices and the bordered GP system (HBM-write bound)
-// Part of the libbqhip.so kernel set; included through kernels.h.
+// Part of the libbqhip.so kernel set; compiled into k_gram.hip / k_panel.hip (host.h lists the units).
 #pragma once
 #include "common.h"
 
@@ -159,9 +159,7 @@ __global__ __launch_bounds__(256) void gram_cross_kernel(const double *__restric
 // holds the posterior covariance, -mean in row yrow and -y'K^-1 y at
 // (yrow, yrow); see DESIGN.md.
 // ---------------------------------------------------------------------------
-struct Layout {
-    int n, npad, M, yrow, ntot; // yrow < 0: no y row
-};
+// (struct Layout: types.h)
 
 // One 128 x 64 tile of the bordered system (pts, y, A: this problem's).  S0 != nullptr: the
 // tile's entries of rows >= 64 of column block 0 -- the unsolved first panel of the one-launch

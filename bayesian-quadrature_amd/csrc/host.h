@@ -1,0 +1,451 @@
+// host.h -- internal header of libbqhip.so's host side: the context, the handle types and
+// the launch / enqueue helpers the translation units share.  Nothing here is part of the C
+// ABI (include/bqhip.h is); the library is built with hidden visibility and exports only
+// the extern "C" entry points.
+//
+// Translation units (Makefile):
+//   k_gram.hip   gram.h kernels                 launch_gram_sym / _cross
+//   k_gemm.hip   gemm.h kernels                 launch_gemm, launch_gemm_rows, launch_rows_step
+//   k_panel.hip  potf2.h trsm.h slab.h kernels  launch_assemble, launch_potf2, launch_trsm_blk,
+//                                               the one-launch steps
+//   k_reduce.hip reduce.h trsv.h kernels        read-outs, single-vector sweeps, utilities
+//   potrf.hip    the blocked factorisation's launch sequences (no kernels of its own)
+//   sweeps.hip   sweeps over a resident factor (no kernels of its own)
+//   ctx.hip      contexts, device memory, timers, the launch profiler
+//   linalg.hip   linalg_c drop-ins, Gram entry points, bq_potrf_dev
+//   plan.hip     resident batched plans, batched / grid entry points
+//   fit.hip      resident GP fits
+//   moments.hip  closed-form integrals, BQ moments, the acquisition entry points
+//   probe.hip    hardware probes
+#pragma once
+#include <hip/hip_runtime.h>
+
+#pragma GCC visibility push(default)
+#include "../../include/bqhip.h"
+#pragma GCC visibility pop
+
+#include "types.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+// RAII device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t alloc(size_t b)
+    {
+        release();
+        if (b == 0)
+            b = 8;
+        hipError_t e = hipMalloc(&p, b);
+        if (e == hipSuccess)
+            bytes = b;
+        else
+            p = nullptr;
+        return e;
+    }
+    double *d() const { return static_cast<double *>(p); }
+    int *i() const { return static_cast<int *>(p); }
+};
+
+struct ProfEvent {
+    hipEvent_t a, b;
+    int cls;
+    double work;
+};
+
+struct bq_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr; // main stream: everything is ordered on it
+    hipStream_t aux = nullptr;    // high-priority panel stream of the look-ahead Cholesky
+    hipStream_t cur = nullptr;    // stream the launch helpers enqueue on (stream or aux)
+    hipEvent_t ev_panel = nullptr, ev_next = nullptr, ev_fork = nullptr;
+    int lookahead = 1;
+    int split_batch = 1; // halves of a mid-sized batch on the two streams (BQ_SPLIT=0: lock-step)
+    int la_min = 4096;   // look-ahead only while the bulk update has at least this many rows (BQ_LA_MIN)
+    DevBuf panel_ws;     // scratch panel columns of the eager linalg entry points
+    DevBuf scratch;      // per-call temporaries of the acquisition / moment entry points, kept
+                         // between calls (hipFree synchronises the device); bq_ctx_trim frees it
+    int gemm_lds = 1;    // LDS-staged 128x128 trailing update (BQ_GEMM_LDS)
+    int use_graph = 1;   // replay plans from a captured hipGraph (BQ_GRAPH=0 disables)
+    bool own_stream = false;
+    int cus = 256;
+    int nb_override = 0;
+    bq_plan *plan_cache = nullptr; // workspace of the last batched call, kept for the next one
+    char err[512] = {0};
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool prof = false;
+    std::vector<ProfEvent> prof_events;
+    double prof_ms[BQ_K_NCLASS] = {0};
+    int64_t prof_n[BQ_K_NCLASS] = {0};
+    double prof_work[BQ_K_NCLASS] = {0};
+    DevBuf gbuf;   // GaussParams of the single-problem entry points (cached)
+    GaussParams gbuf_host{};
+    bool gbuf_valid = false;
+    DevBuf dinv64; // potf2 reciprocal-diagonal scratch
+    long long *stamp_buf = nullptr; // bq_probe_c2_timeline: 160 stamps per slab step
+    int stamp_steps = 0;            // slab steps stamp_buf has room for
+};
+
+namespace bqh {
+
+inline int fail(bq_ctx *c, int code, const char *fmt, ...)
+{
+    if (c) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(c->err, sizeof c->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                        \
+    do {                                                                                       \
+        hipError_t e__ = (call);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return bqh::fail((c), e__ == hipErrorOutOfMemory ? BQ_ERR_NOMEM : BQ_ERR_HIP,      \
+                             "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                             __LINE__);                                                        \
+    } while (0)
+
+#define BQCHK(call)                                                                            \
+    do {                                                                                       \
+        int s__ = (call);                                                                      \
+        if (s__ != BQ_OK)                                                                      \
+            return s__;                                                                        \
+    } while (0)
+
+inline long roundup(long v, long q) { return (v + q - 1) / q * q; }
+
+// leading dimension for an ntot x ntot column-major matrix: even, and nudged
+// off large powers of two so that the 4 columns of an MFMA fragment do not
+// all map to the same HBM channel / L2 set
+inline long pick_ld(long ntot)
+{
+    long ld = ntot;
+    if (ntot >= 1024 && (ntot % 512) == 0)
+        ld += 64;
+    return ld;
+}
+
+inline GaussParams make_params(int d, double h, const double *w, double s)
+{
+    GaussParams g;
+    std::memset(&g, 0, sizeof g);
+    double c = h * h;
+    for (int k = 0; k < d; ++k) {
+        c /= (std::sqrt(2.0 * M_PI) * w[k]);
+        g.nh[k] = -0.5 / (w[k] * w[k]);
+    }
+    g.c = c;
+    g.s2 = s * s;
+    return g;
+}
+
+inline Layout make_layout(int n, int M, bool has_y)
+{
+    Layout L;
+    L.n = n;
+    L.npad = (int)roundup(n, 64);
+    L.M = M;
+    L.yrow = has_y ? L.npad + M : -1;
+    L.ntot = (int)roundup(L.npad + M + (has_y ? 1 : 0), 64);
+    return L;
+}
+
+// ---- profiling brackets: HIP events around a launch, on the stream it goes to ----
+struct Bracket {
+    bq_ctx *c;
+    ProfEvent ev;
+    bool on;
+    Bracket(bq_ctx *ctx, int cls, double work = 0.0) : c(ctx), on(ctx->prof)
+    {
+        if (on) {
+            ev.cls = cls;
+            ev.work = work;
+            if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) {
+                on = false;
+                return;
+            }
+            (void)hipEventRecord(ev.a, c->cur);
+        }
+    }
+    ~Bracket()
+    {
+        if (on) {
+            (void)hipEventRecord(ev.b, c->cur);
+            c->prof_events.push_back(ev);
+        }
+    }
+};
+
+int prof_collect(bq_ctx *c); // ctx.hip
+
+// Carves the per-call temporaries of one entry point out of the context's scratch buffer:
+// sizes first (take), then one commit that grows the buffer if it must, then the pointers.
+struct Scratch {
+    bq_ctx *c;
+    size_t total = 0;
+    explicit Scratch(bq_ctx *ctx) : c(ctx) {}
+    size_t take(size_t doubles)
+    {
+        const size_t off = total;
+        total += (doubles + 31) & ~(size_t)31; // 256-byte granules
+        return off;
+    }
+    int commit()
+    {
+        if (c->scratch.bytes < total * sizeof(double)) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, c->scratch.alloc(total * sizeof(double)));
+        }
+        return BQ_OK;
+    }
+    double *at(size_t off) const { return c->scratch.d() + off; }
+};
+
+int check_dims(bq_ctx *c, int64_t d, int64_t n);                          // ctx.hip
+int check_w(bq_ctx *c, int64_t d, double h, const double *w, double s);   // ctx.hip
+
+// ---- k_gram.hip -----------------------------------------------------------------------
+int launch_gram_sym(bq_ctx *c, int d, const double *x, long xstride, const GaussParams *gp,
+                    int gpstride, double *K, long ldk, long kstride, int n, int batch);
+int launch_gram_cross(bq_ctx *c, int d, const double *x1, int n1, const double *x2, int n2,
+                      const GaussParams &g, double *K, long ldk);
+
+// ---- k_panel.hip ----------------------------------------------------------------------
+// fs: when set, the first launch of the slab sweep rides in the assembly (assemble_first_kernel)
+struct FirstStep {
+    double *S0 = nullptr;
+    long lds = 0, sstride = 0;
+    double *dinv = nullptr;
+    int *info = nullptr;
+};
+int launch_assemble(bq_ctx *c, int d, const double *pts, long pstride, const double *y,
+                    long ystride, const GaussParams *gp, int gpstride, double *A, long lda,
+                    long astride, Layout L, int batch, const FirstStep &fs = FirstStep());
+int launch_potf2(bq_ctx *c, double *A, long lda, long astride, int j0, double *dinv, long dstride,
+                 int *info, int batch);
+int launch_trsm_blk(bq_ctx *c, double *X, long ldx, long xstride, int m, const double *L11,
+                    long ldl, long lstride, const double *dinv, long dstride, int batch);
+// the 16 x 16 block inverses of every 64 x 64 diagonal block of a factor (npad / 64 records)
+int launch_diag_winv(bq_ctx *c, const double *L, long ldl, int npad, double *dw);
+int launch_panel_step(bq_ctx *c, double *A, long lda, long astride, int batch, int nrb,
+                      double *Sin, double *Sout, long lds, long sstride, int K0, int j0,
+                      double *dinv_in, double *dinv_out, int has_next, int first, double *SL,
+                      int *info, double work);
+int launch_slab_first(bq_ctx *c, double *A, long lda, long astride, int batch, double *S, long lds,
+                      long sstride, int ntot, double *dinv, int *info, int col0);
+int launch_slab_step(bq_ctx *c, double *A, long lda, long astride, int batch, double *Sin,
+                     double *Sout, long lds, long sstride, int ntot, int j0, double *dinv_in,
+                     double *dinv_out, int fnext, int last, int *info, int col0,
+                     long long *stamps, double work);
+
+// ---- k_gemm.hip -----------------------------------------------------------------------
+int gemm_init(bq_ctx *c); // function attributes of the LDS-staged kernels, once per context
+bool gemm_uses_lds(const bq_ctx *c, int m, int n, int k, int lower, int batch);
+// C(m x n) -= P(m x k) Q(n x k)^T; see k_gemm.hip
+int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const double *P, long ldp,
+                long pstride, const double *Q, long qsj, long qsk, long qstride, int m, int n,
+                int k, int lower, int batch, int fuse_j0 = -1, double *dinv = nullptr,
+                long dstride = 0, int *info = nullptr, int ccut = 0);
+int launch_gemm_rows(bq_ctx *c, int cls, double *C, long ldc, const double *P, long ldp,
+                     const double *Q, long qsj, long qsk, int m, int n, int k);
+int launch_rows_step(bq_ctx *c, int mrows, const RowsJob &a, const RowsJob &b, double work);
+
+// ---- k_reduce.hip ---------------------------------------------------------------------
+int launch_finalize(bq_ctx *c, const double *A, long lda, long astride, Layout L, double *scal,
+                    double *mean, double *var, long mstride, int batch, double work = 0.0);
+int launch_plan_readout(bq_ctx *c, const double *A, long lda, long astride, Layout L,
+                        const GaussParams *gp, double *scal, double *mean, double *var,
+                        long mstride, int batch);
+int launch_rowdot(bq_ctx *c, const double *V, long ldv, int M, int Mp, int npad, const double *z,
+                  double k0, double *mean, double *var);
+int launch_predict_mean(bq_ctx *c, int d, const double *xo, int M, const double *pts, int n,
+                        const double *alpha, const GaussParams &g, double *mean);
+int launch_neg_identity(bq_ctx *c, double *nr, int B, int npad);
+int launch_pad_identity(bq_ctx *c, double *A, long lda, int n, int ntot);
+int launch_logdet(bq_ctx *c, const double *diag, long stride, int n, double *out);
+int launch_transpose_pad(bq_ctx *c, const double *src, long lds, int rows, int cols, double *dst,
+                         long ldd);
+int launch_transpose_blocks(bq_ctx *c, const double *src, double *dst, int B, long bstride,
+                            int bx, int by, int batch);
+int launch_neg_sumsq(bq_ctx *c, const double *v, int n, double *out);
+int launch_trsv_fwd(bq_ctx *c, const double *L, long ldl, int J, int bJ, int B, int nupd,
+                    const double *nr, const double *tt, double *x, double *y, double work);
+int launch_trsv_bwd(bq_ctx *c, const double *L, long ldl, int J, int bJ, int B, int bn, int nupd,
+                    const double *nt, const double *uu, double *x, double *y, double work);
+
+// ---- potrf.hip ------------------------------------------------------------------------
+int auto_nb(const bq_ctx *c, int ntot, int batch);
+size_t panel_ws_doubles(int ntot, int batch);
+bool panel_ws_useful(const bq_ctx *c, int ntot, int batch);
+bool sweep_is_slab(const bq_ctx *c, int ntot, int ncols, int batch, size_t panel_ws_len);
+int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
+                          int ncols, double *dinv, int *info, double *panel_ws = nullptr,
+                          size_t panel_ws_len = 0, bool first_done = false,
+                          bool skip_border = false);
+
+// ---- sweeps.hip -----------------------------------------------------------------------
+struct WideInv {
+    const double *nr = nullptr; // -W^T of every block
+    // the single-vector sweeps (trsv.h):
+    const double *nt = nullptr; // -W (the transposes)
+    const double *tt = nullptr; // T_J^T, T_J = W_J L[J, J-B] (blocks J >= B)
+    const double *uu = nullptr; // U_J = L[J+B, J] W_J (all blocks but the last)
+    const double *t = nullptr;  // T_J itself (rows of T contiguous: the fused row-sweep step)
+    int B = 0;
+};
+inline int wide_block(int npad) { return npad < 2048 ? std::min(npad, 256) : 512; }
+inline size_t wide_doubles(int npad) { return (size_t)npad * wide_block(npad); }
+// NR, NT, TT, UU and the scratch of T before its transposition (a full B x B per block)
+inline size_t wide_alloc_doubles(int npad)
+{
+    const size_t B = (size_t)wide_block(npad);
+    return 5 * wide_doubles(npad) + B * B;
+}
+WideInv wide_views(const double *base, int npad);
+int compute_wide_inverses(bq_ctx *c, const double *L, long ldl, int npad, const double *dw,
+                          double *nr);
+int enqueue_forward_vec(bq_ctx *c, double *x, double *y, const double *L, long ldl, int npad,
+                        WideInv w);
+int enqueue_backward_vec(bq_ctx *c, double *x, double *y, const double *L, long ldl, int npad,
+                         WideInv w);
+int enqueue_forward_rows_blk(bq_ctx *c, double *X, long ldx, int mrows, const double *L, long ldl,
+                             int npad, const double *dw);
+int enqueue_forward_rows(bq_ctx *c, double *Xin, double *Xout, long ldx, int mrows,
+                         const double *L, long ldl, int npad, WideInv w);
+int enqueue_backward_rows(bq_ctx *c, double *Xin, double *Xout, long ldx, int mrows,
+                          const double *L, long ldl, int npad, WideInv w);
+int solve_rows_host(bq_ctx *c, const double *L, long ldl, int n, int npad, WideInv w,
+                    const double *B, int64_t nrhs, double *X);
+
+} // namespace bqh
+
+// ---- handle types (plan.hip, fit.hip) ---------------------------------------------------
+struct bq_plan {
+    int nprob = 0, d = 0, n = 0, M = 0;
+    Layout L{};
+    long lda = 0, astride = 0;
+    DevBuf A, pts, y, gp, dinv, info, scal, mean, var;
+    DevBuf panel; // scratch panel columns of the one-launch slab sweep (small systems)
+    std::vector<GaussParams> hgp;
+    bool has_inputs = false;
+    // the launch sequence of a plan is static: it is captured once into a hipGraph
+    // and replayed (cuts the host launch cost of the ~50 short kernels of a step)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    int graph_state = 0; // 0 = not tried, 1 = ready, -1 = unavailable (eager launches)
+    int graph_nb = 0, graph_la = 0, graph_pw = 0;
+};
+
+struct bq_fit {
+    int d = 0, n = 0, npad = 0;
+    long ldl = 0;
+    Layout L{}; // layout of the fit system (M = 0, y row)
+    double h = 0, s = 0, w[BQ_MAXD] = {0};
+    GaussParams g{};
+    DevBuf A;     // ntot x ntot bordered factor: L in [0,npad)^2, z in row yrow
+    DevBuf pts;   // d x ntot
+    DevBuf y;     // npad
+    DevBuf gp;    // GaussParams
+    DevBuf dinv;  // npad reciprocal diagonal (+ BQ_DINV_STRIDE scratch for the factorisation)
+    DevBuf panel; // scratch panel columns of the one-launch slab sweep
+    DevBuf dw;    // diag_winv_kernel records of the resident factor (MFMA solves in the sweeps)
+    DevBuf wide;  // -W^T of the B-wide diagonal blocks (row sweeps), valid if have_wide
+    bool have_wide = false;
+    bool have_dw = false; // dw is built on its first use: a loop that reads log-ML never pays
+    DevBuf wV, wV2, wx, wout, wz; // prediction workspaces, grown on demand and kept
+    DevBuf misc;  // info (int) + scal[4], then 2 x 64 doubles: the posterior of the border points
+                  // of bq_gp_refit_predict (one read-back for all of it)
+    DevBuf alpha; // npad, valid if have_alpha
+    bool have_alpha = false;
+    // the single-vector sweeps (trsv.h): x | y, 2 npad doubles, and their captured launch
+    // chains -- [0] solve (forward + backward), [1] backward into alpha, [2] forward; the
+    // pointers survive a refit, so the graphs do too
+    DevBuf vec;
+    hipGraph_t vgraph[3] = {nullptr, nullptr, nullptr};
+    hipGraphExec_t vgexec[3] = {nullptr, nullptr, nullptr};
+    bool vg_failed[3] = {false, false, false};
+    ~bq_fit()
+    {
+        for (int i = 0; i < 3; ++i) {
+            if (vgexec[i])
+                (void)hipGraphExecDestroy(vgexec[i]);
+            if (vgraph[i])
+                (void)hipGraphDestroy(vgraph[i]);
+        }
+    }
+    // false from the start of a (re)factorisation until it has succeeded: a refit that hits a
+    // non-positive pivot leaves L, dinv, dw and the scalars overwritten with garbage
+    bool valid = false;
+    // true after bq_gp_set_y until the next (re)fit: the targets changed, the factor did not
+    bool stale = false;
+    double logml = 0, logdet = 0, qf = 0;
+};
+
+namespace bqh {
+// fit.hip: shared with moments.hip
+int check_fit(bq_ctx *c, const bq_fit *f);
+int fit_dw(bq_ctx *c, bq_fit *f);
+int fit_wide(bq_ctx *c, bq_fit *f, WideInv &w);
+int fit_vec(bq_ctx *c, bq_fit *f);
+int fit_alpha(bq_ctx *c, bq_fit *f);
+// Replays a chain of sweep launches over a fit's own buffers from a captured hipGraph (a
+// sweep is 2 npad / B launches of 2-8 us each: enqueued one by one the host is the
+// bottleneck); eager when graphs are off, under the launch profiler, or if capture fails.
+template <class F>
+int fit_replay(bq_ctx *c, bq_fit *f, int slot, F &&enqueue)
+{
+    if (!c->use_graph || c->prof || !c->own_stream || c->cur != c->stream)
+        return enqueue();
+    if (!f->vgexec[slot] && !f->vg_failed[slot]) {
+        f->vg_failed[slot] = true;
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
+            const int st = enqueue();
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(c->stream, &g);
+            if (st == BQ_OK && e == hipSuccess && g &&
+                hipGraphInstantiate(&f->vgexec[slot], g, nullptr, nullptr, 0) == hipSuccess) {
+                f->vgraph[slot] = g;
+                f->vg_failed[slot] = false;
+            } else {
+                if (g)
+                    (void)hipGraphDestroy(g);
+                f->vgexec[slot] = nullptr;
+                (void)hipGetLastError();
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (f->vgexec[slot]) {
+        HIPCHK(c, hipGraphLaunch(f->vgexec[slot], c->stream));
+        return BQ_OK;
+    }
+    return enqueue();
+}
+// plan.hip: the launch sequence of one pass of a plan (bq_probe_c2_timeline runs it eagerly)
+int plan_enqueue(bq_ctx *c, bq_plan *p);
+} // namespace bqh

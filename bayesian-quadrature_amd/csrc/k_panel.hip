@@ -1,0 +1,124 @@
+// k_panel.hip -- the panel side of the factorisation: assembly of the bordered system (with
+// the sweep's first launch folded in), the 64 x 64 diagonal factor, the MFMA panel solve and
+// the one-launch steps (gram.h, potf2.h, trsm.h, slab.h), and their launchers.
+#include "host.h"
+#include "gram.h"
+#include "trsm.h"
+#include "slab.h"
+
+namespace bqh {
+
+template <int D>
+void launch_assemble_d(bq_ctx *c, const double *pts, long pstride, const double *y, long ystride,
+                       const GaussParams *gp, int gpstride, double *A, long lda, long astride,
+                       Layout L, int batch, const FirstStep &fs)
+{
+    dim3 grid((L.ntot + 127) / 128, (L.ntot + 63) / 64, batch);
+    if (fs.S0)
+        hipLaunchKernelGGL(assemble_first_kernel<D>, grid, dim3(256), 0, c->cur, pts, pstride, y,
+                           ystride, gp, gpstride, A, lda, astride, L, fs.S0, fs.lds, fs.sstride,
+                           fs.dinv, (long)BQ_DINV_STRIDE, fs.info);
+    else
+        hipLaunchKernelGGL(assemble_kernel<D>, grid, dim3(256), 0, c->cur, pts, pstride, y, ystride,
+                           gp, gpstride, A, lda, astride, L);
+}
+
+int launch_assemble(bq_ctx *c, int d, const double *pts, long pstride, const double *y,
+                    long ystride, const GaussParams *gp, int gpstride, double *A, long lda,
+                    long astride, Layout L, int batch, const FirstStep &fs)
+{
+    Bracket br(c, BQ_K_GRAM, 8.0 * L.ntot * (L.ntot + 1.0) / 2.0 * batch);
+    switch (d) {
+    case 1: launch_assemble_d<1>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
+    case 2: launch_assemble_d<2>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
+    case 3: launch_assemble_d<3>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
+    case 4: launch_assemble_d<4>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
+    case 5: launch_assemble_d<5>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
+    case 6: launch_assemble_d<6>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
+    case 7: launch_assemble_d<7>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
+    case 8: launch_assemble_d<8>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
+    default: return fail(c, BQ_ERR_BAD_ARG, "d must be in 1..%d", BQ_MAXD);
+    }
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+int launch_potf2(bq_ctx *c, double *A, long lda, long astride, int j0, double *dinv, long dstride,
+                 int *info, int batch)
+{
+    Bracket br(c, BQ_K_POTF2, 64.0 * 64 * 64 / 3.0 * batch);
+    hipLaunchKernelGGL(potf2_kernel, dim3(1, 1, batch), dim3(256), 0, c->cur, A, lda, astride,
+                           j0, dinv, dstride, info);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+// the MFMA panel solve (trsm_blk_kernel): needs the block inverses potf2f_body leaves
+// behind the 64 reciprocal pivots
+int launch_trsm_blk(bq_ctx *c, double *X, long ldx, long xstride, int m, const double *L11,
+                    long ldl, long lstride, const double *dinv, long dstride, int batch)
+{
+    if (m <= 0)
+        return BQ_OK;
+    Bracket br(c, BQ_K_TRSM, 64.0 * 64 * (double)m * batch);
+    hipLaunchKernelGGL(trsm_blk_kernel, dim3((m + 63) / 64, 1, batch), dim3(256), 0, c->cur, X, ldx,
+                       xstride, m, L11, ldl, lstride, dinv, dstride);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+int launch_diag_winv(bq_ctx *c, const double *L, long ldl, int npad, double *dw)
+{
+    hipLaunchKernelGGL(diag_winv_kernel, dim3(npad / 64), dim3(256), 0, c->stream, L, ldl, dw);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+// one step of a wide panel in one launch (panel_step_kernel, slab.h)
+int launch_panel_step(bq_ctx *c, double *A, long lda, long astride, int batch, int nrb,
+                      double *Sin, double *Sout, long lds, long sstride, int K0, int j0,
+                      double *dinv_in, double *dinv_out, int has_next, int first, double *SL,
+                      int *info, double work)
+{
+    Bracket br(c, BQ_K_GEMM, work);
+    hipLaunchKernelGGL(panel_step_kernel, dim3(nrb, 1, batch), dim3(256), 0, c->cur, A, lda,
+                       astride, Sin, Sout, lds, sstride, K0, j0, dinv_in, dinv_out,
+                       (long)BQ_DINV_STRIDE, has_next, first, SL, info);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+// the first diagonal factor of a slab sweep and the staging of panel 0 in one launch
+int launch_slab_first(bq_ctx *c, double *A, long lda, long astride, int batch, double *S, long lds,
+                      long sstride, int ntot, double *dinv, int *info, int col0)
+{
+    Bracket br(c, BQ_K_POTF2, 64.0 * 64 * 64 / 3.0 * batch);
+    hipLaunchKernelGGL(slab_first_kernel, dim3(ntot / 64, 1, batch), dim3(256), 0, c->cur, A, lda,
+                       astride, S, lds, sstride, ntot, dinv, (long)BQ_DINV_STRIDE, info, col0);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+// one 64-column step of a small system in one launch (slab_step_kernel); stamps: the
+// profiling instantiation (bq_probe_c2_timeline)
+int launch_slab_step(bq_ctx *c, double *A, long lda, long astride, int batch, double *Sin,
+                     double *Sout, long lds, long sstride, int ntot, int j0, double *dinv_in,
+                     double *dinv_out, int fnext, int last, int *info, int col0,
+                     long long *stamps, double work)
+{
+    const int T = (ntot - j0 - 64) / 64;
+    Bracket br(c, BQ_K_SYRK_SMALL, work);
+    if (stamps)
+        hipLaunchKernelGGL(slab_step_kernel<true>, dim3(T * (T + 1) / 2, 1, batch), dim3(256), 0,
+                           c->cur, A, lda, astride, Sin, Sout, lds, sstride, ntot, j0, dinv_in,
+                           dinv_out, (long)BQ_DINV_STRIDE, fnext, last, info, col0, stamps);
+    else
+        hipLaunchKernelGGL(slab_step_kernel<false>, dim3(T * (T + 1) / 2, 1, batch), dim3(256), 0,
+                           c->cur, A, lda, astride, Sin, Sout, lds, sstride, ntot, j0, dinv_in,
+                           dinv_out, (long)BQ_DINV_STRIDE, fnext, last, info, col0,
+                           (long long *)nullptr);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+} // namespace bqh

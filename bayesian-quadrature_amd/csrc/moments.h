@@ -1,5 +1,5 @@
 // moments.h -- closed-form gauss_c integrals, BQ moments, batched active-sampling systems
-// Part of the libbqhip.so kernel set; included through kernels.h.
+// Part of the libbqhip.so kernel set; compiled into moments.hip (host.h lists the units).
 #pragma once
 #include "common.h"
 
@@ -11,12 +11,7 @@
 // inverse Cholesky factor of the small D x D covariance (D <= 16), so the
 // Mahalanobis term is || Linv z ||^2 with no division on the device.
 // ===========================================================================
-template <int D>
-struct GaussForm {
-    double mu[D];        // subtracted from the point(s) to form z
-    double linv[D * D];  // row-major lower-triangular inverse Cholesky factor
-    double logc;         // -(D log 2pi + log|C|) / 2
-};
+// (struct GaussForm<D>: types.h)
 
 template <int D>
 __device__ __forceinline__ double gauss_form_eval(const GaussForm<D> &f, const double (&z)[D])
@@ -210,9 +205,7 @@ __global__ __launch_bounds__(256) void reduce_sum_kernel(const double *__restric
 // After eliminating the npad columns, A_a and A_sc . l_sc are read off the panel
 // and the Schur complement (esm_finalize_kernel); no back substitution.
 // ===========================================================================
-struct EsmLayout {
-    int ns, nsc, npad, ntot; // points [0, nsc] (nsc+1 of them), border rows npad, npad+1
-};
+// (struct EsmLayout: types.h)
 
 __global__ __launch_bounds__(256) void assemble_esm_kernel(const double *__restrict__ x_sc,
                                                            const double *__restrict__ x_a,

@@ -1,9 +1,13 @@
-// integrals.inc -- host side of the closed-form Gaussian-kernel integrals and of
-// the BQ moments (part of the bqhip.hip translation unit).
+// moments.hip -- host side of the closed-form Gaussian-kernel integrals, of the BQ moments and
+// of the acquisition entry points, with their kernels (moments.h).
 //
 // Reference: gauss_c.pyx:95-164,235-339,416-531,617-713 and bq_c.pyx:157-213,264-355.
 // The d x d (or 2d x 2d) covariance algebra is done here on the host in plain
-// loops; the per-point / per-pair work runs in the kernels at the end of kernels.h.
+// loops; the per-point / per-pair work runs in the kernels of moments.h.
+#include "host.h"
+#include "moments.h"
+
+using namespace bqh;
 
 namespace {
 
@@ -462,8 +466,7 @@ extern "C" int bq_bq_Z_var(bq_ctx *c, bq_fit *gp_tl, bq_fit *gp_l, const double 
     BQCHK(fit_replay(c, gp_tl, 2, [&]() -> int {
         return enqueue_forward_vec(c, sol, X, gp_tl->A.d(), gp_tl->ldl, npad, wi);
     }));
-    hipLaunchKernelGGL(neg_sumsq_kernel, dim3(1), dim3(256), 0, c->stream, X, npad, scal + 1);
-    HIPCHK(c, hipGetLastError());
+    BQCHK(launch_neg_sumsq(c, X, npad, scal + 1));
     double hs[2];
     HIPCHK(c, hipMemcpyAsync(hs, scal, sizeof hs, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -602,7 +605,7 @@ extern "C" int bq_esm_batch(bq_ctx *c, const double *x_sc, const double *l_sc, i
 // the sweep, one GEMM of the leading parts against b and l, the squared norms.  No inverse
 // of K_sc is formed and nothing is subtracted but the Schur complement itself.  (A first
 // version corrected K_sc^-1 by Woodbury: with the jitter larger than K_sc's small
-// eigenvalues it lost cond(K) -- 3e-10 against the oracle's 7e-13 on the ill-conditioned case
+// eigenvalues it lost cond(K) -- 3e-10 against the CPU restatement's 7e-13 on the ill-conditioned case
 // of test_acquisition_and_posterior_vs_extended_precision.)  status[a] = 1 where the Schur
 // complement is not positive (bq.py:481-490's fallback).  Requires a noise-free gp_l (Kxoxo
 // carries no s^2 term, bq.py:465): BQ_ERR_BAD_ARG else, and the caller uses bq_esm_batch.
@@ -669,11 +672,7 @@ extern "C" int bq_esm_border(bq_ctx *c, bq_fit *gp_l, int64_t ns, const double *
     if (p > 0) {
         BQCHK(launch_gemm(c, BQ_K_GEMM, G.d(), mrows, 0, F.d(), mrows, 0, F.d(), 1, mrows, 0, mrows,
                           T, p, 0, 1));
-        Bracket br(c, BQ_K_REDUCE, 8.0 * (double)mrows * p);
-        hipLaunchKernelGGL(rowdot_kernel, dim3(mrows / 16), dim3(1024), 0, c->stream, F.d(),
-                           (long)mrows, mrows, p, (const double *)nullptr, 0.0, (double *)nullptr,
-                           sq.d());
-        HIPCHK(c, hipGetLastError());
+        BQCHK(launch_rowdot(c, F.d(), (long)mrows, mrows, mrows, p, nullptr, 0.0, nullptr, sq.d()));
     }
     std::vector<double> hG((size_t)mrows * T), hsq((size_t)mrows), hb((size_t)M), xsc((size_t)nsc),
         F2((size_t)mrows * nt), L22((size_t)nt * nt);

@@ -1,5 +1,5 @@
 // potf2.h -- the 64x64 diagonal Cholesky block (four waves) and its block inverses
-// Part of the libbqhip.so kernel set; included through kernels.h.
+// Part of the libbqhip.so kernel set; compiled into k_gemm.hip / k_panel.hip / probe.hip (host.h lists the units).
 #pragma once
 #include "common.h"
 
@@ -287,40 +287,4 @@ __device__ __forceinline__ void potf2_body(double *__restrict__ Ab, long lda, in
                                            long lsrc = 0, long long *stamps = nullptr)
 {
     potf2f_body(Ab, lda, j0, dinv_b, info_b, lds, src, lsrc, src == lds, stamps);
-}
-
-__global__ __launch_bounds__(256) void potf2_kernel(double *__restrict__ A, long lda, long astride,
-                                                    int j0, double *__restrict__ dinv,
-                                                    long dstride, int *__restrict__ info)
-{
-    __shared__ __attribute__((aligned(16))) double lds[BQ_POTF2_LDS_DOUBLES];
-    __builtin_amdgcn_s_setprio(3);
-    const int b = blockIdx.z;
-    potf2_body(A + (long)b * astride + j0 + (long)j0 * lda, lda, j0, dinv + (long)b * dstride,
-               info + b, lds);
-}
-
-// timing probe: the factor alone on a block that is restored from Ain every launch;
-// stamps[0..4] of the last launch = s_memtime at entry / loaded / chain done / blocks in LDS / end
-__global__ __launch_bounds__(256) void potf2_probe_kernel(const double *__restrict__ Ain,
-                                                          double *__restrict__ A, long lda,
-                                                          double *__restrict__ dinv,
-                                                          int *__restrict__ info,
-                                                          long long *stamps, int from_lds)
-{
-    __shared__ __attribute__((aligned(16))) double lds[BQ_POTF2_LDS_DOUBLES];
-    __builtin_amdgcn_s_setprio(3);
-    if (from_lds) {
-        // as the slab step hands the block over: through LDS
-        double *Ts = lds; // where the panel slots will be
-        for (int e = threadIdx.x; e < 4096; e += 256)
-            Ts[e] = Ain[(e & 63) + (long)(e >> 6) * lda];
-        __syncthreads();
-        potf2_body(A, lda, 0, dinv, info, lds, Ts, 64, stamps);
-    } else {
-        for (int e = threadIdx.x; e < 4096; e += 256)
-            A[(e & 63) + (long)(e >> 6) * lda] = Ain[(e & 63) + (long)(e >> 6) * lda];
-        __syncthreads();
-        potf2_body(A, lda, 0, dinv, info, lds, nullptr, 0, stamps);
-    }
 }

@@ -1,0 +1,333 @@
+// potrf.hip -- the launch sequences of the blocked right-looking Cholesky: block sizes,
+// recursive panels, the one-launch sweeps of small systems, the two-stream look-ahead and the
+// two half-batches of mid-sized batches.  No kernels of its own (k_panel.hip, k_gemm.hip).
+#include "host.h"
+
+namespace bqh {
+
+// below this size one or two matrices sweep with the one-launch steps of outer block 64
+// (tools/potrf_sizes.py, ms with blocks 64 / 128 / 256: N = 2048 0.57 / 0.76 / 0.80,
+// 4096 1.69 / 1.93 / 1.92, 6144 4.21 / 3.72 / 3.57)
+#define BQ_SLAB_MAX 4800
+
+int auto_nb(const bq_ctx *c, int ntot, int batch)
+{
+    if (c->nb_override > 0)
+        return c->nb_override;
+    // the trailing update re-reads and re-writes the whole remaining matrix once per
+    // outer block: when the batch's matrices do not fit the caches the outer block
+    // must be wide (256: 46 GB instead of 183 GB of traffic at N=16384), when they do
+    // a narrow block means fewer, shorter launches
+    const double mb = 8.0 * (double)ntot * ntot * batch / 1e6;
+    if (batch <= 2) {
+        // One or two matrices cannot fill the chip with a 64-column panel: the sweep is a
+        // chain of dependent launches and the one-launch step of outer block 64 (slab.h) is
+        // the shortest chain until the k = 64 updates cost more than it saves
+        // (tools/potrf_sizes.py on one matrix: N=2048 0.73 / 0.81 ms, 3072 1.24 / 1.31,
+        // 4096 2.03 / 2.00, 6144 4.37 / 3.83 with blocks 64 / 128; 8192 6.49 / 6.44 with 128 / 256)
+        if (ntot < BQ_SLAB_MAX)
+            return 64;
+        // a wider block halves the trailing update's C traffic per flop (60 instead of 56
+        // TFLOP/s at k = 512); it pays once the panel it lengthens hides behind the bulk
+        // update (N = 8192: 5.43 / 5.56 ms with 256 / 512, 12288: 13.55 / 13.11, 16384: 28.0 / 26.9)
+        return ntot < 12000 ? 256 : 512;
+    }
+    // (batches of mid-sized matrices, recursive panels: C5 shard 6.55 / 6.42 / 6.70 / 6.57 ms
+    // with 256 / 320 / 384 / 512; 256 x C2 5.72 / 5.47 / 5.64 ms with 256 / 320 / 448)
+    if (ntot >= 1024 && mb >= 100.0)
+        return 320;
+    if (ntot >= 512 && mb >= 30.0)
+        return 128;
+    return 64;
+}
+
+// Columns [j0, j0 + w) of a panel, recursively: the left half, ONE update of the right half's
+// columns with the whole left half, the right half.  Same flops as the left-looking slab
+// order (each 64-column slab updated with everything before it, n = 64 per launch), but two
+// thirds of a 256-wide panel's update flops are then ONE n = 128, k = 128 product -- wide
+// enough for the LDS-staged kernel -- instead of two n = 64 launches that re-stream the panel
+// (a batch's panel does not fit in L2: the n = 64 updates ran at 12 TFLOP/s; C5 shard
+// 6.8 -> see DESIGN).  A 64-column slab: its diagonal factor (unless the launch that last
+// updated it carried it: diag_done) and the solve of the rows below.
+static int enqueue_panel_rec(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot, int j0,
+                      int w, double *dinv, int *info, bool diag_done)
+{
+    if (w <= 64) {
+        double *Ajj = A + j0 + (long)j0 * lda;
+        if (!diag_done)
+            BQCHK(launch_potf2(c, A, lda, astride, j0, dinv, BQ_DINV_STRIDE, info, batch));
+        return launch_trsm_blk(c, Ajj + 64, lda, astride, ntot - j0 - 64, Ajj, lda, astride, dinv,
+                               BQ_DINV_STRIDE, batch);
+    }
+    const int wl = ((w / 64 + 1) / 2) * 64, wr = w - wl;
+    BQCHK(enqueue_panel_rec(c, A, lda, astride, batch, ntot, j0, wl, dinv, info, diag_done));
+    const int r0 = j0 + wl;
+    const double *P = A + r0 + (long)j0 * lda;
+    const int fj = gemm_uses_lds(c, ntot - r0, wr, wl, 1, batch) ? -1 : r0;
+    BQCHK(launch_gemm(c, BQ_K_GEMM, A + r0 + (long)r0 * lda, lda, astride, P, lda, astride, P, 1,
+                      lda, astride, ntot - r0, wr, wl, 1, batch, fj, dinv, BQ_DINV_STRIDE, info));
+    return enqueue_panel_rec(c, A, lda, astride, batch, ntot, r0, wr, dinv, info, fj >= 0);
+}
+
+// the 64-column slabs of one outer block [K0, K0+KB): left-looking update, diagonal
+// factor, panel solve -- enqueued on c->cur.  With fusion on, the diagonal factor of a
+// slab rides in the launch that last updates it (the slab update here, or the
+// trailing update of the previous block: `diag_done`).
+// With a scratch column pair `ws` (panel_ws_doubles) every step is ONE launch
+// (panel_step_kernel, slab.h): the workgroups solve the rows they need themselves.
+static int enqueue_panel(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot, int K0,
+                  int KB, double *dinv, int *info, bool diag_done, double *ws = nullptr)
+{
+    // (a batch fills the chip without this: the redundant solves then only cost throughput)
+    if (ws && batch <= 2) {
+        if (!diag_done)
+            BQCHK(launch_potf2(c, A, lda, astride, K0, dinv, BQ_DINV_STRIDE, info, batch));
+        if (ntot - K0 - 64 <= 0)
+            return BQ_OK;
+        const long sstride = 64L * ntot;
+        double *S[2] = {ws, ws + sstride * batch};
+        double *SL = ws + 2 * sstride * batch; // 64 x 64 per problem
+        const int ns = KB / 64;
+        for (int sidx = 0; sidx < ns; ++sidx) {
+            const int j0 = K0 + 64 * sidx;
+            const int nrb = (ntot - j0 - 64) / 64;
+            if (nrb <= 0)
+                break;
+            const int has_next = sidx + 1 < ns;
+            const double m = 64.0 * nrb;
+            const int par = sidx & 1;
+            BQCHK(launch_panel_step(
+                c, A, lda, astride, batch, nrb, S[par], S[par ^ 1], (long)ntot, sstride, K0, j0,
+                dinv + par * BQ_DINV_HALF, dinv + (par ^ 1) * BQ_DINV_HALF, has_next, sidx == 0, SL,
+                info,
+                (m * 64.0 * 64.0 + (has_next ? 2.0 * m * 64.0 * 64.0 * (sidx + 1) : 0.0)) * batch));
+        }
+        return BQ_OK;
+    }
+    return enqueue_panel_rec(c, A, lda, astride, batch, ntot, K0, KB, dinv, info, diag_done);
+}
+
+// Eliminate the first ncols columns (multiple of 64) of the ntot x ntot lower
+// matrix (ntot multiple of 64), batched.  dinv: BQ_DINV_STRIDE doubles per problem.
+//
+// With more than one outer block and a wide block the factorisation runs with a
+// look-ahead of one panel on two streams.  The main stream carries only the bulk
+// trailing updates (everything right of the next panel), back to back; the
+// high-priority aux stream updates the next panel's columns and factors that
+// panel meanwhile.  The two meet through events: update k+1 waits for panel k+1,
+// the panel-column update k+1 waits for trailing update k (which last wrote
+// those columns).
+// doubles of scratch the one-launch slab sweep needs (two panel columns per problem)
+size_t panel_ws_doubles(int ntot, int batch) { return ((size_t)2 * 64 * ntot + 4096) * batch; }
+
+// whether a sweep over `batch` matrices of size ntot can use that scratch at all (with the
+// block size in force now): callers that own long-lived workspaces skip the allocation else
+bool panel_ws_useful(const bq_ctx *c, int ntot, int batch)
+{
+    return batch <= 2 || auto_nb(c, ntot, batch) == 64;
+}
+
+// Outer block 64 (small systems): one launch per 64-column step (slab.h) after the first
+// diagonal factor and the staging of panel 0.
+// col0: global column of A's first column (a sweep over the trailing block of a larger
+// factorisation reports failures in the larger matrix's numbering)
+static int enqueue_slab_sweep(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
+                       int ncols, double *dinv, int *info, double *ws, int col0 = 0,
+                       bool first_done = false)
+{
+    if (ntot <= 64)
+        return launch_potf2(c, A - col0 - (long)col0 * lda, lda, astride, col0, dinv,
+                            BQ_DINV_STRIDE, info, batch);
+    const long sstride = 64L * ntot;
+    double *S[2] = {ws, ws + sstride * batch};
+    if (!first_done)
+        // the first diagonal factor and the staging of panel 0 share a launch (or ride in the
+        // assembly: assemble_first_kernel)
+        BQCHK(launch_slab_first(c, A, lda, astride, batch, S[0], (long)ntot, sstride, ntot, dinv,
+                                info, col0));
+    for (int j0 = 0, par = 0; j0 < ncols; j0 += 64, par ^= 1) {
+        const int r0 = j0 + 64;
+        if (r0 >= ntot)
+            break;
+        const int fnext = r0 < ncols;
+        const double m = (double)(ntot - r0);
+        // only batch element 0 is stamped, and only while the probe's buffer has room
+        long long *stamps = (c->stamp_buf && j0 / 64 < c->stamp_steps)
+                                ? c->stamp_buf + 160 * (j0 / 64)
+                                : nullptr;
+        // the tile updates (lower half of 2 m^2 64) and the solve of the panel (m 64^2)
+        BQCHK(launch_slab_step(c, A, lda, astride, batch, S[par], S[par ^ 1], (long)ntot, sstride,
+                               ntot, j0, dinv + par * BQ_DINV_HALF,
+                               dinv + (par ^ 1) * BQ_DINV_HALF, fnext, !fnext, info, col0, stamps,
+                               (m * m * 64.0 + m * 64.0 * 64.0) * batch));
+    }
+    return BQ_OK;
+}
+
+// nb_forced: the outer block of the whole batch when this call factors one half of it
+// whether a factorisation of these sizes goes to the one-launch slab sweep from its first column
+bool sweep_is_slab(const bq_ctx *c, int ntot, int ncols, int batch, size_t panel_ws_len)
+{
+    return auto_nb(c, ntot, batch) == 64 && panel_ws_len >= panel_ws_doubles(ntot, batch) &&
+           ncols >= 64 && ntot > 64;
+}
+
+// skip_border: the caller reads its results off the border ROWS (plan_readout_kernel), so the
+// trailing updates leave the border x border block alone
+static int enqueue_potrf_group(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
+                        int ncols, double *dinv, int *info, double *panel_ws, size_t panel_ws_len,
+                        int nb_forced, bool first_done = false, bool skip_border = false)
+{
+    const int NB = nb_forced > 0 ? nb_forced : auto_nb(c, ntot, batch);
+    double *ws = (panel_ws && panel_ws_len >= panel_ws_doubles(ntot, batch)) ? panel_ws : nullptr;
+    if (NB == 64 && ws && ncols >= 64)
+        return enqueue_slab_sweep(c, A, lda, astride, batch, ntot, ncols, dinv, info, ws, 0,
+                                  first_done);
+    const bool la = c->lookahead && c->aux && NB >= 128 && ncols > NB;
+    int K0 = 0;
+    bool panel_done = false; // panel K0 was already factored by the look-ahead phase
+    int st = BQ_OK;
+    if (la && ntot - std::min(NB, ncols) >= c->la_min) {
+        // fork: the aux stream starts after everything already queued on the main stream
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+        // aux stream: panel 0
+        c->cur = c->aux;
+        st = enqueue_panel(c, A, lda, astride, batch, ntot, 0, std::min(NB, ncols), dinv, info,
+                           false, ws);
+        c->cur = c->stream;
+        if (st != BQ_OK)
+            return st;
+        HIPCHK(c, hipEventRecord(c->ev_panel, c->aux));
+        bool have_b = false; // a trailing update is in flight on the main stream
+        for (; K0 < ncols && st == BQ_OK; K0 += NB) {
+            const int KB = std::min(NB, ncols - K0);
+            const int r0 = K0 + KB;
+            // main stream: wait for panel K0
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_panel, 0));
+            panel_done = true;
+            if (r0 >= ntot) {
+                K0 = ncols;
+                break;
+            }
+            // Once the bulk update is shorter than the panel chain it has to hide, the two
+            // streams only slow each other down (N = 4096: 2.50 ms with, 2.26 ms without):
+            // the rest of the sweep runs sequentially on the main stream.
+            if (ntot - r0 < c->la_min)
+                break;
+            const double *P = A + r0 + (long)K0 * lda;
+            const int nw = (r0 < ncols) ? std::min(NB, ncols - r0) : 0; // width of the next panel
+            if (nw > 0) {
+                // aux stream: bring the next panel's columns up to date (they were last
+                // written by the previous trailing update on the main stream), factor it
+                if (have_b)
+                    HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_next, 0));
+                c->cur = c->aux;
+                // (a wide panel's update is worth the LDS-staged kernel, which carries no
+                // fused diagonal factor: enqueue_panel then factors the block itself)
+                const int fj =
+                    !gemm_uses_lds(c, ntot - r0, nw, KB, 1, batch) ? r0 : -1;
+                st = launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda,
+                                 astride, P, 1, lda, astride, ntot - r0, nw, KB, 1, batch, fj, dinv,
+                                 BQ_DINV_STRIDE, info);
+                if (st == BQ_OK)
+                    st = enqueue_panel(c, A, lda, astride, batch, ntot, r0, nw, dinv, info,
+                                       fj >= 0, ws);
+                c->cur = c->stream;
+                if (st != BQ_OK)
+                    break;
+                HIPCHK(c, hipEventRecord(c->ev_panel, c->aux));
+                // main stream: everything right of the next panel, concurrently
+                const int r1 = r0 + nw;
+                if (r1 < ntot) {
+                    const double *P1 = A + r1 + (long)K0 * lda;
+                    st = launch_gemm(c, BQ_K_SYRK, A + r1 + (long)r1 * lda, lda, astride, P1, lda,
+                                     astride, P1, 1, lda, astride, ntot - r1, ntot - r1, KB, 1,
+                                     batch, -1, nullptr, 0, nullptr,
+                                     skip_border ? ncols - r1 : 0);
+                    HIPCHK(c, hipEventRecord(c->ev_next, c->stream));
+                    have_b = true;
+                }
+            } else {
+                // no further panel: the remaining trailing block is pure Schur complement
+                st = launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda,
+                                 astride, P, 1, lda, astride, ntot - r0, ntot - r0, KB, 1, batch);
+            }
+            panel_done = false;
+        }
+        c->cur = c->stream;
+        if (st != BQ_OK)
+            return st;
+    }
+    // sequential sweep: everything without look-ahead, otherwise the rest
+    bool diag_done = false;
+    for (; K0 < ncols; K0 += NB) {
+        const int KB = std::min(NB, ncols - K0);
+        if (!panel_done)
+            BQCHK(enqueue_panel(c, A, lda, astride, batch, ntot, K0, KB, dinv, info, diag_done,
+                                ws));
+        panel_done = false;
+        const int r0 = K0 + KB;
+        diag_done = false;
+        // The last rows of a large matrix are a small factorisation of their own -- the
+        // Schur complement once this block's update is in --, and for one or two matrices
+        // the one-launch steps are its shortest chain: hand the rest to the slab sweep.
+        const bool to_slab = batch <= 2 && ws && NB > 64 && r0 < ncols && ntot - r0 < BQ_SLAB_MAX;
+        if (r0 < ntot) {
+            const double *P = A + r0 + (long)K0 * lda;
+            // the trailing update also factors the next diagonal block if there is one
+            const int fj = (r0 < ncols && !to_slab &&
+                            !gemm_uses_lds(c, ntot - r0, ntot - r0, KB, 1, batch))
+                               ? r0
+                               : -1;
+            BQCHK(launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda, astride,
+                              P, 1, lda, astride, ntot - r0, ntot - r0, KB, 1, batch, fj, dinv,
+                              BQ_DINV_STRIDE, info, skip_border ? ncols - r0 : 0));
+            diag_done = fj >= 0;
+        }
+        if (to_slab)
+            return enqueue_slab_sweep(c, A + r0 + (long)r0 * lda, lda, astride, batch, ntot - r0,
+                                      ncols - r0, dinv, info, ws, r0);
+    }
+    return BQ_OK;
+}
+
+// Eliminate the first ncols columns of `batch` matrices.  A batch of mid-sized matrices
+// (config C5: 64 x N = 2048) sweeps in lock-step: every 64-column panel step is two short
+// dependent launches that leave most of the chip idle, and a third of the sweep's time is
+// such panel work.  The batch is therefore cut in two halves on the two streams: one half's
+// panel chain runs beside the other half's MFMA trailing update (C5 shard: 7.21 -> 6.78 ms;
+// three or four groups on more streams were slower, 7.8 / 7.5 ms).  (Large single matrices
+// use the second stream for the look-ahead instead, small ones the one-launch steps.)
+int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
+                          int ncols, double *dinv, int *info, double *panel_ws,
+                          size_t panel_ws_len, bool first_done, bool skip_border)
+{
+    if ((ntot & 63) || (ncols & 63) || ncols > ntot)
+        return fail(c, BQ_ERR_BAD_ARG, "potrf: sizes must be multiples of 64");
+    const int NB = auto_nb(c, ntot, batch);
+    const bool la = c->lookahead && c->aux && NB >= 128 && ncols > NB &&
+                    ntot - std::min(NB, ncols) >= c->la_min;
+    if (c->split_batch && c->lookahead && c->aux && c->cur == c->stream && batch >= 8 &&
+        NB >= 128 && !la) {
+        const int b0 = batch / 2, b1 = batch - b0;
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+        c->cur = c->aux;
+        int st = enqueue_potrf_group(c, A + (long)b0 * astride, lda, astride, b1, ntot, ncols,
+                                     dinv + (long)b0 * BQ_DINV_STRIDE, info + b0, nullptr, 0, NB,
+                                     false, skip_border);
+        c->cur = c->stream;
+        if (st != BQ_OK)
+            return st;
+        HIPCHK(c, hipEventRecord(c->ev_panel, c->aux));
+        BQCHK(enqueue_potrf_group(c, A, lda, astride, b0, ntot, ncols, dinv, info, nullptr, 0, NB,
+                                  false, skip_border));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_panel, 0));
+        return BQ_OK;
+    }
+    return enqueue_potrf_group(c, A, lda, astride, batch, ntot, ncols, dinv, info, panel_ws,
+                               panel_ws_len, 0, first_done, skip_border);
+}
+
+} // namespace bqh

@@ -1,8 +1,8 @@
 // probe.h -- hardware probes (MFMA / FMA rate, HBM bandwidth, MFMA layout, rsq accuracy)
-// Part of the libbqhip.so kernel set; included through kernels.h.
+// Part of the libbqhip.so kernel set; compiled into probe.hip (host.h lists the units).
 #pragma once
 #include "common.h"
-#include "gemm.h" // row_ror_quads
+#include "potf2.h"
 
 // ---------------------------------------------------------------------------
 // hardware probes
@@ -206,4 +206,29 @@ __global__ void probe_layout_kernel(double *out)
     c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c, 0, 0, 0);
     for (int r = 0; r < 4; ++r)
         out[l * 4 + r] = c[r];
+}
+
+// timing probe: the factor alone on a block that is restored from Ain every launch;
+// stamps[0..4] of the last launch = s_memtime at entry / loaded / chain done / blocks in LDS / end
+__global__ __launch_bounds__(256) void potf2_probe_kernel(const double *__restrict__ Ain,
+                                                          double *__restrict__ A, long lda,
+                                                          double *__restrict__ dinv,
+                                                          int *__restrict__ info,
+                                                          long long *stamps, int from_lds)
+{
+    __shared__ __attribute__((aligned(16))) double lds[BQ_POTF2_LDS_DOUBLES];
+    __builtin_amdgcn_s_setprio(3);
+    if (from_lds) {
+        // as the slab step hands the block over: through LDS
+        double *Ts = lds; // where the panel slots will be
+        for (int e = threadIdx.x; e < 4096; e += 256)
+            Ts[e] = Ain[(e & 63) + (long)(e >> 6) * lda];
+        __syncthreads();
+        potf2_body(A, lda, 0, dinv, info, lds, Ts, 64, stamps);
+    } else {
+        for (int e = threadIdx.x; e < 4096; e += 256)
+            A[(e & 63) + (long)(e >> 6) * lda] = Ain[(e & 63) + (long)(e >> 6) * lda];
+        __syncthreads();
+        potf2_body(A, lda, 0, dinv, info, lds, nullptr, 0, stamps);
+    }
 }

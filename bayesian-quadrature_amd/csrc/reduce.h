@@ -1,5 +1,5 @@
 // reduce.h -- read-out, reductions, fused prediction, small utility kernels
-// Part of the libbqhip.so kernel set; included through kernels.h.
+// Part of the libbqhip.so kernel set; compiled into k_reduce.hip (host.h lists the units).
 #pragma once
 #include "common.h"
 

@@ -1,8 +1,7 @@
 // slab.h -- one launch per 64-column step of a small factorisation (outer block 64)
-// Part of the libbqhip.so kernel set; included through kernels.h.
+// Part of the libbqhip.so kernel set; compiled into k_panel.hip (host.h lists the units).
 #pragma once
 #include "common.h"
-#include "gemm.h"
 #include "potf2.h"
 
 // ---------------------------------------------------------------------------
@@ -93,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void slab_step_kernel(double *__restrict__ 
     if (STAMP) {                                                                                   \
         asm volatile("" ::"v"(dep));                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (blockIdx.x == 0 && threadIdx.x == 0)                                                   \
+        if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0)                                \
             stamps[k] = (long long)__builtin_amdgcn_s_memtime();                                   \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
@@ -273,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void slab_step_kernel(double *__restrict__ 
         __syncthreads();
         // (col0: the global column of this sweep's first column, for the failure report)
         potf2_body(A + r0 + (long)r0 * lda, lda, col0 + r0, dout, info + b, plds, Ts, 64,
-                   STAMP ? stamps + 5 : nullptr);
+                   (STAMP && blockIdx.z == 0) ? stamps + 5 : nullptr);
         return;
     }
     const bool to_s = by == 0 && bx > 0 && !last;

@@ -1,7 +1,8 @@
 // trsm.h -- the MFMA panel solve from 16 x 16 block inverses, and those inverses for a resident factor
-// Part of the libbqhip.so kernel set; included through kernels.h.
+// Part of the libbqhip.so kernel set; compiled into k_panel.hip (host.h lists the units).
 #pragma once
 #include "common.h"
+#include "potf2.h"
 
 // ---------------------------------------------------------------------------
 // Panel solve on the matrix cores: X (m x 64) <- X L11^-T in four 16-column block steps,
@@ -133,3 +134,15 @@ __global__ __launch_bounds__(256) void diag_winv_kernel(const double *__restrict
 // required, out-of-range wave tiles exit, but m and n must be multiples of 16
 // and k a multiple of 8.
 // ---------------------------------------------------------------------------
+
+// the 64 x 64 diagonal factor as a launch of its own (potf2.h has the body)
+__global__ __launch_bounds__(256) void potf2_kernel(double *__restrict__ A, long lda, long astride,
+                                                    int j0, double *__restrict__ dinv,
+                                                    long dstride, int *__restrict__ info)
+{
+    __shared__ __attribute__((aligned(16))) double lds[BQ_POTF2_LDS_DOUBLES];
+    __builtin_amdgcn_s_setprio(3);
+    const int b = blockIdx.z;
+    potf2_body(A + (long)b * astride + j0 + (long)j0 * lda, lda, j0, dinv + (long)b * dstride,
+               info + b, lds);
+}

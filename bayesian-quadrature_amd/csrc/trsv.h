@@ -1,6 +1,6 @@
 // trsv.h -- sweeps over a resident factor for ONE right-hand side (cho_solve_vec, alpha, the
 // quadratic form of Z_var): GEMV kernels that stream the factor once at HBM rate.
-// Part of the libbqhip.so kernel set; included through kernels.h.
+// Part of the libbqhip.so kernel set; compiled into k_reduce.hip (host.h lists the units).
 //
 // The row form of the MFMA sweeps pads one right-hand side to 64 rows and runs two GEMMs per
 // B columns whose long-k product has too few tiles to fill the chip (0.95 ms at N = 4096 for

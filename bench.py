@@ -215,7 +215,7 @@ def make_workload(name, batch, rank):
 
 
 def auto_nb(ntot, override, batch=1):
-    """Mirror of auto_nb() in csrc/bqhip.hip (outer Cholesky block)."""
+    """Mirror of auto_nb() in csrc/potrf.hip (outer Cholesky block)."""
     if override:
         return override
     mb = 8.0 * ntot * ntot * batch / 1e6

@@ -20,7 +20,7 @@ def relmax(a, b, scale=None):
 
 # ---- hardware facts the kernels rely on ----------------------------------------
 def test_mfma_f64_layout(engine):
-    """D register r of lane l holds D[(l>>4) + 4r][l&15] (kernels.h gemm_sub_kernel)."""
+    """D register r of lane l holds D[(l>>4) + 4r][l&15] (gemm.h gemm_sub_kernel)."""
     lay = engine.probe_mfma_layout()
     for l in range(64):
         for r in range(4):
