@@ -191,7 +191,7 @@ class BQ(object):
             return out
         xa = np.ascontiguousarray(x_a[idx])
         eng = get_engine()
-        if hasattr(eng, "esm_border") and float(self.gp_l.s) == 0.0:
+        if float(self.gp_l.s) == 0.0:
             # bordered update of gp_l's resident factor: one multi-right-hand-side solve for
             # all candidates instead of a factorisation each
             A_a, A_sc_l, status = eng.esm_border(

@@ -17,6 +17,7 @@ static int fit_factor(bq_ctx *c, bq_fit *f, double *pm = nullptr, double *pv = n
     int *info = f->misc.i();
     double *scal = f->misc.d() + 2;
     f->valid = false;
+    f->stale = false;
     f->have_alpha = false;
     f->have_wide = false;
     f->have_dw = false;
@@ -65,6 +66,9 @@ int check_fit(bq_ctx *c, const bq_fit *f)
         return BQ_ERR_BAD_ARG;
     if (!f)
         return fail(c, BQ_ERR_BAD_ARG, "null fit handle");
+    if (f->stale)
+        return fail(c, BQ_ERR_BAD_ARG,
+                    "fit has new targets (bq_gp_set_y): refit required before its next use");
     if (!f->valid)
         return fail(c, BQ_ERR_NOT_PD,
                     "fit holds no valid factor: its last (re)fit was not positive definite");
@@ -214,7 +218,8 @@ extern "C" int bq_gp_refit(bq_ctx *c, bq_fit *f, double h, const double *w, doub
 // New targets for the same points: the hyper-parameter loop hands GP2 new targets l_sc =
 // [l_s, exp(mean of GP1 at the candidates)] on every evaluation (bq.py:948-954) -- a new fit
 // object per evaluation costs 0.10 ms at the reference's sizes and 0.57 ms at N = 1034, a
-// refit 0.05 / 0.32.  The fit is invalid until its next bq_gp_refit / bq_gp_refit_predict.
+// refit 0.05 / 0.32.  Until its next bq_gp_refit / bq_gp_refit_predict every consumer of the
+// fit returns BQ_ERR_BAD_ARG ("refit required") -- not BQ_ERR_NOT_PD: nothing failed.
 extern "C" int bq_gp_set_y(bq_ctx *c, bq_fit *f, const double *y)
 {
     if (!c)
@@ -224,7 +229,7 @@ extern "C" int bq_gp_set_y(bq_ctx *c, bq_fit *f, const double *y)
     if (!y)
         return fail(c, BQ_ERR_BAD_ARG, "illegal value");
     HIPCHK(c, hipSetDevice(c->device));
-    f->valid = false;
+    f->stale = true; // the factor is intact, z / alpha / log-ML belong to the old targets
     f->have_alpha = false;
     HIPCHK(c, hipMemcpyAsync(f->y.p, y, sizeof(double) * f->n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream)); // y is the caller's buffer

@@ -610,6 +610,10 @@ extern "C" int bq_esm_batch(bq_ctx *c, const double *x_sc, const double *l_sc, i
 // complement is not positive (bq.py:481-490's fallback).  Requires a noise-free gp_l (Kxoxo
 // carries no s^2 term, bq.py:465): BQ_ERR_BAD_ARG else, and the caller uses bq_esm_batch.
 // ===========================================================================
+// largest host tail / number of distinct jittered sets bq_esm_border takes on itself
+#define BQ_ESM_MAX_TAIL 320
+#define BQ_ESM_MAX_GROUPS 64
+
 extern "C" int bq_esm_border(bq_ctx *c, bq_fit *gp_l, int64_t ns, const double *x_a, int64_t M,
                              double thresh, const double *mu, const double *cov, double *A_a,
                              double *A_sc_l, int32_t *status)
@@ -630,6 +634,34 @@ extern "C" int bq_esm_border(bq_ctx *c, bq_fit *gp_l, int64_t ns, const double *
     const int nt = (int)nsc - p;         // trailing block handled on the host
     const double h = gp_l->h, wv[1] = {gp_l->w[0]};
     GaussParams g = make_params(1, h, wv, 0.0);
+    // The trailing block lives on the host: an nt^3 / 3 Cholesky per DISTINCT set of jittered
+    // candidates and O(nt^2) per candidate, single-threaded.  With many candidates (nt grows
+    // with n_candidate) or many distinct sets that tail would dominate: then all candidates go
+    // through the batched refactorisation on the device instead (bq_esm_batch).
+    std::vector<double> xsc((size_t)nsc);
+    HIPCHK(c, hipMemcpyAsync(xsc.data(), gp_l->pts.p, sizeof(double) * nsc, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+        std::vector<std::vector<int>> sets;
+        std::vector<int> cl;
+        for (int64_t a = 0; a < M && sets.size() <= BQ_ESM_MAX_GROUPS; ++a) {
+            cl.clear();
+            for (int i = 0; i < nc; ++i)
+                if (std::fabs(xsc[(size_t)(ns + i)] - x_a[a]) < thresh)
+                    cl.push_back(i);
+            if (std::find(sets.begin(), sets.end(), cl) == sets.end())
+                sets.push_back(cl);
+        }
+        if (nt > BQ_ESM_MAX_TAIL || sets.size() > BQ_ESM_MAX_GROUPS) {
+            std::vector<double> lsc((size_t)nsc);
+            HIPCHK(c, hipMemcpyAsync(lsc.data(), gp_l->y.p, sizeof(double) * nsc,
+                                     hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            return bq_esm_batch(c, xsc.data(), lsc.data(), ns, nsc, x_a, M, h, wv[0], thresh, mu,
+                                cov, A_a, A_sc_l, status);
+        }
+    }
     // rows: [b_sc; l_sc; padding to 64] then the M borders
     const int T = 64, rb = 0, rl = 1;
     const int mrows = (int)roundup(T + M, 64);
@@ -674,15 +706,14 @@ extern "C" int bq_esm_border(bq_ctx *c, bq_fit *gp_l, int64_t ns, const double *
                           T, p, 0, 1));
         BQCHK(launch_rowdot(c, F.d(), (long)mrows, mrows, mrows, p, nullptr, 0.0, nullptr, sq.d()));
     }
-    std::vector<double> hG((size_t)mrows * T), hsq((size_t)mrows), hb((size_t)M), xsc((size_t)nsc),
+    // (of G only columns rb and rl -- the products with the b and l rows -- are read)
+    std::vector<double> hG((size_t)mrows * 2), hsq((size_t)mrows), hb((size_t)M),
         F2((size_t)mrows * nt), L22((size_t)nt * nt);
     HIPCHK(c, hipMemcpyAsync(hG.data(), G.p, sizeof(double) * hG.size(), hipMemcpyDeviceToHost,
                              c->stream));
     HIPCHK(c, hipMemcpyAsync(hsq.data(), sq.p, sizeof(double) * mrows, hipMemcpyDeviceToHost,
                              c->stream));
     HIPCHK(c, hipMemcpyAsync(hb.data(), ika.p, sizeof(double) * M, hipMemcpyDeviceToHost,
-                             c->stream));
-    HIPCHK(c, hipMemcpyAsync(xsc.data(), gp_l->pts.p, sizeof(double) * nsc, hipMemcpyDeviceToHost,
                              c->stream));
     // F2[r + mrows j] = F[r, p + j]; L22[i + nt j] = L[p + i, p + j]
     HIPCHK(c, hipMemcpyAsync(F2.data(), F.d() + (size_t)p * mrows, sizeof(double) * F2.size(),

@@ -193,6 +193,28 @@ __global__ __launch_bounds__(256) void probe_copy_kernel(double2_t *dst, const d
         dst[i] = src[i];
 }
 
+// Known-bytes calibration of the FETCH_SIZE counter for the access pattern of the single-vector
+// sweeps (trsv.h): every lane loads 8 bytes, a wave 512 contiguous bytes, each byte of `src`
+// exactly once per launch -- `n` doubles, nothing else is read.
+__global__ __launch_bounds__(1024) void probe_read8_kernel(const double *__restrict__ src,
+                                                           size_t n, double *out)
+{
+    size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 1024;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        a0 += src[i];
+        a1 += src[i + stride];
+        a2 += src[i + 2 * stride];
+        a3 += src[i + 3 * stride];
+    }
+    for (; i < n; i += stride)
+        a0 += src[i];
+    const double s = (a0 + a1) + (a2 + a3);
+    if (s == 123.456)
+        out[0] = s;
+}
+
 // D = A B with A[i][k] = i (row tag), B[k][j] = [k==0] * 1 ... we want each D
 // element to carry row*16+col: use A[i][k] = (k==0) ? i*16 : (k==1 ? 1 : 0),
 // B[k][j] = (k==0) ? 1 : (k==1 ? j : 0)  ->  D[i][j] = 16 i + j.

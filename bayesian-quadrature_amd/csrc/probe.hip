@@ -79,6 +79,33 @@ extern "C" int bq_probe_hbm(bq_ctx *c, size_t bytes, double *write_gbs, double *
     return BQ_OK;
 }
 
+// `reps` launches of probe_read8_kernel over a `bytes`-sized buffer: a known byte count in the
+// single-vector sweeps' access pattern (8 B per lane, 512 contiguous bytes per wave), for the
+// calibration of rocprofv3's FETCH_SIZE on that pattern (tools/r03_profiles.sh)
+extern "C" int bq_probe_hbm_read8(bq_ctx *c, size_t bytes, int64_t reps, double *read_gbs)
+{
+    if (!c || bytes < 4096 || reps < 1)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf a, o;
+    HIPCHK(c, a.alloc(bytes));
+    HIPCHK(c, o.alloc(64));
+    HIPCHK(c, hipMemsetAsync(a.p, 0, bytes, c->stream));
+    const size_t n = bytes / 8;
+    float ms = 0;
+    hipLaunchKernelGGL(probe_read8_kernel, dim3(c->cus * 2), dim3(1024), 0, c->stream, a.d(), n,
+                       o.d());
+    BQCHK(bq_timer_start(c));
+    for (int64_t i = 0; i < reps; ++i)
+        hipLaunchKernelGGL(probe_read8_kernel, dim3(c->cus * 2), dim3(1024), 0, c->stream, a.d(),
+                           n, o.d());
+    BQCHK(bq_timer_stop_ms(c, &ms));
+    HIPCHK(c, hipGetLastError());
+    if (read_gbs)
+        *read_gbs = (double)reps * bytes / (ms * 1e-3) / 1e9;
+    return BQ_OK;
+}
+
 // kind 0: v_mfma_f64_16x16x4_f64, 1: v_mfma_f64_4x4x4_4b_f64; nacc in {1,2,4,8};
 // blocks_per_cu 256-thread blocks per CU (= waves per SIMD)
 extern "C" int bq_probe_mfma_variant(bq_ctx *c, int kind, int nacc, int blocks_per_cu,

@@ -385,6 +385,14 @@ class Engine(object):
                                            C.cast(C.byref(b), _dp)))
         return float(a.value), float(b.value)
 
+    def probe_hbm_read8(self, nbytes=1 << 30, reps=4):
+        """GB/s of a read-only pass with the single-vector sweeps' access pattern (8 B per
+        lane); under ``rocprofv3 --pmc FETCH_SIZE`` a known byte count for that counter."""
+        v = C.c_double()
+        self._check(self._lib.bq_probe_hbm_read8(self._ctx, int(nbytes), int(reps),
+                                                 C.cast(C.byref(v), _dp)))
+        return float(v.value)
+
     def probe_launch(self, n=2000):
         v = C.c_double()
         self._check(self._lib.bq_probe_launch(self._ctx, int(n), C.cast(C.byref(v), _dp)))

@@ -153,7 +153,7 @@ class GP(object):
             # evaluation, bq.py:948-954): the device fit stays and is re-factored on next use
             try:
                 fit.set_y(val)
-            except Exception:
+            except (ValueError, RuntimeError, MemoryError):  # the engine's error types
                 self._invalidate()
             else:
                 self._invalidate(data_changed=False)

@@ -52,7 +52,9 @@ TRAILING_KERNEL = "gemm_lds_kernel"
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary
     (profiles/*_pmc_traffic.json, made by tools/pmc_summary.py from separate
-    `rocprofv3 --pmc` passes); None when there is none."""
+    `rocprofv3 --pmc` passes); None when there is none.  WRITE_SIZE + FETCH_SIZE with the
+    guide's gfx950 correction where it applies (16-B-per-lane reads tally at half): the
+    corrected figure is an ESTIMATE and the raw counters stay beside it in the summary."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
@@ -63,35 +65,42 @@ def pmc_traffic(kernel):
     k = ks.get(kernel + " [C2 passes]") or ks.get(kernel)
     if not k:
         return None, None
-    # FETCH_SIZE_corrected_bytes_avg: the guide's x2 for 16-B-per-lane reads applied to the
-    # share of the fetch that is read that way (tools/pmc_summary.py); raw where no share is known
-    fetch = k.get("FETCH_SIZE_corrected_bytes_avg", k.get("FETCH_SIZE_bytes_avg", 0.0))
+    fetch = k.get("FETCH_SIZE_estimate_bytes_avg",
+                  k.get("FETCH_SIZE_corrected_bytes_avg", k.get("FETCH_SIZE_bytes_avg", 0.0)))
     return (fetch + k.get("WRITE_SIZE_bytes_avg", 0.0),
             "profiles/%s (separate rocprofv3 --pmc passes, not this run)"
             % os.path.basename(files[-1]))
 
 
 def _trsv_traffic():
-    """HBM bytes of one N=16384 single-vector solve from the committed PMC summary: the
-    totals of the trsv step kernels over tools/roofline_run.py's 4 solves, per solve (the
-    loads are 8 B per lane: FETCH_SIZE kept raw)."""
+    """HBM bytes of one N=16384 single-vector solve from the committed PMC summary: the RAW
+    FETCH_SIZE + WRITE_SIZE totals of the trsv step kernels over the pass's 4 solves, per solve
+    (`bytes_per_solve_raw`), and beside it the estimate with the factor MEASURED on a known-bytes
+    read of the same access pattern (8 B per lane: the counter is uncalibrated for it)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
         return None
     with open(files[-1]) as f:
-        ks = json.load(f)["kernels"]
-    tot, solves = 0.0, None
+        doc = json.load(f)
+    ks = doc["kernels"]
+    raw, est, solves = 0.0, 0.0, None
     for name in ("trsv_fwd_step_kernel<8>", "trsv_bwd_step_kernel"):
         k = ks.get(name)
         if not k:
             return None
-        tot += (k.get("FETCH_SIZE_corrected_bytes_total", k.get("FETCH_SIZE_bytes_total", 0.0))
+        raw += k.get("FETCH_SIZE_bytes_total", 0.0) + k.get("WRITE_SIZE_bytes_total", 0.0)
+        est += (k.get("FETCH_SIZE_estimate_bytes_total",
+                      k.get("FETCH_SIZE_corrected_bytes_total", k.get("FETCH_SIZE_bytes_total", 0.0)))
                 + k.get("WRITE_SIZE_bytes_total", 0.0))
         solves = k["launches"] / 32.0
-    return {"bytes_per_solve": tot / solves, "from": "profiles/%s (separate rocprofv3 --pmc "
-            "passes, not this run; FETCH_SIZE x 2: it tallies these coalesced 512-byte wave "
-            "loads at half)" % os.path.basename(files[-1])}
+    cal = doc.get("read8_calibration")
+    return {"bytes_per_solve_raw": raw / solves, "bytes_per_solve_estimate": est / solves,
+            "calibration": cal,
+            "from": "profiles/%s (separate rocprofv3 --pmc passes, not this run); the estimate "
+                    "scales the raw FETCH_SIZE by the factor measured on probe_read8_kernel, a "
+                    "known 1 GiB read with the same 8-B-per-lane pattern"
+                    % os.path.basename(files[-1])}
 
 
 def parse():
@@ -506,9 +515,10 @@ def solve_predict_rooflines(eng):
         b1 = rs.randn(n)
         dev, cls, wall = _prof_call(eng, lambda: fit.solve(b1), reps=10)
         byt = 8.0 * n * n
-        # the call is npad / 512 launches per sweep of 5-16 us each: its unprofiled wall time
-        # (host vector in and out included) is below the sum of the event brackets
-        t1 = min(dev, wall)
+        # the headline is the unprofiled wall time of the whole call (hipGraph replay, host
+        # vector in and out); the sum of the per-launch event brackets (eager launches, a
+        # different execution mode) is informational only
+        t1 = wall
         out["cho_solve_n%d_rhs1" % n] = {
             "bound": "hbm", "achieved": byt / (t1 * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
             "unit": "GB/s", "frac": byt / (t1 * 1e-3) / 1e9 / PEAK_HBM_GBS,
@@ -517,7 +527,9 @@ def solve_predict_rooflines(eng):
             "traffic": _trsv_traffic() if n == 16384 else None,
             "note": "bq_gp_solve on a resident factor, one right-hand side: the GEMV sweeps "
                     "of trsv.h, one launch per 512 columns (forward + backward), replayed "
-                    "from a hipGraph; ms = min(event brackets, wall time of the whole call)"}
+                    "from a hipGraph; ms = unprofiled wall time of the whole call (median of five "
+                    "groups); ms_event_brackets = eager launches under the launch profiler, "
+                    "informational"}
         B = np.asfortranarray(rs.randn(n, 256))
         dev, cls, wall = _prof_call(eng, lambda: fit.solve(B), reps=2)
         fl = 2.0 * n * n * 256

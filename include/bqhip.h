@@ -263,6 +263,10 @@ int bq_probe_mfma_f64(bq_ctx *ctx, double *tflops);
 int bq_probe_fma_f64(bq_ctx *ctx, double *tflops);
 /* streaming fp64 write / copy bandwidth in GB/s over `bytes` */
 int bq_probe_hbm(bq_ctx *ctx, size_t bytes, double *write_gbs, double *copy_gbs);
+/* `reps` read-only passes over `bytes` with 8-byte-per-lane loads, 512 contiguous bytes per
+ * wave (the access pattern of the single-vector sweeps): a known byte count for calibrating
+ * the profiler's FETCH_SIZE counter on that pattern; read_gbs may be NULL */
+int bq_probe_hbm_read8(bq_ctx *ctx, size_t bytes, int64_t reps, double *read_gbs);
 /* MFMA issue study: kind 0 = v_mfma_f64_16x16x4_f64, 1 = v_mfma_f64_4x4x4_4b_f64; nacc
  * independent accumulators per wave (1,2,4,8); blocks_per_cu = waves per SIMD */
 int bq_probe_mfma_variant(bq_ctx *ctx, int kind, int nacc, int blocks_per_cu, double *tflops);

@@ -131,6 +131,14 @@ class EngineDouble(object):
             A_sc_l[k] = A[:nsc].dot(l_sc)
         return A_a, A_sc_l, status
 
+    def esm_border(self, fit_l, ns, x_a, thresh, mu, cov):
+        """Same interface as the device engine's bordered update of gp_l's resident factor;
+        the double just applies the reference's recipe to the fit's own data."""
+        if fit_l.s != 0.0:
+            raise ValueError("esm_border: gp_l carries a noise term")
+        return self.esm_batch(fit_l.x, fit_l.y, ns, x_a, fit_l.h, float(fit_l.w[0]), thresh, mu,
+                              cov)
+
     def Z_mean(self, fit_l, mu, cov):
         return self.o.Z_mean(fit_l.x, fit_l._alpha, fit_l.h, fit_l.w, mu, cov)
 

@@ -187,8 +187,10 @@ def test_set_y_keeps_the_fit(engine, oracle, n):
     fit = engine.gp_fit(x, y, h, w, s)
     y2 = np.cos(x) + 0.1 * y
     fit.set_y(y2)
-    with pytest.raises(np.linalg.LinAlgError):
-        fit.alpha()
+    # "refit required" is a usage error (ValueError), not a failed factorisation
+    for use in (fit.alpha, lambda: fit.logml, lambda: fit.predict(x[:3]), lambda: fit.solve(y)):
+        with pytest.raises(ValueError, match="refit required"):
+            use()
     fit.refit(h, 1.05 * w, s)
     Lo, ao, lmo = oracle.gp_fit(x, y2, h, 1.05 * w, s)
     assert abs(fit.logml - lmo) <= 1e-10 * abs(lmo)
@@ -809,6 +811,31 @@ def test_esm_border_vs_refactorisation(engine, oracle, ns, nc, M):
         engine.esm_border(noisy, ns, x_a, thresh, MU1, COV1)
     noisy.close()
     fit.close()
+
+
+def test_esm_border_bounded_host_tail(engine, oracle):
+    """The trailing block of bq_esm_border lives on the host (one nt^3 / 3 Cholesky per distinct
+    set of jittered candidates).  Beyond nt = 320 rows or 64 distinct sets the call hands all
+    candidates to the batched device refactorisation instead: same answers either way."""
+    rs = np.random.RandomState(77)
+    for ns, nc, M, thresh in ((40, 340, 30, 0.02), (64, 200, 150, 0.06)):
+        xs = np.linspace(-5, 5, ns)
+        xc = np.sort(rs.uniform(-5.5, 5.5, nc))
+        x_sc = np.concatenate([xs, xc])
+        l_sc = np.exp(wl.norm_logpdf(x_sc))
+        x_a = np.sort(rs.uniform(-6, 6, M))
+        h, w = 0.2, 0.035
+        fit = engine.gp_fit(x_sc, l_sc, h, w, 0.0)
+        got = engine.esm_border(fit, ns, x_a, thresh, MU1, COV1)
+        chk = engine.esm_batch(x_sc, l_sc, ns, x_a, h, w, thresh, MU1, COV1)
+        if ns == 64:   # many candidates within the radius: more than 64 distinct close sets
+            sets = {tuple(np.nonzero(np.abs(xc - a) < thresh)[0]) for a in x_a}
+            assert len(sets) > 64
+        assert (got[2] == chk[2]).all()
+        ok = chk[2] == 0
+        assert ok.sum() > M // 2
+        assert np.array_equal(got[0][ok], chk[0][ok]) and np.array_equal(got[1][ok], chk[1][ok])
+        fit.close()
 
 
 def _ld_chol_solve(K, B):

@@ -1,78 +1,186 @@
-"""Summarises rocprofv3 passes of tools/roofline_run.py into profiles/:
-    python tools/pmc_summary.py gpurun_out/rf_trace gpurun_out/rf_pmc_write gpurun_out/rf_pmc_fetch r01
-writes profiles/<tag>_roofline_kernel_stats.csv (copy of the --stats summary) and
-profiles/<tag>_pmc_traffic.json (per-kernel average FETCH_SIZE / WRITE_SIZE in bytes).
-FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  Per MI355X_MICROARCH.md,
-WRITE_SIZE is exact for 16-B-per-lane streaming stores; FETCH_SIZE under-counts wide
-(16 B/lane) coalesced reads by 2x and is uncalibrated for other widths -- the GEMM
-reads 8 B/lane, so its fetch figure is kept raw and flagged."""
+"""Condenses the rocprofv3 runs of tools/r03_profiles.sh into the small tables that are
+committed under profiles/ (run on the GPU box; results come back through gpurun_out/):
+
+    python3 tools/pmc_summary.py gpurun_out/r03p r03 [outdir]
+
+Per pass P of tools/roofline_run.py (one rocprofv3 run each, never blended):
+    <tag>_<P>_kernel_stats.csv     copy of the --stats summary of `t_<P>`
+    <tag>_bench_kernel_stats.csv   the same for `python3 bench.py --steps 200`
+and
+    <tag>_trailing_dispatches.csv  one row per gemm_lds_kernel launch of the sequential
+                                   N=16384, tile-256 potrf: dispatch, grid, m, ns, flop --
+                                   sum(m^2 nb) / sum(ns) is the trailing-update roofline line
+    <tag>_pmc_traffic.json         WRITE_SIZE / FETCH_SIZE per kernel and pass, RAW, plus clearly
+                                   labelled estimates (see below)
+    <tag>_mfma_util.json           SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_VALU_MFMA_MOPS_F64 of
+                                   gemm_lds_kernel (potrf256 and c5 passes)
+
+Counters: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  Per MI355X_MICROARCH.md WRITE_SIZE
+is exact for 16-B-per-lane streaming stores; FETCH_SIZE tallies 16-B-per-lane coalesced reads
+at half and is UNCALIBRATED for other widths.  The raw counter is always reported.  Two
+estimates are added and labelled as such: (a) gemm_lds_kernel: C-tile share (8 B per lane,
+= WRITE_SIZE) kept, LDS-DMA share (16 B per lane) doubled -- the guide's rule; (b) the trsv step
+kernels (8 B per lane, 512 contiguous bytes per wave): raw x the factor MEASURED in the `calib`
+pass on probe_read8_kernel, which reads a known 1 GiB per launch with exactly that pattern."""
+import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
-import pandas as pd
+PASSES = ("c2", "gram", "potrf256", "potrf_engine", "trsv", "solve256", "predict", "c5", "c3",
+          "calib")
+PEAK = 78.6e12
+
+
+def short(name):
+    m = re.search(r"(\w+_kernel(?:<[^>]*>)?)", name)
+    return m.group(1) if m else name[:60]
+
+
+def find(d, pat):
+    f = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    return f[0] if f else None
+
+
+def counters(d):
+    """{kernel: {counter: [values per dispatch in dispatch order]}}"""
+    f = find(d, "*_counter_collection.csv")
+    out = {}
+    if not f:
+        return out
+    rows = list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    for r in rows:
+        out.setdefault(short(r["Kernel_Name"]), {}).setdefault(r["Counter_Name"], []).append(
+            float(r["Counter_Value"]))
+    return out
 
 
 def main():
-    trace, pw, pf, tag = sys.argv[1:5]
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    stats = glob.glob(os.path.join(trace, "**", "*_kernel_stats.csv"), recursive=True)[0]
-    shutil.copy(stats, os.path.join(root, "profiles", "%s_roofline_kernel_stats.csv" % tag))
-    st = pd.read_csv(stats)
-    out = {"_source": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate passes) of "
-                      "`python3 tools/roofline_run.py`; bytes = counter KiB x 1024; "
-                      "FETCH_SIZE_bytes_avg is RAW; FETCH_SIZE_corrected_bytes_avg applies the guide's x2 "
-                      "to the 16-B-per-lane share where that share is known",
-           "kernels": {}}
-    for path, name in ((pw, "WRITE_SIZE"), (pf, "FETCH_SIZE")):
-        f = glob.glob(os.path.join(path, "**", "*_counter_collection.csv"), recursive=True)[0]
-        t = pd.read_csv(f)
-        t = t[t.Counter_Name == name]
-        t["short"] = t.Kernel_Name.str.extract(r"(\w+_kernel(?:<[^>]*>)?)", expand=False)
-        for k, g in t.groupby("short"):
-            d = out["kernels"].setdefault(k, {})
-            d[name + "_bytes_avg"] = float(g.Counter_Value.mean() * 1024)
-            d[name + "_bytes_total"] = float(g.Counter_Value.sum() * 1024)
-            d["launches"] = int(len(g))
-    # the headline workload's launches alone: roofline_run.py runs its 20 C2 passes first (16
-    # slab steps each); later slab steps belong to the tails of the N=16384 factorisations
-    for path, name in ((pw, "WRITE_SIZE"), (pf, "FETCH_SIZE")):
-        f = glob.glob(os.path.join(path, "**", "*_counter_collection.csv"), recursive=True)[0]
-        t = pd.read_csv(f)
-        t = t[(t.Counter_Name == name) & t.Kernel_Name.str.contains("slab_step_kernel<false>",
-                                                                      regex=False)]
-        t = t.sort_values("Dispatch_Id").head(320)
-        d = out["kernels"].setdefault("slab_step_kernel<false> [C2 passes]", {})
-        d[name + "_bytes_avg"] = float(t.Counter_Value.mean() * 1024)
-        d["launches"] = int(len(t))
-    # the trsv step kernels read the factor with fully coalesced 512-byte wave loads (8 B per
-    # lane): FETCH_SIZE tallies them at half like the guide's wide reads -- 1.085 GB raw per
-    # N=16384 solve against 2.147 GB that the two sweeps must read; corrected = 2 x raw
-    for kn in ("trsv_fwd_step_kernel<8>", "trsv_bwd_step_kernel"):
-        g = out["kernels"].get(kn)
-        if g and "FETCH_SIZE_bytes_total" in g:
-            g["FETCH_SIZE_corrected_bytes_total"] = 2.0 * g["FETCH_SIZE_bytes_total"]
-            g["FETCH_SIZE_correction"] = "coalesced 512-B wave loads tallied at half: x2"
-    # gemm_lds_kernel reads its C tile with 8-B-per-lane loads -- every tile once, exactly
-    # what it writes -- and stages P / Q by LDS-DMA, 16 B per lane, which FETCH_SIZE tallies
-    # at half (MI355X_MICROARCH.md, HBM): corrected fetch = C share + 2 x the rest.
-    g = out["kernels"].get("gemm_lds_kernel")
-    if g and "FETCH_SIZE_bytes_avg" in g and "WRITE_SIZE_bytes_avg" in g:
-        cshare = min(g["WRITE_SIZE_bytes_avg"], g["FETCH_SIZE_bytes_avg"])
-        g["FETCH_SIZE_corrected_bytes_avg"] = cshare + 2.0 * (g["FETCH_SIZE_bytes_avg"] - cshare)
-        g["FETCH_SIZE_correction"] = ("C tile share (= WRITE_SIZE, 8 B/lane loads) kept, the "
-                                      "LDS-DMA share (16 B/lane) doubled")
-    st["short"] = st.Name.str.extract(r"(\w+_kernel(?:<[^>]*>)?)", expand=False)
-    for _, r in st.iterrows():
-        if r.short in out["kernels"]:
-            out["kernels"][r.short]["avg_ns"] = float(r.AverageNs)
-            out["kernels"][r.short]["calls_in_trace"] = int(r.Calls)
-    with open(os.path.join(root, "profiles", "%s_pmc_traffic.json" % tag), "w") as f:
+    O, tag = sys.argv[1], sys.argv[2]
+    outdir = sys.argv[3] if len(sys.argv) > 3 else os.path.join(O, "profiles")
+    os.makedirs(outdir, exist_ok=True)
+    # ---- kernel stats of every pass ------------------------------------------------
+    for p in ("bench",) + PASSES:
+        f = find(os.path.join(O, "bench" if p == "bench" else "t_" + p), "*_kernel_stats.csv")
+        if f:
+            shutil.copy(f, os.path.join(outdir, "%s_%s_kernel_stats.csv" % (tag, p)))
+    # ---- the trailing update, dispatch by dispatch -----------------------------------
+    tr = find(os.path.join(O, "t_potrf256"), "*_kernel_trace.csv")
+    summary = {}
+    if tr:
+        rows = [r for r in csv.DictReader(open(tr)) if "gemm_lds_kernel" in r["Kernel_Name"]]
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        nb = 256
+        table, tot = [], {"bulk": [0, 0.0, 0], "small": [0, 0.0, 0]}
+        for r in rows:
+            wgs = int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])
+            T = int(((8 * wgs + 1) ** 0.5 - 1) / 2 + 0.5)
+            assert T * (T + 1) // 2 == wgs, (wgs, T)
+            m = 128 * T
+            ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            fl = float(m) * m * nb
+            cls = "bulk" if wgs >= 256 else "small"     # launch_gemm's SYRK / SYRK_SMALL split
+            tot[cls][0] += 1
+            tot[cls][1] += fl
+            tot[cls][2] += ns
+            table.append((r["Dispatch_Id"], wgs, m, nb, ns, fl, cls))
+        with open(os.path.join(outdir, "%s_trailing_dispatches.csv" % tag), "w") as f:
+            f.write("# gemm_lds_kernel launches of ONE sequential N=16384 potrf, outer block 256 "
+                    "(python3 tools/roofline_run.py potrf256 under rocprofv3 --kernel-trace); "
+                    "flop = m^2 nb (the lower half of 2 m^2 nb)\n")
+            f.write("dispatch_id,workgroups,m,nb,duration_ns,algorithmic_flop,class\n")
+            for t in table:
+                f.write("%s,%d,%d,%d,%d,%.0f,%s\n" % t)
+            for cls in ("bulk", "small"):
+                n, fl, ns = tot[cls]
+                if n:
+                    f.write("# %s: %d launches, %.4e flop, %.3f ms -> %.2f TFLOP/s = %.3f of 78.6\n"
+                            % (cls, n, fl, ns / 1e6, fl / ns / 1e3, fl / ns * 1e9 / PEAK))
+        for cls in ("bulk", "small"):
+            n, fl, ns = tot[cls]
+            if n:
+                summary[cls] = {"launches": n, "flop": fl, "ms": ns / 1e6,
+                                "tflops": fl / ns / 1e3, "frac": fl / ns * 1e9 / PEAK,
+                                "avg_launch_us": ns / n / 1e3}
+    # ---- traffic ----------------------------------------------------------------------
+    out = {"_source": "tools/r03_profiles.sh: rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE, "
+                      "separate runs, one per pass of tools/roofline_run.py; bytes = KiB x 1024; "
+                      "*_bytes_* are RAW counters, *_estimate_* are labelled corrections "
+                      "(tools/pmc_summary.py docstring)",
+           "passes": {}, "kernels": {}, "trailing_update_from_trace": summary}
+    calib = None
+    for p in PASSES:
+        w, f = counters(os.path.join(O, "w_" + p)), counters(os.path.join(O, "f_" + p))
+        if not w and not f:
+            continue
+        d = out["passes"].setdefault(p, {})
+        for k in sorted(set(w) | set(f)):
+            e = d.setdefault(k, {})
+            for src, name in ((w, "WRITE_SIZE"), (f, "FETCH_SIZE")):
+                v = src.get(k, {}).get(name)
+                if v:
+                    e[name + "_bytes_avg"] = sum(v) / len(v) * 1024
+                    e[name + "_bytes_total"] = sum(v) * 1024
+                    e["launches"] = len(v)
+    pc = out["passes"].get("calib", {}).get("probe_read8_kernel")
+    if pc and pc.get("FETCH_SIZE_bytes_avg"):
+        known = float(1 << 30)
+        calib = known / pc["FETCH_SIZE_bytes_avg"]
+        out["read8_calibration"] = {
+            "known_bytes_per_launch": known, "FETCH_SIZE_raw_bytes_avg": pc["FETCH_SIZE_bytes_avg"],
+            "factor": calib,
+            "note": "probe_read8_kernel: 8 B per lane, 512 contiguous bytes per wave, every byte "
+                    "of a 1 GiB buffer once per launch"}
+    # flat view for bench.py: the pass that owns each roofline kernel
+    own = {"gemm_lds_kernel": "potrf256", "gram_tri_kernel<2>": "gram", "gram_tri_kernel<1>": "gram",
+           "trsv_fwd_step_kernel<8>": "trsv", "trsv_bwd_step_kernel": "trsv",
+           "slab_step_kernel<false>": "c2"}
+    for k, p in own.items():
+        e = out["passes"].get(p, {}).get(k)
+        if not e:
+            continue
+        e = dict(e, **{"pass": p})
+        if k == "gemm_lds_kernel" and "FETCH_SIZE_bytes_avg" in e and "WRITE_SIZE_bytes_avg" in e:
+            c = min(e["WRITE_SIZE_bytes_avg"], e["FETCH_SIZE_bytes_avg"])
+            e["FETCH_SIZE_estimate_bytes_avg"] = c + 2.0 * (e["FETCH_SIZE_bytes_avg"] - c)
+            e["FETCH_SIZE_estimate_rule"] = ("ESTIMATE: C tile share (= WRITE_SIZE, 8 B/lane "
+                                             "loads) kept, LDS-DMA share (16 B/lane) doubled")
+        if k.startswith("trsv") and calib and "FETCH_SIZE_bytes_total" in e:
+            e["FETCH_SIZE_estimate_bytes_total"] = calib * e["FETCH_SIZE_bytes_total"]
+            e["FETCH_SIZE_estimate_rule"] = ("ESTIMATE: raw x %.3f, the factor measured on "
+                                             "probe_read8_kernel (same access pattern, known bytes)"
+                                             % calib)
+        out["kernels"][k if p != "c2" else k + " [C2 passes]"] = e
+    with open(os.path.join(outdir, "%s_pmc_traffic.json" % tag), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
-    print(json.dumps(out["kernels"].get("gemm_lds_kernel"), indent=1))
-    print(json.dumps(out["kernels"].get("gram_tri_kernel<2>"), indent=1))
+    # ---- MFMA utilisation ----------------------------------------------------------------
+    mu = {"_source": "tools/r03_profiles.sh: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES "
+                     "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE (own runs, "
+                     "counters only); mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 "
+                     "XCDs x 256 CUs x 4 SIMDs)", "passes": {}}
+    for p in ("potrf256", "c5"):
+        m = counters(os.path.join(O, "m_" + p)).get("gemm_lds_kernel")
+        if not m:
+            continue
+        n = len(m["GRBM_GUI_ACTIVE"])
+        sel = range(n)
+        if p == "potrf256":   # the bulk launches only (>= 256 workgroups = the first ones)
+            nbulk = summary.get("bulk", {}).get("launches", n)
+            sel = range(min(n, nbulk))
+        s = {c: sum(v[i] for i in sel) for c, v in m.items()}
+        mu["passes"][p] = {
+            "kernel": "gemm_lds_kernel", "launches": len(sel), "sums": s,
+            "mfma_util": s["SQ_VALU_MFMA_BUSY_CYCLES"] / (s["GRBM_GUI_ACTIVE"] / 8 * 256 * 4),
+            "flop_from_MOPS": s["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0,
+            "algorithmic_flop": summary.get("bulk", {}).get("flop") if p == "potrf256" else None}
+    with open(os.path.join(outdir, "%s_mfma_util.json" % tag), "w") as f:
+        json.dump(mu, f, indent=1, sort_keys=True)
+    print(json.dumps({"trailing": summary, "read8": out.get("read8_calibration"),
+                      "mfma": {k: v["mfma_util"] for k, v in mu["passes"].items()}}, indent=1))
 
 
 if __name__ == "__main__":
