@@ -48,6 +48,7 @@ SIGNATURES = {
     "bq_profile_enable": (C.c_int, [_vp, C.c_int]),
     "bq_profile_reset": (C.c_int, [_vp]),
     "bq_profile_read": (C.c_int, [_vp, _dp, _i64p, _dp]),
+    "bq_profile_timeline": (C.c_int, [_vp, C.c_int, _dp, _i64, _i64p]),
     "bq_cho_factor": (C.c_int, [_vp, _dp, _dp, _i64, _i64p]),
     "bq_cho_solve": (C.c_int, [_vp, _dp, _dp, _dp, _i64, _i64]),
     "bq_logdet": (C.c_int, [_vp, _dp, _i64, _dp]),

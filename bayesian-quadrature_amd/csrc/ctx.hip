@@ -16,7 +16,16 @@ int prof_collect(bq_ctx *c)
             c->prof_ms[e.cls] += ms;
             c->prof_n[e.cls] += 1;
             c->prof_work[e.cls] += e.work;
+            if (c->prof_keep_timeline) {
+                float t0 = 0.f;
+                (void)hipEventElapsedTime(&t0, c->prof_events.front().a, e.a);
+                c->prof_timeline.insert(c->prof_timeline.end(),
+                                        {(double)e.cls, (double)e.on_aux, (double)t0,
+                                         (double)t0 + ms, e.work});
+            }
         }
+    }
+    for (auto &e : c->prof_events) { // (the first launch's start is the timeline's origin)
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
@@ -78,6 +87,7 @@ static int ctx_init(bq_ctx *c, int device)
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_next, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+
     int lo = 0, hi = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIPCHK(c, hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, hi));
@@ -312,6 +322,28 @@ extern "C" int bq_profile_reset(bq_ctx *c)
         c->prof_n[k] = 0;
         c->prof_work[k] = 0;
     }
+    return BQ_OK;
+}
+
+// The launches bracketed since the recording was armed, as a timeline: rows of {class, stream
+// (0 main, 1 second), start ms, end ms, algorithmic work}, times since the first launch's start.
+// keep = 1 and out = NULL arms (and clears) the recording; keep = 0 stops it: with out = NULL
+// that call only reports *nrows, with out it copies up to max_rows rows.
+extern "C" int bq_profile_timeline(bq_ctx *c, int keep, double *out, int64_t max_rows,
+                                   int64_t *nrows)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    BQCHK(prof_collect(c));
+    if (keep && !out)
+        c->prof_timeline.clear();
+    const int64_t n = (int64_t)c->prof_timeline.size() / 5;
+    if (nrows)
+        *nrows = n;
+    if (out && max_rows > 0)
+        std::memcpy(out, c->prof_timeline.data(),
+                    sizeof(double) * 5 * (size_t)std::min<int64_t>(n, max_rows));
+    c->prof_keep_timeline = keep != 0;
     return BQ_OK;
 }
 

@@ -72,6 +72,7 @@ struct ProfEvent {
     hipEvent_t a, b;
     int cls;
     double work;
+    int on_aux; // recorded on the context's second stream
 };
 
 struct bq_ctx {
@@ -96,6 +97,10 @@ struct bq_ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool prof = false;
     std::vector<ProfEvent> prof_events;
+    // bq_profile_timeline: (class, stream, start, end in ms since the first bracket) per launch
+    bool prof_keep_timeline = false;
+    hipEvent_t prof_origin = nullptr;
+    std::vector<double> prof_timeline;
     double prof_ms[BQ_K_NCLASS] = {0};
     int64_t prof_n[BQ_K_NCLASS] = {0};
     double prof_work[BQ_K_NCLASS] = {0};
@@ -184,6 +189,7 @@ struct Bracket {
         if (on) {
             ev.cls = cls;
             ev.work = work;
+            ev.on_aux = ctx->cur != ctx->stream;
             if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) {
                 on = false;
                 return;

@@ -1,0 +1,362 @@
+// pair.hip -- the stacked pair of GPs of Bayesian quadrature at S hyper-parameter sets in ONE
+// batched pass: GP1 over log l at the samples, GP2 over exp(log l) at samples + candidates.
+//
+// The reference evaluates the hyper-parameter objective (bq.py:536-550: refit GP1, re-predict the
+// candidates, hand GP2 its new targets, refit GP2, add the two log-MLs -- bq.py:933-965) and the
+// acquisition under sampled hyper-parameters (marginalize / choose_next, bq.py:604-662) one
+// parameter set after the other; on the device each of those is a chain of a few short dependent
+// launches.  The S sets are independent, and every kernel of the engine takes a batch in
+// blockIdx.z: here they run as
+//   stage 1  a bordered plan over S copies of GP1's system, the candidates (and the
+//            acquisition points x_a) as border points -> log-ML, mean / variance at x_c, x_a;
+//   targets  l_c = exp(mean) with the reference's overflow guard, GP2's targets [l_s, l_c];
+//   stage 2  bq_pair_llh: a plan over S copies of GP2's system -> log-ML;
+//            bq_pair_esm: the S x Ma bordered (nsc + 1)^2 systems of the acquisition
+//            (bq.py:447-527), the reference's own recipe with its jitter, one batch.
+#include "host.h"
+#include "pair.h"
+
+using namespace bqh;
+
+struct bq_pair {
+    int ns = 0, nc = 0, ma = 0, S = 0, nsc = 0;
+    bq_plan *p1 = nullptr; // GP1: n = ns, M = nc + ma
+    bq_plan *p2 = nullptr; // GP2: n = nsc, M = 0 (the objective; the acquisition has its own systems)
+    DevBuf l_s, x_sc, x_a, y2, flag;
+    std::vector<double> hx_s, hx_c, hx_a;
+};
+
+namespace {
+
+constexpr double LOG_2PI = 1.8378770664093453;
+
+// log of the largest double the reference lets exp() see: log(2^(maxexp - 4)) (bq.py:14-16)
+double max_log() { return std::log(std::exp2((double)(std::numeric_limits<double>::max_exponent - 4))); }
+
+int check_params(bq_ctx *c, const double *p, int64_t S, const char *what)
+{
+    for (int64_t b = 0; b < S; ++b) {
+        const double w[1] = {p[3 * b + 1]};
+        if (check_w(c, 1, p[3 * b], w, p[3 * b + 2]) != BQ_OK)
+            return fail(c, BQ_ERR_BAD_ARG, "%s: parameter set %d is invalid", what, (int)b);
+    }
+    return BQ_OK;
+}
+
+// stage 1 + targets: leaves mean / var of GP1 at [x_c, x_a] in p1->mean / p1->var, GP2's targets
+// in `y2` (stride ystride) and the overflow flags in pr->flag
+int run_stage1(bq_ctx *c, bq_pair *pr, const double *p_tl, double *y2, long ystride)
+{
+    const int S = pr->S;
+    std::vector<double> h((size_t)S), w((size_t)S), s((size_t)S);
+    for (int b = 0; b < S; ++b) {
+        h[(size_t)b] = p_tl[3 * b];
+        w[(size_t)b] = p_tl[3 * b + 1];
+        s[(size_t)b] = p_tl[3 * b + 2];
+    }
+    BQCHK(plan_set_params(c, pr->p1, h.data(), w.data(), s.data()));
+    BQCHK(bq_plan_run(c, pr->p1));
+    HIPCHK(c, hipMemsetAsync(pr->flag.p, 0, sizeof(int) * S, c->stream));
+    const long ms = std::max(pr->nc + pr->ma, 1);
+    hipLaunchKernelGGL(pair_targets_kernel, dim3((pr->nsc + 255) / 256, S), dim3(256), 0, c->stream,
+                       pr->l_s.d(), pr->ns, pr->nc, pr->p1->mean.d(), pr->p1->var.d(), ms,
+                       max_log(), y2, ystride, pr->flag.i());
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+} // namespace
+
+extern "C" int bq_pair_create(bq_ctx *c, const double *x_s, const double *tl_s, const double *l_s,
+                              int64_t ns, const double *x_c, int64_t nc, const double *x_a,
+                              int64_t ma, int64_t S, bq_pair **out)
+{
+    if (!out)
+        return BQ_ERR_BAD_ARG;
+    *out = nullptr;
+    BQCHK(check_dims(c, 1, ns));
+    if (!x_s || !tl_s || !l_s || nc < 0 || ma < 0 || S < 1 || S > 65535 || (nc && !x_c) ||
+        (ma && !x_a) || nc + ma > (1 << 20))
+        return fail(c, BQ_ERR_BAD_ARG, "illegal value");
+    HIPCHK(c, hipSetDevice(c->device));
+    bq_pair *pr = new (std::nothrow) bq_pair();
+    if (!pr)
+        return fail(c, BQ_ERR_NOMEM, "out of host memory");
+    pr->ns = (int)ns;
+    pr->nc = (int)nc;
+    pr->ma = (int)ma;
+    pr->S = (int)S;
+    pr->nsc = (int)(ns + nc);
+    pr->hx_s.assign(x_s, x_s + ns);
+    pr->hx_c.assign(x_c, x_c + nc);
+    pr->hx_a.assign(x_a, x_a + ma);
+    int st = BQ_OK;
+    auto H = [&](hipError_t e) {
+        if (st == BQ_OK && e != hipSuccess)
+            st = fail(c, e == hipErrorOutOfMemory ? BQ_ERR_NOMEM : BQ_ERR_HIP, "pair: %s",
+                      hipGetErrorString(e));
+    };
+    const int M1 = (int)(nc + ma), nsc = pr->nsc;
+    std::vector<double> xr((size_t)S * ns), yr((size_t)S * ns), xo((size_t)S * std::max(M1, 1)),
+        one((size_t)S, 1.0), zero((size_t)S, 0.0), xsc((size_t)nsc), xr2((size_t)S * nsc),
+        yr2((size_t)S * nsc, 0.0);
+    for (int64_t b = 0; b < S; ++b) {
+        std::memcpy(&xr[(size_t)b * ns], x_s, sizeof(double) * ns);
+        std::memcpy(&yr[(size_t)b * ns], tl_s, sizeof(double) * ns);
+        if (nc)
+            std::memcpy(&xo[(size_t)b * M1], x_c, sizeof(double) * nc);
+        if (ma)
+            std::memcpy(&xo[(size_t)b * M1 + nc], x_a, sizeof(double) * ma);
+    }
+    std::memcpy(xsc.data(), x_s, sizeof(double) * ns);
+    if (nc)
+        std::memcpy(xsc.data() + ns, x_c, sizeof(double) * nc);
+    for (int64_t b = 0; b < S; ++b)
+        std::memcpy(&xr2[(size_t)b * nsc], xsc.data(), sizeof(double) * nsc);
+    st = bq_plan_create(c, S, 1, ns, M1, &pr->p1);
+    if (st == BQ_OK)
+        st = bq_plan_set_inputs(c, pr->p1, xr.data(), yr.data(), M1 ? xo.data() : nullptr,
+                                one.data(), one.data(), zero.data());
+    if (st == BQ_OK && ma == 0) {
+        st = bq_plan_create(c, S, 1, nsc, 0, &pr->p2);
+        if (st == BQ_OK)
+            st = bq_plan_set_inputs(c, pr->p2, xr2.data(), yr2.data(), nullptr, one.data(),
+                                    one.data(), zero.data());
+    }
+    if (st == BQ_OK) {
+        H(pr->l_s.alloc(sizeof(double) * ns));
+        H(pr->x_sc.alloc(sizeof(double) * nsc));
+        H(pr->x_a.alloc(sizeof(double) * std::max<int64_t>(ma, 1)));
+        H(pr->flag.alloc(sizeof(int) * S));
+        if (ma)
+            H(pr->y2.alloc(sizeof(double) * (size_t)S * nsc));
+    }
+    if (st == BQ_OK) {
+        H(hipMemcpyAsync(pr->l_s.p, l_s, sizeof(double) * ns, hipMemcpyHostToDevice, c->stream));
+        H(hipMemcpyAsync(pr->x_sc.p, xsc.data(), sizeof(double) * nsc, hipMemcpyHostToDevice,
+                         c->stream));
+        if (ma)
+            H(hipMemcpyAsync(pr->x_a.p, x_a, sizeof(double) * ma, hipMemcpyHostToDevice, c->stream));
+        H(hipStreamSynchronize(c->stream));
+    }
+    if (st != BQ_OK) {
+        bq_pair_destroy(c, pr);
+        return st;
+    }
+    *out = pr;
+    return BQ_OK;
+}
+
+extern "C" void bq_pair_destroy(bq_ctx *c, bq_pair *pr)
+{
+    if (!pr)
+        return;
+    if (c) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+    }
+    if (pr->p1)
+        bq_plan_destroy(c, pr->p1);
+    if (pr->p2)
+        bq_plan_destroy(c, pr->p2);
+    delete pr;
+}
+
+// llh[b] = log_lh(GP1) + log_lh(GP2) under parameter set b = (p_tl[3b..], p_l[3b..]) = (h, w, s)
+// each; -inf where a factorisation fails or the overflow guard trips (status[b] = 1 / 2 / 3:
+// GP1 not positive definite / GP mean too large / GP2 not positive definite).  l_c (S x nc,
+// optional): the candidates' values under every set.
+extern "C" int bq_pair_llh(bq_ctx *c, bq_pair *pr, const double *p_tl, const double *p_l,
+                           double *llh, double *l_c, int32_t *status)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    if (!pr || !p_tl || !p_l || !llh)
+        return fail(c, BQ_ERR_BAD_ARG, "illegal value");
+    if (!pr->p2)
+        return fail(c, BQ_ERR_BAD_ARG, "pair was created for the acquisition (ma > 0)");
+    const int S = pr->S, nsc = pr->nsc;
+    BQCHK(check_params(c, p_tl, S, "pair_llh (GP1)"));
+    BQCHK(check_params(c, p_l, S, "pair_llh (GP2)"));
+    HIPCHK(c, hipSetDevice(c->device));
+    BQCHK(run_stage1(c, pr, p_tl, pr->p2->y.d(), pr->p2->L.npad));
+    std::vector<double> h((size_t)S), w((size_t)S), s((size_t)S);
+    for (int b = 0; b < S; ++b) {
+        h[(size_t)b] = p_l[3 * b];
+        w[(size_t)b] = p_l[3 * b + 1];
+        s[(size_t)b] = p_l[3 * b + 2];
+    }
+    BQCHK(plan_set_params(c, pr->p2, h.data(), w.data(), s.data()));
+    BQCHK(bq_plan_run(c, pr->p2));
+    std::vector<double> s1((size_t)S * 4), s2((size_t)S * 4), y2;
+    std::vector<int> i1((size_t)S), i2((size_t)S), fl((size_t)S);
+    HIPCHK(c, hipMemcpyAsync(s1.data(), pr->p1->scal.p, sizeof(double) * 4 * S,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s2.data(), pr->p2->scal.p, sizeof(double) * 4 * S,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(i1.data(), pr->p1->info.p, sizeof(int) * S, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipMemcpyAsync(i2.data(), pr->p2->info.p, sizeof(int) * S, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipMemcpyAsync(fl.data(), pr->flag.p, sizeof(int) * S, hipMemcpyDeviceToHost,
+                             c->stream));
+    if (l_c && pr->nc)
+        HIPCHK(c, hipMemcpy2DAsync(l_c, sizeof(double) * pr->nc, pr->p2->y.d() + pr->ns,
+                                   sizeof(double) * pr->p2->L.npad, sizeof(double) * pr->nc, S,
+                                   hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)nsc;
+    for (int b = 0; b < S; ++b) {
+        const int st = i1[(size_t)b] ? 1 : (fl[(size_t)b] ? 2 : (i2[(size_t)b] ? 3 : 0));
+        if (status)
+            status[b] = st;
+        llh[b] = st ? -std::numeric_limits<double>::infinity()
+                    : s1[(size_t)b * 4] + s2[(size_t)b * 4];
+    }
+    return BQ_OK;
+}
+
+// The acquisition under S parameter sets: for set b and candidate a (element b * ma + a)
+//   A_a, A_sc_l   the two bilinear forms of bq_c.pyx:425-490 from the bordered (nsc + 1)^2
+//                 system with the reference's jitter (status = 1: singular system, the
+//                 caller's fallback of bq.py:481-490)
+//   tm_a, tC_a    GP1's posterior mean / variance at x_a (bq.py:493-496)
+// and per set: l_c (S x nc) and sstatus (1: GP1 not positive definite, 2: GP mean too large;
+// the set's elements are then not computed).  Only the noise-free Gram of GP2's kernel enters
+// (gp.Kxoxo, bq.py:465): p_l's s is not used.
+extern "C" int bq_pair_esm(bq_ctx *c, bq_pair *pr, const double *p_tl, const double *p_l,
+                           double thresh, const double *mu, const double *cov, double *A_a,
+                           double *A_sc_l, int32_t *status, double *tm_a, double *tC_a,
+                           double *l_c, int32_t *sstatus)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    if (!pr || !p_tl || !p_l || !mu || !cov || !A_a || !A_sc_l || !status || !tm_a || !tC_a ||
+        !sstatus)
+        return fail(c, BQ_ERR_BAD_ARG, "illegal value");
+    if (pr->ma == 0)
+        return fail(c, BQ_ERR_BAD_ARG, "pair was created without acquisition points");
+    const int S = pr->S, ns = pr->ns, nc = pr->nc, nsc = pr->nsc, ma = pr->ma;
+    BQCHK(check_params(c, p_tl, S, "pair_esm (GP1)"));
+    BQCHK(check_params(c, p_l, S, "pair_esm (GP2)"));
+    if (!(cov[0] > 0.0))
+        return fail(c, BQ_ERR_NOT_PD, "matrix is not positive definite");
+    HIPCHK(c, hipSetDevice(c->device));
+    BQCHK(run_stage1(c, pr, p_tl, pr->y2.d(), nsc));
+    // GP1's posterior at x_a and the set flags come back while stage 2 is being set up
+    const int M1 = nc + ma;
+    std::vector<double> hm((size_t)S * M1), hv((size_t)S * M1);
+    std::vector<int> i1((size_t)S), fl((size_t)S);
+    HIPCHK(c, hipMemcpyAsync(hm.data(), pr->p1->mean.p, sizeof(double) * hm.size(),
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hv.data(), pr->p1->var.p, sizeof(double) * hv.size(),
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(i1.data(), pr->p1->info.p, sizeof(int) * S, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipMemcpyAsync(fl.data(), pr->flag.p, sizeof(int) * S, hipMemcpyDeviceToHost,
+                             c->stream));
+    if (l_c && nc)
+        HIPCHK(c, hipMemcpy2DAsync(l_c, sizeof(double) * nc, pr->y2.d() + ns, sizeof(double) * nsc,
+                                   sizeof(double) * nc, S, hipMemcpyDeviceToHost, c->stream));
+    // ---- stage 2: S x ma bordered systems -------------------------------------------------
+    EsmLayout L;
+    L.ns = ns;
+    L.nsc = nsc;
+    L.npad = (int)roundup(nsc + 1, 64);
+    L.ntot = L.npad + 64;
+    const long lda = pick_ld(L.ntot);
+    const int64_t E = (int64_t)S * ma;
+    const size_t per = sizeof(double) * ((size_t)lda * L.ntot + panel_ws_doubles(L.ntot, 1) +
+                                         BQ_DINV_STRIDE + 2) + sizeof(int);
+    size_t freeb = 0, totalb = 0;
+    HIPCHK(c, hipMemGetInfo(&freeb, &totalb));
+    int64_t chunk = std::max<int64_t>(1, (int64_t)((freeb / 2) / per));
+    chunk = std::min<int64_t>(std::min<int64_t>(chunk, E), 32768);
+    // per set: kernel parameters of GP2 (no noise term), the closed form of int K p;
+    // per element: the jitter exactly as two successive improve_covariance_conditioning calls
+    // produce it (bq.py:470-476)
+    const double eps = std::numeric_limits<double>::epsilon();
+    std::vector<GaussParams> gps((size_t)S);
+    std::vector<double> par((size_t)S * 3), j1((size_t)E), j2((size_t)E);
+    std::vector<char> close((size_t)ma, 0);
+    for (int a = 0; a < ma; ++a)
+        for (int j = 0; j < nc && !close[(size_t)a]; ++j)
+            close[(size_t)a] = std::fabs(pr->hx_c[(size_t)j] - pr->hx_a[(size_t)a]) < thresh;
+    for (int b = 0; b < S; ++b) {
+        const double h = p_l[3 * b], wv[1] = {p_l[3 * b + 1]};
+        gps[(size_t)b] = make_params(1, h, wv, 0.0);
+        const double Cc = 1.0 * cov[0] + wv[0] * wv[0], Lc = std::sqrt(Cc);
+        par[(size_t)3 * b] = h * h;
+        par[(size_t)3 * b + 1] = 1.0 / Lc;
+        par[(size_t)3 * b + 2] = -0.5 * (1 * LOG_2PI + 2.0 * std::log(Lc));
+        for (int a = 0; a < ma; ++a) {
+            const double first = close[(size_t)a] ? std::max(eps, gps[(size_t)b].c) * 1e-4 : 0.0;
+            j1[(size_t)b * ma + a] = first;
+            j2[(size_t)b * ma + a] = std::max(eps, gps[(size_t)b].c + first) * 1e-4;
+        }
+    }
+    DevBuf gpd, pard, ik, ika, dj1, dj2, Ad, dinv, info, outd, panel;
+    HIPCHK(c, gpd.alloc(sizeof(GaussParams) * S));
+    HIPCHK(c, pard.alloc(sizeof(double) * 3 * S));
+    HIPCHK(c, ik.alloc(sizeof(double) * (size_t)S * nsc));
+    HIPCHK(c, ika.alloc(sizeof(double) * (size_t)E));
+    HIPCHK(c, dj1.alloc(sizeof(double) * (size_t)E));
+    HIPCHK(c, dj2.alloc(sizeof(double) * (size_t)E));
+    HIPCHK(c, Ad.alloc(sizeof(double) * (size_t)lda * L.ntot * (size_t)chunk));
+    HIPCHK(c, dinv.alloc(sizeof(double) * BQ_DINV_STRIDE * (size_t)chunk));
+    HIPCHK(c, panel.alloc(panel_ws_useful(c, L.ntot, (int)chunk)
+                              ? sizeof(double) * panel_ws_doubles(L.ntot, (int)chunk)
+                              : 0));
+    HIPCHK(c, info.alloc(sizeof(int) * (size_t)chunk));
+    HIPCHK(c, outd.alloc(sizeof(double) * 2 * (size_t)chunk));
+    HIPCHK(c, hipMemcpyAsync(gpd.p, gps.data(), sizeof(GaussParams) * S, hipMemcpyHostToDevice,
+                             c->stream));
+    HIPCHK(c, hipMemcpyAsync(pard.p, par.data(), sizeof(double) * 3 * S, hipMemcpyHostToDevice,
+                             c->stream));
+    HIPCHK(c, hipMemcpyAsync(dj1.p, j1.data(), sizeof(double) * E, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dj2.p, j2.data(), sizeof(double) * E, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pair_int_K_kernel, dim3((nsc + 255) / 256, S), dim3(256), 0, c->stream,
+                       pr->x_sc.d(), nsc, pard.d(), mu[0], ik.d());
+    hipLaunchKernelGGL(pair_int_K_kernel, dim3((ma + 255) / 256, S), dim3(256), 0, c->stream,
+                       pr->x_a.d(), ma, pard.d(), mu[0], ika.d());
+    HIPCHK(c, hipGetLastError());
+    std::vector<double> hout((size_t)chunk * 2);
+    std::vector<int> hinfo((size_t)chunk);
+    for (int64_t e0 = 0; e0 < E; e0 += chunk) {
+        const int nb = (int)std::min(chunk, E - e0);
+        HIPCHK(c, hipMemsetAsync(info.p, 0, sizeof(int) * nb, c->stream));
+        {
+            Bracket br(c, BQ_K_GRAM, 8.0 * L.ntot * (L.ntot + 1.0) / 2.0 * nb);
+            dim3 grid((L.ntot + 127) / 128, (L.ntot + 63) / 64, nb);
+            hipLaunchKernelGGL(assemble_esm_multi_kernel, grid, dim3(256), 0, c->stream,
+                               pr->x_sc.d(), pr->x_a.d(), ma, (long)e0, ik.d(), ika.d(),
+                               pr->y2.d(), (long)nsc, dj1.d(), dj2.d(), thresh,
+                               static_cast<const GaussParams *>(gpd.p), Ad.d(), lda,
+                               lda * (long)L.ntot, L);
+            HIPCHK(c, hipGetLastError());
+        }
+        BQCHK(enqueue_potrf_partial(c, Ad.d(), lda, lda * (long)L.ntot, nb, L.ntot, L.npad,
+                                    dinv.d(), info.i(), panel.d(), panel.bytes / sizeof(double)));
+        hipLaunchKernelGGL(esm_multi_finalize_kernel, dim3((nb + 255) / 256), dim3(256), 0,
+                           c->stream, Ad.d(), lda, lda * (long)L.ntot, L, nb, outd.d());
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(hout.data(), outd.p, sizeof(double) * 2 * nb,
+                                 hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hinfo.data(), info.p, sizeof(int) * nb, hipMemcpyDeviceToHost,
+                                 c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int k = 0; k < nb; ++k) {
+            A_a[e0 + k] = hout[(size_t)2 * k];
+            A_sc_l[e0 + k] = hout[(size_t)2 * k + 1];
+            status[e0 + k] = hinfo[(size_t)k];
+        }
+    }
+    for (int b = 0; b < S; ++b) {
+        sstatus[b] = i1[(size_t)b] ? 1 : (fl[(size_t)b] ? 2 : 0);
+        for (int a = 0; a < ma; ++a) {
+            tm_a[(size_t)b * ma + a] = hm[(size_t)b * M1 + nc + a];
+            tC_a[(size_t)b * ma + a] = hv[(size_t)b * M1 + nc + a];
+        }
+    }
+    return BQ_OK;
+}

@@ -142,6 +142,20 @@ class Engine(object):
     def profile_reset(self):
         self._check(self._lib.bq_profile_reset(self._ctx))
 
+    def timeline(self, fn):
+        """Runs fn() under the launch profiler and returns its launches as rows
+        (class name, stream, start ms, end ms, work), times since the first launch."""
+        self.profile(True)
+        self.profile_reset()
+        self._check(self._lib.bq_profile_timeline(self._ctx, 1, None, 0, None))
+        fn()
+        n = C.c_int64(0)
+        self._check(self._lib.bq_profile_timeline(self._ctx, 0, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 5))
+        self._check(self._lib.bq_profile_timeline(self._ctx, 0, L.dptr(out), n.value, C.byref(n)))
+        self.profile(False)
+        return [(L.K_CLASSES[int(r[0])], int(r[1]), r[2], r[3], r[4]) for r in out[:n.value]]
+
     def profile_read(self):
         ms = np.zeros(len(L.K_CLASSES))
         work = np.zeros(len(L.K_CLASSES))

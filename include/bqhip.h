@@ -100,6 +100,11 @@ int bq_profile_reset(bq_ctx *ctx);
  * or bytes of the launches of each class (trailing update: the lower half only,
  * m^2 k; Gram: 8 N^2 + 8 d N); synchronises.  Any pointer may be NULL. */
 int bq_profile_read(bq_ctx *ctx, double *ms, int64_t *launches, double *work);
+/* the bracketed launches as a timeline: rows {class, stream (0 main / 1 second), start ms,
+ * end ms, algorithmic work}, times since the first bracketed launch.  keep = 1 with out = NULL
+ * arms (and clears) the recording; keep = 0 stops it -- with out = NULL that call only reports
+ * *nrows, with out it copies up to max_rows rows. */
+int bq_profile_timeline(bq_ctx *ctx, int keep, double *out, int64_t max_rows, int64_t *nrows);
 
 /* ---- linalg_c drop-ins: host buffers in and out --------------------- */
 /* L <- lower Cholesky factor of C (n x n, ld = n).  C == L allowed (in place).

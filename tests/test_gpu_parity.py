@@ -818,13 +818,19 @@ def test_esm_border_bounded_host_tail(engine, oracle):
     set of jittered candidates).  Beyond nt = 320 rows or 64 distinct sets the call hands all
     candidates to the batched device refactorisation instead: same answers either way."""
     rs = np.random.RandomState(77)
-    for ns, nc, M, thresh in ((40, 340, 30, 0.02), (64, 200, 150, 0.06)):
+    for ns, nc0, M, thresh in ((40, 360, 30, 0.02), (64, 215, 150, 0.06)):
         xs = np.linspace(-5, 5, ns)
-        xc = np.sort(rs.uniform(-5.5, 5.5, nc))
+        # candidates on a jittered grid (spacing ~ w: the conditioning regime of the configs),
+        # none closer than half a spacing to a sample
+        dc = 11.0 / nc0
+        xc = -5.5 + dc * (np.arange(nc0) + 0.5 + rs.uniform(-0.2, 0.2, nc0))
+        xc = xc[np.abs(xc[:, None] - xs[None, :]).min(axis=1) > 0.5 * dc]
+        nc = xc.shape[0]
+        assert (ns == 40 and ns + nc - ns // 64 * 64 > 320) or (ns == 64 and nc > 150)
         x_sc = np.concatenate([xs, xc])
         l_sc = np.exp(wl.norm_logpdf(x_sc))
         x_a = np.sort(rs.uniform(-6, 6, M))
-        h, w = 0.2, 0.035
+        h, w = 0.2, 1.1 * dc
         fit = engine.gp_fit(x_sc, l_sc, h, w, 0.0)
         got = engine.esm_border(fit, ns, x_a, thresh, MU1, COV1)
         chk = engine.esm_batch(x_sc, l_sc, ns, x_a, h, w, thresh, MU1, COV1)
