@@ -100,6 +100,8 @@ static int ctx_init(bq_ctx *c, int device)
         c->la_min = std::atoi(e);
     if (const char *e = std::getenv("BQ_GEMM_LDS"))
         c->gemm_lds = std::atoi(e);
+    if (const char *e = std::getenv("BQ_GEMM_LDS64"))
+        c->gemm_lds64 = std::atoi(e);
     if (const char *e = std::getenv("BQ_GRAPH"))
         c->use_graph = std::atoi(e);
     return BQ_OK;

@@ -597,6 +597,154 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C
 
 
 // ---------------------------------------------------------------------------
+// The same product with a 64 x 64 workgroup tile (four waves of 32 x 32): four times the
+// workgroups of gemm_lds_kernel for products whose 128 x 128 tiles cannot fill the chip -- the
+// row sweeps over a resident factor with a few hundred right-hand sides (a 256-row operand
+// gives the 128-tile kernel ONE workgroup per CU whatever the other dimension, and a step then
+// costs one 65 us workgroup lifetime however little work it has), the late trailing updates and
+// the panel-internal products of a batch.  36 KiB of LDS and <= 128 VGPRs: four workgroups
+// per CU, sixteen waves to hide each other's barriers.
+// Staging: an LDS-DMA instruction moves 1 KiB = TWO k rows of a 64-row operand block; DMA row
+// d (1152 B with the pad) holds k rows d and d + 8 of the chunk, so that the four k rows of a
+// k-step sit in four consecutive DMA rows of one half -- the bank pattern of the 128-row layout
+// (rows 1152 B apart, conflict-free ds_read_b64).  Chunk = 16 k columns = 8 DMA rows of P +
+// 8 of Q; wave w stages DMA rows 4 (w & 1) .. + 3 of P (w < 2) or Q.
+// Requires ldq unit stride in the row index, m and n multiples of 64, k of 32.
+// QT: Q is given k-contiguous -- Q(j, k) at Q[j ldq + k], the form of the backward row sweep's
+// operand L[J.., 0..J)^T, which the register-streaming kernels read with a stride of ldl between
+// lanes (24 TFLOP/s against 45 for the forward sweep).  A DMA lane then carries k rows 2 d,
+// 2 d + 1 of ONE operand row (16 contiguous bytes), a DMA row the k-row pair d of all 64 rows,
+// interleaved; the fragment views only change their address pattern (lanes l4 = 0, 1 of a
+// k-step read the two halves of consecutive 16-byte pairs: 256 contiguous bytes, no conflict).
+// ---------------------------------------------------------------------------
+#define BQ_L64_STAGE (16 * BQ_LDS_ROW)
+#define BQ_L64_BYTES (2 * BQ_L64_STAGE)
+
+template <bool QT>
+__global__ __launch_bounds__(256, 4) void gemm_lds64_kernel(double *__restrict__ C, long ldc,
+                                                            long cstride,
+                                                            const double *__restrict__ P, long ldp,
+                                                            long pstride,
+                                                            const double *__restrict__ Q, long ldq,
+                                                            long qstride, int m, int n, int k,
+                                                            int lower, int ncut)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.z;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (lower == 2)
+        tri_decode(blockIdx.x, bx, by);
+    C += (long)b * cstride;
+    P += (long)b * pstride;
+    Q += (long)b * qstride;
+    const int R0 = bx * 64, C0 = by * 64;
+    if (C0 >= ncut)
+        return; // (the whole workgroup, before any barrier)
+    const int wr = (wave & 1) * 32, wc = (wave >> 1) * 32;
+    const int row0 = R0 + wr, col0 = C0 + wc;
+    const bool active = row0 < m && col0 < n && col0 < ncut && !(lower && col0 >= row0 + 32);
+
+    const bool stq = wave >= 2;
+    const int dma0 = 4 * (wave & 1); // this wave's first DMA row of its operand
+    // lane i: operand rows 2 (i & 31), + 1 of k row (dma row) + 8 (i >> 5);
+    // QT operand: operand row i, k rows 2 (dma row), + 1
+    const double *gsrc;
+    long sld;    // source step from one DMA row to the next
+    long schunk; // ... and from one chunk to the next
+    if (QT && stq) {
+        gsrc = Q + (long)min(C0 + lane, n - 1) * ldq + 2 * dma0;
+        sld = 2;
+        schunk = 16;
+    } else {
+        sld = stq ? ldq : ldp;
+        gsrc = (stq ? Q + min(C0 + 2 * (lane & 31), n - 2) : P + min(R0 + 2 * (lane & 31), m - 2)) +
+               (long)(dma0 + 8 * (lane >> 5)) * sld;
+        schunk = 16 * sld;
+    }
+    const int srow = ((stq ? 8 : 0) + dma0) * BQ_LDS_ROW;
+
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const unsigned char *pview = smem + l4 * BQ_LDS_ROW + (wr + l15) * 8;
+    const unsigned char *qview[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        qview[s] = QT ? smem + (8 + (l4 >> 1)) * BQ_LDS_ROW +
+                            (wc + ((l15 - 4 * s) & 15)) * 16 + (l4 & 1) * 8
+                      : smem + (8 + l4) * BQ_LDS_ROW + (wc + ((l15 - 4 * s) & 15)) * 8;
+
+    double acc[2][2][4];
+
+#define BQ_L64_FILL(BUF_, CH_)                                                                     \
+    {                                                                                              \
+        const double *g_ = gsrc + (long)(CH_) * schunk;                                            \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) __builtin_amdgcn_global_load_lds(            \
+            (global_cvoid_t *)(g_ + (long)r * sld),                                                \
+            (lds_void_t *)(smem + (BUF_) * BQ_L64_STAGE + srow + r * BQ_LDS_ROW), 16, 0, 0);       \
+    }
+    // k-step ST_ of a chunk: k rows 4 ST_ + l4 = DMA rows 4 (ST_ & 1) + l4 of half ST_ >> 1
+#define BQ_L64_OFF(BUF_, ST_) ((BUF_) * BQ_L64_STAGE + 4 * ((ST_) & 1) * BQ_LDS_ROW + ((ST_) >> 1) * 512)
+#define BQ_L64_READ_P(BUF_, ST_, PF)                                                               \
+    _Pragma("unroll") for (int tm = 0; tm < 2; ++tm) PF[tm] = *reinterpret_cast<const double *>(   \
+        pview + BQ_L64_OFF(BUF_, ST_) + tm * 128);
+    // (QT: k-step ST_ = DMA rows 2 ST_, 2 ST_ + 1; a 16-row fragment block is 256 B apart)
+#define BQ_L64_QOFF(BUF_, ST_, TN_)                                                                \
+    (QT ? (BUF_) * BQ_L64_STAGE + 2 * (ST_) * BQ_LDS_ROW + (TN_) * 256                             \
+        : BQ_L64_OFF(BUF_, ST_) + (TN_) * 128)
+#define BQ_L64_READ_Q(BUF_, ST_, TN_, QF)                                                          \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) QF[s] = *reinterpret_cast<const double *>(       \
+        qview[s] + BQ_L64_QOFF(BUF_, ST_, TN_));
+#define BQ_L64_CHUNK(BUF_, CH_)                                                                    \
+    {                                                                                              \
+        __syncthreads();                                                                           \
+        if ((CH_) + 1 < nchunk)                                                                    \
+            BQ_L64_FILL(1 - (BUF_), (CH_) + 1)                                                     \
+        if (active) {                                                                              \
+            BQ_L64_READ_P(BUF_, 0, pf[0])                                                          \
+            BQ_L64_READ_Q(BUF_, 0, 0, qf[0])                                                       \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j)                                          \
+            {                                                                                      \
+                const int st = j >> 1, tn = j & 1;                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                 \
+                if (j < 7)                                                                         \
+                    BQ_L64_READ_Q(BUF_, (j + 1) >> 1, (j + 1) & 1, qf[(j + 1) & 1])                \
+                if (tn == 1 && j < 7)                                                              \
+                    BQ_L64_READ_P(BUF_, st + 1, pf[(st + 1) & 1])                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                 \
+                _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                   \
+                    _Pragma("unroll") for (int s = 0; s < 4; ++s) acc[tm][tn][s] =                 \
+                        __builtin_amdgcn_mfma_f64_4x4x4f64(qf[j & 1][s], pf[st & 1][tm],           \
+                                                           acc[tm][tn][s], 0, 0, 0);               \
+            }                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }                                                                                          \
+    }
+
+    double pf[2][2], qf[2][4];
+    const int nchunk = k / 16; // even
+    BQ_L64_FILL(0, 0)
+    const Tile444<2, 2> ct(C, ldc, row0, col0, lane);
+    if (active)
+        ct.load_neg(acc);
+    for (int ch = 0; ch < nchunk; ch += 2) {
+        BQ_L64_CHUNK(0, ch)
+        BQ_L64_CHUNK(1, ch + 1)
+    }
+#undef BQ_L64_READ_P
+#undef BQ_L64_READ_Q
+#undef BQ_L64_CHUNK
+#undef BQ_L64_FILL
+#undef BQ_L64_OFF
+#undef BQ_L64_QOFF
+
+    if (!active)
+        return;
+    ct.store_neg(acc, lower);
+}
+
+
+// ---------------------------------------------------------------------------
 // C (m x n) -= P (m x k) Q for the SMALL products of the row sweeps over a resident factor
 // (posterior variance at C2 size: m = 256 prediction points, n <= 768, k = 256): the 64 x 64
 // tiles of gemm_sub_kernel leave 16-48 workgroups that each walk 64 dependent k-steps with

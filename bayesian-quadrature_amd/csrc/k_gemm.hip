@@ -9,6 +9,10 @@ int gemm_init(bq_ctx *c)
 {
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lds_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, BQ_LDS_BYTES));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lds64_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, BQ_L64_BYTES));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lds64_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, BQ_L64_BYTES));
     return BQ_OK;
 }
 
@@ -25,13 +29,31 @@ int gemm_init(bq_ctx *c)
 // Such an update never carries the fused diagonal factor (the factor would ride on the
 // register-streaming kernel, which is slower by more than a potf2 launch costs).
 #define BQ_LDS_MIN_TILES 96
+// 0: no; 128 / 64: the workgroup tile of the LDS-staged kernel that takes the product.
+// 128 x 128 tiles when there are at least BQ_LDS_MIN_TILES of them; products that cannot fill
+// the chip with those -- a few hundred rows against a long operand (the row sweeps), the late
+// updates of a batch -- take the 64 x 64 form (gemm_lds64_kernel) when that gives at least a
+// workgroup per CU.
+static int gemm_lds_tile(const bq_ctx *c, int m, int n, int k, int lower, int batch)
+{
+    if (!c->gemm_lds || (m % 64) || (n % 64) || (k % 32))
+        return 0;
+    long a = (long)((m + 127) / 128) * ((n + 127) / 128) * batch;
+    long a64 = (long)(m / 64) * (n / 64) * batch;
+    if (lower) {
+        a = a / 2 + 1;
+        a64 = a64 / 2 + 1;
+    }
+    if (n >= 128 && a >= 2L * c->cus)
+        return 128;
+    if (c->gemm_lds64 && a64 >= c->cus / 2 && k >= 64)
+        return 64;
+    return (n >= 128 && a >= BQ_LDS_MIN_TILES) ? 128 : 0;
+}
+
 bool gemm_uses_lds(const bq_ctx *c, int m, int n, int k, int lower, int batch)
 {
-    long a = (long)((m + 127) / 128) * ((n + 127) / 128) * batch;
-    if (lower)
-        a = a / 2 + 1;
-    return c->gemm_lds && a >= BQ_LDS_MIN_TILES && n >= 128 && (m % 64) == 0 &&
-           (n % 64) == 0 && (k % 32) == 0;
+    return gemm_lds_tile(c, m, n, k, lower, batch) != 0;
 }
 
 int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const double *P, long ldp,
@@ -78,10 +100,24 @@ int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const dou
                                mode, fuse_j0, dinv, dstride, info);                                \
     } while (0)
     // a 64-column slab has no use for 128-column workgroup tiles (half of their waves idle)
-    if (f444 && fuse_j0 < 0 && n >= 128 && gemm_uses_lds(c, m, n, k, lower, batch)) {
+    const int ldst = (f444 && fuse_j0 < 0) ? gemm_lds_tile(c, m, n, k, lower, batch) : 0;
+    if (ldst == 128) {
         dim3 g = grid_for(128);
         hipLaunchKernelGGL(gemm_lds_kernel, g, dim3(256), BQ_LDS_BYTES, c->cur, C, ldc, cstride, P,
                            ldp, pstride, Q, qsk, qstride, m, n, k, mode,
+                           ccut > 0 ? ccut : 0x7fffffff);
+    } else if (ldst == 64) {
+        dim3 g = grid_for(64);
+        hipLaunchKernelGGL(gemm_lds64_kernel<false>, g, dim3(256), BQ_L64_BYTES, c->cur, C, ldc,
+                           cstride, P, ldp, pstride, Q, qsk, qstride, m, n, k, mode,
+                           ccut > 0 ? ccut : 0x7fffffff);
+    } else if (qsk == 1 && (qsj & 1) == 0 && fuse_j0 < 0 && (m % 64) == 0 &&
+               gemm_lds_tile(c, m, n, k, lower, batch) != 0 && c->gemm_lds64 &&
+               tiles(64) >= c->cus / 2) {
+        // Q given k-contiguous (the backward row sweep): the 64-tile kernel's transposed staging
+        dim3 g = grid_for(64);
+        hipLaunchKernelGGL(gemm_lds64_kernel<true>, g, dim3(256), BQ_L64_BYTES, c->cur, C, ldc,
+                           cstride, P, ldp, pstride, Q, qsj, qstride, m, n, k, mode,
                            ccut > 0 ? ccut : 0x7fffffff);
     } else if (tiles(128) >= cu && n >= 128) {
         BQ_GEMM_SUB(4, 4, 128);
