@@ -88,6 +88,12 @@ SIGNATURES = {
     "bq_plan_bytes": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
     "bq_probe_mfma_f64": (C.c_int, [_vp, _dp]),
     "bq_probe_fma_f64": (C.c_int, [_vp, _dp]),
+    "bq_pair_create": (C.c_int, [_vp, _dp, _dp, _dp, _i64, _dp, _i64, _dp, _i64, _i64,
+                                 C.POINTER(_vp)]),
+    "bq_pair_destroy": (None, [_vp, _vp]),
+    "bq_pair_llh": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp, _i32p]),
+    "bq_pair_esm": (C.c_int, [_vp, _vp, _dp, _dp, _dbl, _dp, _dp, _dp, _dp, _i32p, _dp, _dp, _dp,
+                              _i32p]),
     "bq_probe_hbm": (C.c_int, [_vp, C.c_size_t, _dp, _dp]),
     "bq_probe_hbm_read8": (C.c_int, [_vp, C.c_size_t, _i64, _dp]),
     "bq_probe_mfma_variant": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),

@@ -62,6 +62,26 @@ class BQ(object):
         self.x_sc = self.l_sc = self.nsc = None   # samples followed by candidates
         self._approx_x = None
         self._approx_px = None
+        self._drop_pairs()
+
+    def _drop_pairs(self):
+        """The resident batched evaluators (engine.Pair) belong to one set of samples and
+        candidates: dropped whenever those change."""
+        for p in getattr(self, "_pairs", {}).values():
+            try:
+                p.close()
+            except Exception:
+                pass
+        self._pairs = {}
+
+    def _pair(self, S, x_a=None):
+        x_a = np.empty(0) if x_a is None else np.ascontiguousarray(x_a, dtype=DTYPE)
+        key = (int(S), x_a.tobytes())
+        if key not in self._pairs:
+            if len(self._pairs) >= 4:   # a few shapes at most stay resident
+                self._drop_pairs()
+            self._pairs[key] = get_engine().pair(self.x_s, self.tl_s, self.l_s, self.x_c, x_a, S)
+        return self._pairs[key]
 
     def load_options(self, kernel, n_candidate, candidate_thresh, x_mean, x_var, optim_method):
         """All six options are required (bq.py:94).  ``kernel`` is the kernel class,
@@ -86,6 +106,7 @@ class BQ(object):
         """Create both GPs.  ``params_*`` = (h, w, s): kernel parameters then noise."""
         self._require_exact()
         kernel = self.options["kernel"]
+        self._drop_pairs()
         self.gp_log_l = GP(kernel(*params_tl[:-1]), self.x_s, self.tl_s, s=params_tl[-1])
         self.gp_log_l.jitter = np.zeros(self.ns, dtype=DTYPE)
         self._choose_candidates()
@@ -253,10 +274,42 @@ class BQ(object):
         return np.array([self.gp_log_l.get_param(p) for p in params] +
                         [self.gp_l.get_param(p) for p in params])
 
+    def _param_sets(self, params, X):
+        """S parameter vectors [params of GP1..., params of GP2...] as the two S x 3 arrays
+        (h, w, s) of the batched evaluators, and the mask of the sets the reference's closure
+        would reject before touching a GP (NaN, or a value set_param refuses: bq.py:539-543)."""
+        X = np.atleast_2d(np.asarray(X, dtype=DTYPE))
+        S, nparam = X.shape[0], len(params)
+        order = {"h": 0, "w": 1, "s": 2}
+        p_tl = np.repeat(np.asarray(self.gp_log_l.params, dtype=DTYPE)[None, :], S, axis=0)
+        p_l = np.repeat(np.asarray(self.gp_l.params, dtype=DTYPE)[None, :], S, axis=0)
+        for j, name in enumerate(params):
+            p_tl[:, order[name]] = X[:, j]
+            p_l[:, order[name]] = X[:, nparam + j]
+        ok = np.isfinite(p_tl).all(axis=1) & np.isfinite(p_l).all(axis=1)
+        for p in (p_tl, p_l):
+            ok &= (p[:, 0] > 0) & (p[:, 1] > 0) & (p[:, 2] >= 0)
+        # rejected sets still ride through the batch, with harmless parameters
+        p_tl[~ok] = np.asarray(self.gp_log_l.params, dtype=DTYPE)
+        p_l[~ok] = np.asarray(self.gp_l.params, dtype=DTYPE)
+        return np.ascontiguousarray(p_tl), np.ascontiguousarray(p_l), ok
+
+    def _make_llh_batch(self, params):
+        """X (S x 2 len(params)) -> the S values of the closure of ``_make_llh_params``, all sets
+        in ONE batched device pass (bq_pair_llh) instead of S sequential refits of both GPs.
+        Unlike the closure it leaves the GPs' parameters alone."""
+        def fb(X):
+            p_tl, p_l, ok = self._param_sets(params, X)
+            llh, _, _ = self._pair(p_tl.shape[0]).llh(p_tl, p_l)
+            return np.where(ok, llh, -np.inf)
+
+        return fb
+
     def fit_hypers(self, params):
         f = self._make_llh_params(params)
         p0 = util.find_good_parameters(f, self._current_params(params),
-                                       self.options["optim_method"])
+                                       self.options["optim_method"],
+                                       logpdf_batch=self._make_llh_batch(params))
         if p0 is None:
             raise RuntimeError("couldn't find good parameters")
         f(p0)  # leave the GPs at the optimum (the optimiser's last call may be elsewhere)
@@ -301,13 +354,74 @@ class BQ(object):
         return values
 
     def choose_next(self, x_a, n, params, plot=False):
-        """The entry of x_a with the smallest marginal loss -E[m(Z)^2]."""
+        """The entry of x_a with the smallest marginal loss -E[m(Z)^2] under ``n`` sampled
+        hyper-parameter settings (bq.py:659-662).  The reference -- and ``marginalize`` -- visit
+        the settings one after the other; here all of them are one batched device pass
+        (``_esm_marginal``).  Same random draws, same state restored afterwards."""
         if plot:
             raise NotImplementedError("plotting is not part of the MI355X engine")
-        loss = self.marginalize([lambda: -self.expected_squared_mean(x_a)], n, params)[0]
-        loss = loss.mean(axis=0)
+        x_a = np.atleast_1d(np.asarray(x_a, dtype=DTYPE))
+        state = deepcopy(self.__getstate__())
+        hypers_tl, hypers_l = self.sample_hypers(params, n=n, nburn=1)
+        esm = self._esm_marginal(x_a, params, hypers_tl, hypers_l)
+        self.__setstate__(state)
+        loss = (-esm).mean(axis=0)
         ties = np.nonzero(np.isclose(loss, np.min(loss)))[0]
         return x_a[np.random.choice(ties)]
+
+    def _esm_marginal(self, x_a, params, hypers_tl, hypers_l):
+        """E[m(Z)^2 | x_a] for every entry of x_a under every hyper-parameter setting
+        (rows of hypers_tl / hypers_l over ``params``): n x len(x_a).  One batched pass for
+        GP1's refits and posteriors and the n x len(x_a) bordered systems of bq.py:447-527;
+        the closed forms of bq_c.pyx:425-490 and the rules of ``_esm_and_em_batch`` (near-sample
+        short-circuit, singular-system fallback, overflow) are applied per setting."""
+        self._require_exact()
+        if x_a.ndim != 1 or np.isnan(x_a).any() or np.isinf(x_a).any():
+            raise ValueError("invalid value for x_a: %s" % x_a)
+        n, M = hypers_tl.shape[0], x_a.shape[0]
+        X = np.concatenate([hypers_tl, hypers_l], axis=1)
+        p_tl, p_l, ok = self._param_sets(params, X)
+        if not ok.all():
+            raise ValueError("invalid hyper-parameter sample")
+        out = np.empty((n, M))
+        near = np.isclose(x_a[:, None], self.x_s[None, :], atol=1e-4).any(axis=1)
+        idx = np.nonzero(~near)[0]
+        r = None
+        if idx.size:
+            xa = np.ascontiguousarray(x_a[idx])
+            r = self._pair(n, xa).esm(p_tl, p_l, self.options["candidate_thresh"],
+                                      self.options["x_mean"], self.options["x_cov"])
+            bad = np.nonzero(r["sstatus"] != 0)[0]
+            if bad.size:
+                # what _set_gp_log_l_params raises for this setting inside marginalize
+                logger.error("error with parameters %s and %s", p_tl[bad[0]], p_l[bad[0]])
+                raise np.linalg.LinAlgError(
+                    "GP mean is too large" if r["sstatus"][bad[0]] == 2
+                    else "matrix is not positive definite")
+            arg1 = r["tm_a"] + 0.5 * r["tC_a"]
+            arg2 = 2.0 * r["tm_a"] + 2.0 * r["tC_a"]
+            A_a, A_sc_l = r["A_a"], r["A_sc_l"]
+            with np.errstate(over="ignore", invalid="ignore"):
+                e1 = np.where(arg1 > MAX, np.inf, np.exp(np.minimum(arg1, MAX)))
+                e2 = np.where(arg2 > MAX, np.inf, np.exp(np.minimum(arg2, MAX)))
+                esm = (A_sc_l ** 2) + (2 * A_sc_l * A_a * e1) + (A_a ** 2 * e2)
+            esm = np.where(np.isinf(e1) | np.isinf(e2), np.inf, esm)
+            good = r["status"] == 0
+            if (good & (np.isnan(esm) | (esm < 0))).any():
+                b, k = np.argwhere(good & (np.isnan(esm) | (esm < 0)))[0]
+                raise RuntimeError(
+                    "invalid expected squared mean for x_a=%s: %s" % (xa[k], esm[b, k]))
+            out[:, idx] = esm
+        # settings with a point that cannot move the mean, or a singular system: the current
+        # squared mean under THAT setting (bq.py:456-459, 481-490), through the object path
+        need = near[None, :].repeat(n, axis=0)
+        if r is not None:
+            need[:, idx] |= r["status"] != 0
+        for b in np.nonzero(need.any(axis=1))[0]:
+            self._set_gp_log_l_params(dict(zip(("h", "w", "s"), p_tl[b])))
+            self._set_gp_l_params(dict(zip(("h", "w", "s"), p_l[b])))
+            out[b, need[b]] = self.Z_mean() ** 2
+        return out
 
     def add_observation(self, x_a, l_a):
         """Add (x_a, l_a); an x_a within ``candidate_thresh`` of a sample is averaged
@@ -338,6 +452,13 @@ class BQ(object):
         return state
 
     def __setstate__(self, state):
+        same = (getattr(self, "_pairs", None) and getattr(self, "x_s", None) is not None
+                and np.array_equal(self.x_s, state["x_s"])
+                and np.array_equal(self.l_s, state["l_s"]) and state.get("gp_l") is not None
+                and self.x_c is not None
+                and np.array_equal(self.x_c, state["gp_l"]._x[state["x_s"].shape[0]:]))
+        if not same:
+            self._drop_pairs()
         for k in _STATE_ALWAYS:
             setattr(self, k, state[k])
         self.ns = self.x_s.shape[0]

@@ -16,6 +16,7 @@
 //   plan.hip     resident batched plans, batched / grid entry points
 //   fit.hip      resident GP fits
 //   moments.hip  closed-form integrals, BQ moments, the acquisition entry points
+//   pair.hip     the stacked pair of GPs at S hyper-parameter sets in one batched pass
 //   probe.hip    hardware probes
 #pragma once
 #include <hip/hip_runtime.h>
@@ -453,6 +454,8 @@ int fit_replay(bq_ctx *c, bq_fit *f, int slot, F &&enqueue)
     }
     return enqueue();
 }
+// plan.hip: new kernel parameters for every problem of a plan, nothing else re-uploaded
+int plan_set_params(bq_ctx *c, bq_plan *p, const double *h, const double *w, const double *s);
 // plan.hip: the launch sequence of one pass of a plan (bq_probe_c2_timeline runs it eagerly)
 int plan_enqueue(bq_ctx *c, bq_plan *p);
 } // namespace bqh

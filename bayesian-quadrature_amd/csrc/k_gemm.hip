@@ -148,8 +148,11 @@ int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const dou
 int launch_gemm_rows(bq_ctx *c, int cls, double *C, long ldc, const double *P, long ldp,
                      const double *Q, long qsj, long qsk, int m, int n, int k)
 {
-    // small products (posterior variance at C2 size): split-k tiles, gemm_splitk_kernel
-    if ((m % 32) == 0 && (n % 32) == 0 && (k % 64) == 0 && k <= 2048 &&
+    // small products (posterior variance at C2 size): split-k tiles, gemm_splitk_kernel --
+    // unless the 64 x 64 LDS-staged tiles already get half a chip of workgroups
+    const bool lds = (qsj == 1 || (qsk == 1 && (qsj & 1) == 0)) && (m % 64) == 0 &&
+                     gemm_lds_tile(c, m, n, k, 0, 1) != 0;
+    if (!lds && (m % 32) == 0 && (n % 32) == 0 && (k % 64) == 0 && k <= 2048 &&
         (long)(m / 32) * (n / 32) <= 4L * c->cus) {
         Bracket br(c, cls, 2.0 * (double)m * n * k);
         hipLaunchKernelGGL(gemm_splitk_kernel, dim3(m / 32, n / 32), dim3(256), 0, c->cur, C, ldc,

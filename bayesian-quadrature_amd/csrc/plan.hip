@@ -159,6 +159,24 @@ extern "C" int bq_plan_set_inputs(bq_ctx *c, bq_plan *p, const double *x, const 
 
 namespace bqh {
 
+// New (h, w, s) for every problem of a plan whose points and targets stay resident (the
+// hyper-parameter loop: same data, new parameters on every evaluation)
+int plan_set_params(bq_ctx *c, bq_plan *p, const double *h, const double *w, const double *s)
+{
+    if (!p || !p->has_inputs)
+        return fail(c, BQ_ERR_BAD_ARG, "plan has no inputs");
+    const int d = p->d;
+    p->hgp.resize(p->nprob);
+    for (int b = 0; b < p->nprob; ++b) {
+        BQCHK(check_w(c, d, h[b], w + (size_t)b * d, s[b]));
+        p->hgp[b] = make_params(d, h[b], w + (size_t)b * d, s[b]);
+    }
+    // (hgp outlives the copy: it belongs to the plan)
+    HIPCHK(c, hipMemcpyAsync(p->gp.p, p->hgp.data(), sizeof(GaussParams) * p->nprob,
+                             hipMemcpyHostToDevice, c->stream));
+    return BQ_OK;
+}
+
 int plan_enqueue(bq_ctx *c, bq_plan *p)
 {
     // a small system's first sweep launch (and the clearing of the failure flags) rides in

@@ -374,6 +374,11 @@ class Engine(object):
     def plan(self, nprob, d, n, M):
         return Plan(self, nprob, d, n, M)
 
+    def pair(self, x_s, tl_s, l_s, x_c, x_a, S):
+        """The stacked pair of GPs of a BQ object, resident for S hyper-parameter sets
+        (bq_pair): ``llh`` without acquisition points, ``esm`` with them."""
+        return Pair(self, x_s, tl_s, l_s, x_c, x_a, S)
+
     # -- probes ----------------------------------------------------------------
     def probe_mfma_f64(self):
         v = C.c_double()
@@ -524,6 +529,77 @@ class Fit(object):
         e._check(e._lib.bq_gp_predict(e._ctx, self._handle(), L.dptr(xo), M, L.dptr(mean), L.dptr(var),
                                       L.dptr(cov)))
         return mean, var, cov
+
+
+class Pair(object):
+    """GP1 over log l at the samples and GP2 over [l_s, exp(mean of GP1 at x_c)] at samples +
+    candidates, evaluated at S hyper-parameter sets in one batched pass (bq_pair_*): the
+    hyper-parameter objective of bq.py:536-550 and the acquisition under sampled
+    hyper-parameters of bq.py:604-662."""
+
+    def __init__(self, eng, x_s, tl_s, l_s, x_c, x_a, S):
+        self._eng = eng
+        self._h = C.c_void_p()
+        def c(a):
+            if a is None:
+                return np.empty(0)
+            return np.ascontiguousarray(np.atleast_1d(a), dtype=np.float64)
+
+        x_s, tl_s, l_s, x_c, x_a = c(x_s), c(tl_s), c(l_s), c(x_c), c(x_a)
+        self.ns, self.nc, self.ma, self.S = x_s.shape[0], x_c.shape[0], x_a.shape[0], int(S)
+        if tl_s.shape != x_s.shape or l_s.shape != x_s.shape:
+            raise ValueError("shape mismatch")
+        eng._check(eng._lib.bq_pair_create(eng._ctx, L.dptr(x_s), L.dptr(tl_s), L.dptr(l_s),
+                                           self.ns, L.dptr(x_c) if self.nc else None, self.nc,
+                                           L.dptr(x_a) if self.ma else None, self.ma, self.S,
+                                           C.byref(self._h)))
+
+    def close(self):
+        if self._h is not None and self._h.value and self._eng._ctx.value:
+            self._eng._lib.bq_pair_destroy(self._eng._ctx, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _params(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        if p.shape != (self.S, 3):
+            raise ValueError("parameters must be S x 3: (h, w, s) per set")
+        return p
+
+    def llh(self, p_tl, p_l):
+        """(llh[S], l_c[S, nc], status[S]); llh = -inf where status != 0."""
+        p_tl, p_l = self._params(p_tl), self._params(p_l)
+        llh = np.empty(self.S)
+        l_c = np.empty((self.S, self.nc))
+        status = np.zeros(self.S, dtype=np.int32)
+        e = self._eng
+        e._check(e._lib.bq_pair_llh(e._ctx, self._h, L.dptr(p_tl), L.dptr(p_l), L.dptr(llh),
+                                    L.dptr(l_c) if self.nc else None,
+                                    status.ctypes.data_as(L._i32p)))
+        return llh, l_c, status
+
+    def esm(self, p_tl, p_l, thresh, mu, cov):
+        """The acquisition's ingredients for every set and acquisition point: dict with A_a,
+        A_sc_l, status, tm_a, tC_a (all S x ma), l_c (S x nc), sstatus (S)."""
+        p_tl, p_l = self._params(p_tl), self._params(p_l)
+        mu, cov = Engine._mc(1, mu, cov)
+        S, ma = self.S, self.ma
+        out = {k: np.empty((S, ma)) for k in ("A_a", "A_sc_l", "tm_a", "tC_a")}
+        out["status"] = np.zeros((S, ma), dtype=np.int32)
+        out["l_c"] = np.empty((S, self.nc))
+        out["sstatus"] = np.zeros(S, dtype=np.int32)
+        e = self._eng
+        e._check(e._lib.bq_pair_esm(
+            e._ctx, self._h, L.dptr(p_tl), L.dptr(p_l), float(thresh), L.dptr(mu), L.dptr(cov),
+            L.dptr(out["A_a"]), L.dptr(out["A_sc_l"]), out["status"].ctypes.data_as(L._i32p),
+            L.dptr(out["tm_a"]), L.dptr(out["tC_a"]), L.dptr(out["l_c"]) if self.nc else None,
+            out["sstatus"].ctypes.data_as(L._i32p)))
+        return out
 
 
 class Plan(object):

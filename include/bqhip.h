@@ -246,6 +246,32 @@ int bq_esm_border(bq_ctx *ctx, bq_fit *gp_l, int64_t ns, const double *x_a, int6
 /* ---- resident batch pipeline (what bench.py times) ------------------ */
 /* A plan owns device copies of the inputs and all workspaces, so that a run
  * starts with everything resident in HBM and only enqueues kernels. */
+/* ---- the stacked pair of GPs at S hyper-parameter sets in one batched pass --------------
+ * bq.py:536-550, 933-965 (the hyper-parameter objective) and bq.py:604-662 (marginalize /
+ * choose_next over sampled hyper-parameters) evaluate one parameter set after the other; the
+ * sets are independent and run here as one batch.  GP1 is the GP over tl_s = log l_s at the
+ * samples x_s, GP2 the GP over [l_s, exp(mean of GP1 at x_c)] at [x_s, x_c].  A pair object
+ * keeps the points resident for S parameter sets; with ma > 0 acquisition points x_a it serves
+ * bq_pair_esm, with ma = 0 bq_pair_llh.  Parameters are S x 3 row-major: (h, w, s) per set. */
+typedef struct bq_pair bq_pair;
+int bq_pair_create(bq_ctx *ctx, const double *x_s, const double *tl_s, const double *l_s, int64_t ns,
+                   const double *x_c, int64_t nc, const double *x_a, int64_t ma, int64_t S,
+                   bq_pair **out);
+void bq_pair_destroy(bq_ctx *ctx, bq_pair *pair);
+/* llh[b] = log_lh(GP1) + log_lh(GP2) under set b, -inf where the reference's closure returns
+ * -inf (bq.py:542-548); status[b]: 0 ok, 1 GP1 not positive definite, 2 "GP mean is too large"
+ * (bq.py:945-947), 3 GP2 not positive definite.  l_c (S x nc, may be NULL): the candidates'
+ * values exp(mean) under every set. */
+int bq_pair_llh(bq_ctx *ctx, bq_pair *pair, const double *p_tl, const double *p_l, double *llh,
+                double *l_c, int32_t *status);
+/* the acquisition's ingredients (bq.py:447-527, bq_c.pyx:425-490) under every set b and for every
+ * acquisition point a (element b * ma + a): A_a, A_sc_l with status (1: singular bordered system,
+ * the fallback of bq.py:481-490), GP1's posterior mean / variance tm_a, tC_a; per set: l_c (S x nc,
+ * may be NULL) and sstatus (1: GP1 not positive definite, 2: GP mean too large). */
+int bq_pair_esm(bq_ctx *ctx, bq_pair *pair, const double *p_tl, const double *p_l, double thresh,
+                const double *mu, const double *cov, double *A_a, double *A_sc_l, int32_t *status,
+                double *tm_a, double *tC_a, double *l_c, int32_t *sstatus);
+
 typedef struct bq_plan bq_plan;
 int bq_plan_create(bq_ctx *ctx, int64_t nprob, int64_t d, int64_t n, int64_t M, bq_plan **out);
 void bq_plan_destroy(bq_ctx *ctx, bq_plan *plan);

@@ -64,8 +64,80 @@ class FitDouble(object):
         return (mean if want_mean else None), (var if want_var else None), cov
 
 
+MAX_LOG = float(np.log(np.exp2(np.float64(np.finfo(np.float64).maxexp - 4))))
+
+
+class PairDouble(object):
+    """The batched pair evaluators (engine.Pair) as plain loops over the oracle: one parameter
+    set after the other, exactly the reference's order of operations (bq.py:933-957)."""
+
+    def __init__(self, eng, x_s, tl_s, l_s, x_c, x_a, S):
+        self.eng, self.o = eng, eng.o
+        def f(a):
+            if a is None:
+                return np.empty(0)
+            return np.ascontiguousarray(np.atleast_1d(a), dtype=np.float64)
+
+        self.x_s, self.tl_s, self.l_s, self.x_c, self.x_a = f(x_s), f(tl_s), f(l_s), f(x_c), f(x_a)
+        self.ns, self.nc, self.ma, self.S = len(self.x_s), len(self.x_c), len(self.x_a), int(S)
+        self.x_sc = np.concatenate([self.x_s, self.x_c])
+
+    def close(self):
+        pass
+
+    def _stage1(self, p):
+        """GP1 under (h, w, s): (log-ML, l_c, mean / var at x_a, status)."""
+        try:
+            f1 = FitDouble(self.o, self.x_s, self.tl_s, p[0], p[1], p[2])
+        except np.linalg.LinAlgError:
+            return None, None, None, None, 1
+        xo = np.concatenate([self.x_c, self.x_a])
+        m, v, _ = f1.predict(xo) if xo.size else (np.empty(0), np.empty(0), None)
+        mc, vc = m[:self.nc], np.maximum(v[:self.nc], 0.0)
+        if ((mc + 2 * np.sqrt(vc)) > MAX_LOG).any():
+            return None, None, None, None, 2
+        return f1.logml, np.exp(mc), m[self.nc:], v[self.nc:], 0
+
+    def llh(self, p_tl, p_l):
+        llh = np.full(self.S, -np.inf)
+        l_c = np.zeros((self.S, self.nc))
+        status = np.zeros(self.S, dtype=np.int32)
+        for b in range(self.S):
+            lm1, lc, _, _, st = self._stage1(p_tl[b])
+            if st == 0:
+                l_c[b] = lc
+                try:
+                    f2 = FitDouble(self.o, self.x_sc, np.concatenate([self.l_s, lc]), *p_l[b])
+                    llh[b] = lm1 + f2.logml
+                except np.linalg.LinAlgError:
+                    st = 3
+            status[b] = st
+        return llh, l_c, status
+
+    def esm(self, p_tl, p_l, thresh, mu, cov):
+        S, ma = self.S, self.ma
+        out = {k: np.zeros((S, ma)) for k in ("A_a", "A_sc_l", "tm_a", "tC_a")}
+        out["status"] = np.zeros((S, ma), dtype=np.int32)
+        out["l_c"] = np.zeros((S, self.nc))
+        out["sstatus"] = np.zeros(S, dtype=np.int32)
+        for b in range(S):
+            _, lc, tm, tC, st = self._stage1(p_tl[b])
+            out["sstatus"][b] = st
+            if st:
+                continue
+            out["l_c"][b], out["tm_a"][b], out["tC_a"][b] = lc, tm, tC
+            A_a, A_sc_l, status = self.eng.esm_batch(
+                self.x_sc, np.concatenate([self.l_s, lc]), self.ns, self.x_a, p_l[b][0],
+                p_l[b][1], thresh, mu, cov)
+            out["A_a"][b], out["A_sc_l"][b], out["status"][b] = A_a, A_sc_l, status
+        return out
+
+
 class EngineDouble(object):
     device = 0
+
+    def pair(self, x_s, tl_s, l_s, x_c, x_a, S):
+        return PairDouble(self, x_s, tl_s, l_s, x_c, x_a, S)
 
     def __init__(self, oracle):
         self.o = oracle

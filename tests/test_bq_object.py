@@ -353,6 +353,99 @@ def test_marginalize_and_choose_next(pkg):
     assert bq.choose_next(x_a, 3, ["h", "w"]) in x_a
 
 
+def test_llh_batch_matches_closure(pkg):
+    """The batched objective (bq_pair_llh: all parameter sets in one device pass) against the
+    reference's closure evaluated set by set (bq.py:536-550), rejected and failing sets
+    included."""
+    npseed()
+    bq = make_bq(pkg)
+    params = ["h", "w"]
+    f = bq._make_llh_params(params)
+    fb = bq._make_llh_batch(params)
+    p0 = bq._current_params(params)
+    X = np.array([p0, p0 * 1.1, p0 * [0.7, 1.2, 1.5, 0.8], [15.0, -2.0, 0.2, 1.3],
+                  [np.nan, 2.0, 0.2, 1.3], [15.0, 200.0, 0.2, 1.3], [15.0, 2.0, 0.2, 150.0],
+                  p0 + [0, 1e-8, 0, 0]])
+    got = fb(X)
+    npseed()
+    bq2 = make_bq(pkg)
+    ref = np.array([bq2._make_llh_params(params)(x) for x in X])
+    assert (np.isinf(got) == np.isinf(ref)).all() and np.isinf(ref).sum() == 4
+    ok = np.isfinite(ref)
+    assert np.allclose(got[ok], ref[ok], rtol=1e-10, atol=0)
+    # the batched evaluation has no side effects on the GPs
+    assert (bq._current_params(params) == p0).all()
+    assert np.isfinite(f(p0))
+
+
+def test_fit_hypers_batched_gradient(pkg):
+    """fit_hypers hands scipy the 2-point gradient from ONE batched pass over the p + 1 points
+    scipy's own differencing would have visited (same points, same steps): the optimum it
+    reaches is the optimum of the sequential optimisation."""
+    from bayesian_quadrature_amd import util
+    npseed()
+    bq = make_bq(pkg)
+    params = ["h", "w"]
+    p0 = bq._current_params(params)
+    X, dx = util.fd_points(p0, 1e-8)
+    assert X.shape == (5, 4) and (X[0] == p0).all()
+    assert all((X[i + 1] != p0).sum() == 1 and X[i + 1, i] - p0[i] == dx[i] for i in range(4))
+    # the gradient itself: the batched pass against the closure called point by point
+    f = bq._make_llh_params(params)
+    fseq = np.array([-f(x) for x in X])
+    fbat = -bq._make_llh_batch(params)(X)
+    f(p0)
+    g_seq, g_bat = (fseq[1:] - fseq[0]) / dx, (fbat[1:] - fbat[0]) / dx
+    # (a difference of values that agree to rounding, divided by 1e-8: the two routes' gradients
+    # agree to the noise of either, ~1e-15 |f| cond / 1e-8)
+    assert np.abs(g_bat - g_seq).max() <= 2e-4 * max(1.0, np.abs(g_seq).max())
+    llh0 = f(p0)
+    seq = util.find_good_parameters(f, p0, "L-BFGS-B")
+    llh_seq = f(seq)
+    npseed()
+    bq2 = make_bq(pkg)
+    f2 = bq2._make_llh_params(params)
+    bat = util.find_good_parameters(f2, p0, "L-BFGS-B", logpdf_batch=bq2._make_llh_batch(params))
+    llh_bat = f2(bat)
+    # L-BFGS-B on finite-difference gradients stops anywhere on the flat top; both runs must
+    # have climbed most of the way the better one did
+    assert llh_seq > llh0 and llh_bat > llh0
+    best = max(llh_seq, llh_bat)
+    assert min(llh_seq, llh_bat) - llh0 > 0.5 * (best - llh0)
+    if type(bq._pair(5)).__name__ == "PairDouble":
+        # identical arithmetic on the CPU double: the very same optimisation
+        assert abs(llh_bat - llh_seq) < 1e-6 * abs(llh_seq)
+        assert np.allclose(bat, seq, rtol=5e-4)
+
+
+def test_choose_next_batched_vs_loop(pkg):
+    """choose_next evaluates the acquisition under all sampled hyper-parameter settings in one
+    batched pass; the reference (and ``marginalize``) loop over them (bq.py:604-662).  Same
+    random draws, same values, same choice, state restored."""
+    npseed()
+    bq = make_bq(pkg)
+    params = ["h", "w"]
+    x_a = np.sort(np.random.uniform(-10, 10, 12))
+    x_a[3] = bq.x_s[2] + 5e-5            # cannot move the mean: short-circuit per setting
+    x_a[7] = bq.x_c[0] + 0.1             # inside the jitter radius of a candidate
+    Z0 = bq.Z_mean()
+    rng = np.random.get_state()
+    loop = bq.marginalize([lambda: bq.expected_squared_mean(x_a)], 5, params)[0]
+    np.random.set_state(rng)
+    state = copy.deepcopy(bq.__getstate__())
+    tl, l = bq.sample_hypers(params, n=5, nburn=1)
+    batch = bq._esm_marginal(x_a, params, tl, l)
+    bq.__setstate__(state)
+    assert batch.shape == loop.shape == (5, 12)
+    assert np.allclose(batch, loop, rtol=1e-8, atol=0)
+    assert bq.Z_mean() == Z0
+    np.random.set_state(rng)
+    x1 = bq.choose_next(x_a, 5, params)
+    loss = (-loop).mean(axis=0)
+    assert x1 in x_a[np.isclose(loss, loss.min())]
+    assert bq.Z_mean() == Z0
+
+
 def test_out_of_scope_branches_raise(pkg):
     x = np.linspace(-3, 3, 5)
     bq = pkg.BQ(x, f_x(x), kernel=pkg.PeriodicKernel, **OPTIONS)

@@ -1080,3 +1080,89 @@ def test_cho_solve_mat_square_multi_block(engine, oracle):
     assert np.abs(A.dot(X) - B).max() < 1e-12 * n * np.abs(A).max() * np.abs(X).max()
     la.cho_solve_mat(L, B, B)   # aliased (linalg_c.pyx:171)
     assert (B == X).all()
+
+
+# ---- the stacked pair at many hyper-parameter sets (bq_pair_*) ----------------------------
+def _pair_problem(ns, nc, seed):
+    rs = np.random.RandomState(seed)
+    xs = np.linspace(-5, 5, ns)
+    dx = 10.0 / (ns - 1)
+    ls = np.exp(wl.norm_logpdf(xs))
+    xc = np.sort(rs.uniform(-6, 6, 6 * nc))
+    from bayesian_quadrature_amd import bq_c
+    bq_c.filter_candidates(xc, xs, 0.4 * dx)
+    xc = xc[~np.isnan(xc)][:nc]
+    return xs, ls, np.sort(xc), dx, rs
+
+
+@pytest.mark.parametrize("ns,nc,S", [(9, 3, 5), (60, 8, 7), (400, 12, 6)])
+def test_pair_llh_vs_oracle(engine, oracle, ns, nc, S):
+    """bq_pair_llh: the hyper-parameter objective (bq.py:536-550, 933-965) at S parameter sets
+    in one batched pass, against the oracle evaluated set by set; a set whose GP1 is singular
+    and one whose GP2 is singular come back as -inf with their status."""
+    from engine_double import EngineDouble
+    xs, ls, xc, dx, rs = _pair_problem(ns, nc, ns + S)
+    nc = xc.shape[0]
+    p_tl = np.column_stack([rs.uniform(8, 20, S), rs.uniform(1.0, 1.6, S) * dx, np.full(S, 1e-4)])
+    p_l = np.column_stack([rs.uniform(0.1, 0.4, S), rs.uniform(0.9, 1.3, S) * dx, np.zeros(S)])
+    p_tl[1, 1], p_tl[1, 2] = 400 * dx, 0.0      # GP1 numerically singular
+    p_l[2, 1] = 400 * dx                        # GP2 numerically singular
+    pair = engine.pair(xs, np.log(ls), ls, xc, None, S)
+    llh, l_c, status = pair.llh(p_tl, p_l)
+    ref = EngineDouble(oracle).pair(xs, np.log(ls), ls, xc, None, S).llh(p_tl, p_l)
+    assert status[1] == 1 and status[2] == 3 and (status[[0] + list(range(3, S))] == 0).all()
+    assert (status == ref[2]).all()
+    ok = status == 0
+    assert np.isinf(llh[~ok]).all() and (llh[~ok] < 0).all()
+    assert np.abs(llh[ok] - ref[0][ok]).max() <= RTOL * np.abs(ref[0][ok]).max()
+    good1 = status != 1
+    assert relmax(l_c[good1], ref[1][good1]) < 1e-9
+    # a second call with other parameters on the same object
+    llh2, _, st2 = pair.llh(p_tl[::-1].copy(), p_l[::-1].copy())
+    assert (st2 == status[::-1]).all()
+    assert np.abs(llh2[::-1][ok] - llh[ok]).max() <= 1e-12 * np.abs(llh[ok]).max()
+    pair.close()
+
+
+@pytest.mark.parametrize("ns,nc,S,M", [(9, 3, 4, 10), (60, 8, 5, 16), (300, 10, 3, 12)])
+def test_pair_esm_vs_per_set_route(engine, oracle, ns, nc, S, M):
+    """bq_pair_esm: GP1's posterior at the candidates and acquisition points, GP2's targets and
+    the S x M bordered systems of the acquisition in one batched pass, against the per-set route
+    (a resident fit per set + bq_esm_border / bq_gp_predict) and, for the small sizes, the
+    oracle's recipe."""
+    from engine_double import EngineDouble
+    xs, ls, xc, dx, rs = _pair_problem(ns, nc, 3 * ns + M)
+    nc = xc.shape[0]
+    assert nc >= 1
+    x_a = np.sort(np.concatenate([rs.uniform(-7, 7, M - 2), xc[:1] + 0.05, [0.5 * (xc[0] + xc[-1])]]))
+    p_tl = np.column_stack([rs.uniform(8, 20, S), rs.uniform(1.0, 1.3, S) * dx, np.full(S, 1e-4)])
+    p_l = np.column_stack([rs.uniform(0.1, 0.4, S), rs.uniform(0.9, 1.1, S) * dx, np.zeros(S)])
+    thresh = 0.5
+    pair = engine.pair(xs, np.log(ls), ls, xc, x_a, S)
+    r = pair.esm(p_tl, p_l, thresh, MU1, COV1)
+    assert (r["sstatus"] == 0).all() and (r["status"] == 0).all()
+    x_sc = np.concatenate([xs, xc])
+    for b in range(S):
+        f1 = engine.gp_fit(xs, np.log(ls), *p_tl[b])
+        m, v, _ = f1.predict(np.concatenate([xc, x_a]))
+        f1.close()
+        k0 = oracle.kernel_scale(1, p_tl[b, 0], [p_tl[b, 1]])
+        assert relmax(r["tm_a"][b], m[nc:]) < RTOL
+        assert np.abs(r["tC_a"][b] - v[nc:]).max() / k0 < RTOL
+        assert relmax(r["l_c"][b], np.exp(m[:nc])) < 1e-9
+        l_sc = np.concatenate([ls, r["l_c"][b]])
+        f2 = engine.gp_fit(x_sc, l_sc, p_l[b, 0], p_l[b, 1], 0.0)
+        A_a, A_sc_l, st = engine.esm_border(f2, ns, x_a, thresh, MU1, COV1)
+        f2.close()
+        K = oracle.gram_cross(x_sc, x_sc, p_l[b, 0], p_l[b, 1])
+        tol = max(1e-10, 50 * np.linalg.cond(K) * 2.2e-16)
+        scale = max(np.abs(A_a).max(), np.abs(A_sc_l).max())
+        assert (st == 0).all()
+        assert np.abs(r["A_a"][b] - A_a).max() <= tol * scale
+        assert np.abs(r["A_sc_l"][b] - A_sc_l).max() <= tol * scale
+        if ns <= 60:
+            ref = EngineDouble(oracle).esm_batch(x_sc, l_sc, ns, x_a, p_l[b, 0], p_l[b, 1], thresh,
+                                                 MU1, COV1)
+            assert np.abs(r["A_a"][b] - ref[0]).max() <= tol * scale
+            assert np.abs(r["A_sc_l"][b] - ref[1]).max() <= tol * scale
+    pair.close()
