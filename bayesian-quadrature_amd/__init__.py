@@ -13,6 +13,7 @@ from . import engine  # noqa: F401
 from . import linalg  # noqa: F401
 from . import linalg as la  # noqa: F401  (the reference's alias, bq.py:10)
 from .engine import Engine, get_engine, set_engine  # noqa: F401
+from .pool import EnginePool  # noqa: F401
 from .gp import GP, GaussianKernel, PeriodicKernel  # noqa: F401
 from . import gauss, bq_c, util  # noqa: F401
 from . import gauss as gauss_c  # noqa: F401  (the reference's module name)

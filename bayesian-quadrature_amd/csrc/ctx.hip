@@ -186,6 +186,7 @@ extern "C" int bq_ctx_sync(bq_ctx *c)
 {
     if (!c)
         return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return BQ_OK;
 }
@@ -291,6 +292,7 @@ extern "C" int bq_timer_start(bq_ctx *c)
 {
     if (!c)
         return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipEventRecord(c->t0, c->stream));
     return BQ_OK;
 }
@@ -299,6 +301,7 @@ extern "C" int bq_timer_stop_ms(bq_ctx *c, float *ms)
 {
     if (!c || !ms)
         return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipEventRecord(c->t1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->t1));
     HIPCHK(c, hipEventElapsedTime(ms, c->t0, c->t1));

@@ -232,6 +232,7 @@ extern "C" int bq_plan_run(bq_ctx *c, bq_plan *p)
         return fail(c, BQ_ERR_BAD_ARG, "null plan handle");
     if (!p->has_inputs)
         return fail(c, BQ_ERR_BAD_ARG, "plan has no inputs");
+    HIPCHK(c, hipSetDevice(c->device)); // (a context may be driven from any one thread)
     if (c->prof || !c->use_graph || !c->own_stream)
         return plan_enqueue(c, p);
     // settings that change the launch sequence invalidate the captured graph
@@ -277,6 +278,7 @@ extern "C" int bq_plan_results(bq_ctx *c, bq_plan *p, double *mean, double *var,
     if (!p)
         return fail(c, BQ_ERR_BAD_ARG, "null plan handle");
     const int nb = p->nprob, M = p->M;
+    HIPCHK(c, hipSetDevice(c->device));
     std::vector<double> scal((size_t)nb * 4);
     std::vector<int> info((size_t)nb);
     HIPCHK(c, hipMemcpyAsync(scal.data(), p->scal.p, sizeof(double) * 4 * nb,

@@ -114,6 +114,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the C3/C4 roofline runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nb", type=int, default=0, help="outer Cholesky block override")
+    ap.add_argument("--inproc", action="store_true",
+                    help="N > 1 in ONE process: an engine per device, a host thread each "
+                         "(EnginePool), nothing spawned")
     a = ap.parse_args()
     if a.workload is None:
         a.workload = "c2" if a.gpus == 1 else "c5"
@@ -615,33 +618,23 @@ def batched_configs(eng):
         plan.run()
     ms = eng.timer_stop_ms() / 3
     status = plan.results()[3]
-    dev, cls, _ = _prof_call(eng, plan.run, reps=2)
-    eng.profile(True)
-    eng.profile_reset()
-    plan.run()
-    pr = eng.profile_read()
-    eng.profile(False)
     plan.close()
     flops = B * (2048 ** 3 / 3.0)   # the factorisation alone, per problem N^3/3
     # the posterior's M N^2 (marginal variance through the forward sweep).  Round 1
     # and the first half of round 2 also executed and counted the M^2 N of the full posterior
     # covariance; the sweep no longer computes that block (plan_readout_kernel)
     post = B * (256.0 * 2048 * 2048)
-    sy = pr["syrk_trailing"]
-    out["c5_shard_64x2048"] = {"ms_per_batch": ms, "problems_per_s": B / ms * 1e3,
-                               "failed": int((status != 0).sum()),
-                               "potrf_tflops_lower_bound": flops / (ms * 1e-3) / 1e12,
-                               "tflops_incl_posterior": (flops + post) / (ms * 1e-3) / 1e12,
-                               "frac_incl_posterior":
-                                   (flops + post) / (ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
-                               "class_ms_sequential_events": cls,
-                               "dominant_kernel": {
-                                   "kernel": TRAILING_KERNEL, "bound": "mfma",
-                                   "achieved": sy["work"] / (max(sy["ms"], 1e-9) * 1e-3) / 1e12,
-                                   "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": sy["work"] / (max(sy["ms"], 1e-9) * 1e-3) / 1e12
-                                   / PEAK_FP64_TFLOPS,
-                                   "ms": sy["ms"], "launches": sy["launches"]}}
+    out["c5_shard_64x2048"] = {
+        "ms_per_batch": ms, "problems_per_s": B / ms * 1e3, "failed": int((status != 0).sum()),
+        "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_FP64_TFLOPS,
+        "achieved": (flops + post) / (ms * 1e-3) / 1e12,
+        "frac": (flops + post) / (ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
+        "algorithmic_flops": flops + post,
+        "potrf_tflops_lower_bound": flops / (ms * 1e-3) / 1e12,
+        "note": "wall-derived: (N^3/3 + M N^2) per problem over the HIP-event time of a "
+                "plan pass; the kernel classes of this shard and the MFMA utilisation of its "
+                "gemm_lds_kernel launches are in profiles/r03_c5_kernel_stats.csv and "
+                "profiles/r03_mfma_util.json"}
     # the headline problem, 256 independent copies per step: what batching buys over the
     # latency-bound single problem of `value`
     c2 = wl.c2()
@@ -657,8 +650,13 @@ def batched_configs(eng):
     ms2 = eng.timer_stop_ms() / 3
     st2 = plan.results()[3]
     plan.close()
+    fl2 = B2 * (1024 ** 3 / 3.0 + 256.0 * 1024 * 1024)
     out["c2_batch_256x1024"] = {"ms_per_batch": ms2, "problems_per_s": B2 / ms2 * 1e3,
-                                "failed": int((st2 != 0).sum())}
+                                "failed": int((st2 != 0).sum()), "bound": "mfma",
+                                "unit": "TFLOP/s", "peak": PEAK_FP64_TFLOPS,
+                                "achieved": fl2 / (ms2 * 1e-3) / 1e12,
+                                "frac": fl2 / (ms2 * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
+                                "algorithmic_flops": fl2}
     c3 = wl.c3()
     # one untimed chunk first: the first call pays the 100 x 128 MiB workspace allocation
     eng.logml_grid(c3["x"], c3["y"], c3["h"][:100], c3["w"][:100], c3["s"], chunk=100)
@@ -668,33 +666,93 @@ def batched_configs(eng):
         lm = eng.logml_grid(c3["x"], c3["y"], c3["h"], c3["w"], c3["s"], chunk=100)
         walls.append(time.perf_counter() - t0)
     wall = min(walls)
-    eng.profile(True)
-    eng.profile_reset()
-    eng.logml_grid(c3["x"], c3["y"], c3["h"][:100], c3["w"][:100], c3["s"], chunk=100)
-    pr = eng.profile_read()
-    eng.profile(False)
-    sy = pr["syrk_trailing"]
+    fl3 = len(lm) * (4096 ** 3 / 3.0)
     out["c3_grid_400x4096"] = {"wall_ms": wall * 1e3, "wall_ms_all": [w * 1e3 for w in walls],
-                               "class_ms_one_chunk_of_100": {k: v["ms"] for k, v in pr.items()
-                                                             if v["launches"]},
-                               "dominant_kernel": {
-                                   "kernel": TRAILING_KERNEL, "bound": "mfma",
-                                   "achieved": sy["work"] / (max(sy["ms"], 1e-9) * 1e-3) / 1e12,
-                                   "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": sy["work"] / (max(sy["ms"], 1e-9) * 1e-3) / 1e12
-                                   / PEAK_FP64_TFLOPS,
-                                   "ms": sy["ms"], "launches": sy["launches"]},
+                               "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_FP64_TFLOPS,
+                               "achieved": fl3 / wall / 1e12,
+                               "frac": fl3 / wall / 1e12 / PEAK_FP64_TFLOPS,
+                               "algorithmic_flops": fl3,
                                "ms_per_point": wall * 1e3 / len(lm),
                                "n_minus_inf": int(np.isinf(lm).sum()),
-                               "potrf_tflops_lower_bound": len(lm) * (4096 ** 3 / 3.0) / wall / 1e12,
-                               "note": "host wall clock incl. the upload of the 400 parameter "
-                                       "sets and the read-back of the 400 results"}
+                               "note": "wall-derived: N^3/3 per grid point over the host wall "
+                                       "clock incl. the upload of the 400 parameter sets and the "
+                                       "read-back of the 400 results; kernel classes of one chunk "
+                                       "in profiles/r03_c3_kernel_stats.csv"}
     return out
+
+
+def inproc_main(a):
+    """--gpus N --inproc: the second launch mode ("one Python thread per device").
+    This process creates the N contexts itself -- an EnginePool, one host thread per engine --
+    and every engine passes over its own block of problems; the threads meet at a barrier
+    before and after the timed region, the time is first start to last end."""
+    import threading
+    import ctypes as C
+    from bayesian_quadrature_amd import EnginePool, _lib as L_
+    ndev = C.c_int(0)
+    L_.load_library().bq_device_count(C.byref(ndev))
+    share = os.environ.get("BQ_BENCH_SHARE_DEVICE", "0") == "1"
+    if ndev.value <= 0 or (ndev.value < a.gpus and not share):
+        print("bench.py: --gpus %d --inproc needs %d HIP devices, this box has %d"
+              % (a.gpus, a.gpus, ndev.value), file=sys.stderr)
+        sys.exit(2)
+    pool = EnginePool([r % ndev.value for r in range(a.gpus)])
+    barrier = threading.Barrier(a.gpus)
+
+    def job(rank):
+        def run(eng):
+            wk = make_workload(a.workload, a.batch, rank)
+            plan = eng.plan(wk["B"], wk["d"], wk["n"], wk["M"])
+            plan.set_inputs(wk["x"], wk["y"], wk["xo"], wk["h"], wk["w"], wk["s"])
+            for _ in range(a.warmup):
+                plan.run()
+            eng.sync()
+            barrier.wait()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                plan.run()
+            eng.sync()
+            t1 = time.perf_counter()
+            barrier.wait()
+            mean, var, logml, status = plan.results()
+            plan.close()
+            return dict(rank=rank, device=eng.device, t0=t0, t1=t1, wk=wk, mean=mean, var=var,
+                        logml=logml, status=status, info=eng.info() if rank == 0 else None)
+        return run
+
+    res = pool.run([job(r) for r in range(a.gpus)])
+    pool.close()
+    wall = max(r["t1"] for r in res) - min(r["t0"] for r in res)
+    wk = res[0]["wk"]
+    nfail = int(sum((r["status"] != 0).sum() for r in res))
+    units = a.steps * wk["B"] * a.gpus
+    line = {
+        "metric": "bq_fit_posterior_throughput", "value": units / wall, "unit": "problems/s",
+        "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": wk["desc"], "problems_per_gpu_per_step": wk["B"],
+                   "sharding": "independent problems per device, no data-path collective",
+                   "launch_mode": "inproc: one process, an engine and a host thread per device",
+                   "ranks": [{"rank": r["rank"], "device": r["device"],
+                              "ms_per_step": (r["t1"] - r["t0"]) / a.steps * 1e3} for r in res]},
+        "failed_problems": nfail, "device": res[0]["info"],
+        "parity": parity_spotcheck(wk, res[0]),
+    }
+    p = line["parity"]
+    if not (p["mean_rel"] < 1e-10 and p["var_rel_prior"] < 1e-10 and p["logml_rel"] < 1e-10) \
+            or nfail:
+        line["value"] = None
+        line["invalid"] = "parity check failed"
+    print(json.dumps(line))
+    sys.exit(0 if line["value"] is not None else 1)
 
 
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world == 1 and a.inproc:
+        inproc_main(a)  # does not return
     if a.gpus > 1 and world == 1:
         self_launch(a)  # does not return
     if a.gpus != world:

@@ -168,3 +168,101 @@ def test_bench_launches_its_own_ranks(engine):
     assert len({r_["pid"] for r_ in ranks}) == 2
     assert line["single_rank_reference"]["ms_per_step"] > 0
     assert line["parity"]["logml_rel"] < 1e-10
+
+
+def test_engine_pool_partitions_and_propagates_errors(oracle):
+    """EnginePool's host logic on the CPU: contiguous blocks per worker, results in item
+    order, exceptions re-raised -- with oracle-backed doubles in place of device engines."""
+    from bayesian_quadrature_amd import pool as pool_mod
+    from bayesian_quadrature_amd import workloads as wl
+    from engine_double import EngineDouble
+
+    class FakeEngine(EngineDouble):
+        def __init__(self, device):
+            EngineDouble.__init__(self, oracle)
+            self.device = device
+            self.seen = []
+
+        def logml_grid(self, x, y, h, w, s=0.0, chunk=0):
+            self.seen.append(len(h))
+            return EngineDouble.logml_grid(self, x, y, h, w, s, chunk)
+
+        def close(self):
+            pass
+
+    real = pool_mod.Engine
+    pool_mod.Engine = FakeEngine
+    try:
+        with pool_mod.EnginePool([0, 0, 0]) as pool:
+            assert len(pool) == 3
+            c = wl.c5([0], n=40, m=5)
+            h = np.linspace(0.5, 2.0, 7)
+            w = np.full(7, float(c["w"][0]) * 10)
+            lm = pool.logml_grid(c["x"][0], c["y"][0], h, w, 0.01)
+            ref = EngineDouble(oracle).logml_grid(c["x"][0], c["y"][0], h, w[:, None], 0.01)
+            assert np.array_equal(lm, ref)
+            assert sorted(n for wk in pool._workers for n in wk.engine.seen) == [2, 2, 3]
+            c5 = wl.c5(list(range(4)), n=40, m=5)
+            got = pool.batch_fit_predict(c5["x"], c5["y"], c5["h"], c5["w"] * 10, c5["s"], c5["xo"])
+            one = EngineDouble(oracle).batch_fit_predict(c5["x"], c5["y"], c5["h"], c5["w"] * 10,
+                                                         c5["s"], c5["xo"])
+            assert all(np.array_equal(a, b) for a, b in zip(got, one))
+            with pytest.raises(ZeroDivisionError):
+                pool.run([lambda e: 1, lambda e: 1 // 0, lambda e: 3])
+            assert pool.run([lambda e: e.device] * 3) == [0, 0, 0]   # still alive afterwards
+    finally:
+        pool_mod.Engine = real
+
+
+@pytest.mark.gpu
+def test_engine_pool_two_contexts_one_process(engine, oracle):
+    """One process, an engine + host thread per device (here: two contexts on device 0, the
+    one-GPU box's rehearsal of SURVEY 8e's "one Python thread per device"): a log-ML grid, a
+    batch of problems and an acquisition sweep partitioned over the pool equal what a single
+    context computes."""
+    from bayesian_quadrature_amd import EnginePool
+    from bayesian_quadrature_amd import workloads as wl
+    ndev = engine.device_count()
+    with EnginePool([0, 1 % ndev]) as pool:
+        c = wl.c5(list(range(7)), n=300, m=40)
+        got = pool.batch_fit_predict(c["x"], c["y"], c["h"], c["w"] * 10, c["s"], c["xo"])
+        one = engine.batch_fit_predict(c["x"], c["y"], c["h"], c["w"] * 10, c["s"], c["xo"])
+        assert (got[3] == 0).all()
+        for a, b in zip(got[:3], one[:3]):
+            assert np.max(np.abs(a - b)) <= 1e-12 * np.max(np.abs(b))
+        c3 = wl.c3(side=16, gh=4, gw=3)
+        lm = pool.logml_grid(c3["x"], c3["y"], c3["h"], c3["w"], c3["s"])
+        lm1 = engine.logml_grid(c3["x"], c3["y"], c3["h"], c3["w"], c3["s"])
+        assert np.max(np.abs(lm - lm1) / np.abs(lm1)) <= 1e-12
+        xs = np.linspace(-5, 5, 40)
+        x_sc = np.concatenate([xs, [-5.6, 5.7]])
+        l_sc = np.exp(wl.norm_logpdf(x_sc))
+        x_a = np.linspace(-7, 7, 11) + 0.013
+        mu, cov = np.array([0.0]), np.array([[10.0]])
+        a = pool.esm_batch(x_sc, l_sc, 40, x_a, 0.2, 0.3, 0.5, mu, cov)
+        b = engine.esm_batch(x_sc, l_sc, 40, x_a, 0.2, 0.3, 0.5, mu, cov)
+        assert (a[2] == b[2]).all()
+        assert np.allclose(a[0], b[0], rtol=1e-12, atol=0) and np.allclose(a[1], b[1], rtol=1e-12, atol=0)
+        # the two workers really ran concurrently-capable: distinct contexts, distinct threads
+        import threading
+        names = pool.run([lambda e: threading.current_thread().name] * 2)
+        assert len(set(names)) == 2
+
+
+@pytest.mark.gpu
+def test_bench_inproc_mode(engine):
+    """``bench.py --gpus 2 --inproc``: the parent creates both contexts itself and spawns
+    nothing; loud failure without a second device, shared-device rehearsal otherwise."""
+    import json
+    ndev = engine.device_count()
+    args = ["--gpus", "2", "--inproc", "--steps", "2", "--warmup", "1", "--batch", "2"]
+    if ndev < 2:
+        r = _run_bench(args, {})
+        assert r.returncode != 0 and "needs 2 HIP devices" in r.stderr
+    r = _run_bench(args, {"BQ_BENCH_SHARE_DEVICE": "1"} if ndev < 2 else {})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 2 and line["value"] is not None and line["failed_problems"] == 0
+    assert line["config"]["launch_mode"].startswith("inproc")
+    assert sorted(r_["rank"] for r_ in line["config"]["ranks"]) == [0, 1]
+    assert line["parity"]["logml_rel"] < 1e-10
