@@ -620,25 +620,15 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C
 #define BQ_L64_STAGE (16 * BQ_LDS_ROW)
 #define BQ_L64_BYTES (2 * BQ_L64_STAGE)
 
+// the workgroup tile (bx, by); C, P, Q point at the batch element
 template <bool QT>
-__global__ __launch_bounds__(256, 4) void gemm_lds64_kernel(double *__restrict__ C, long ldc,
-                                                            long cstride,
-                                                            const double *__restrict__ P, long ldp,
-                                                            long pstride,
-                                                            const double *__restrict__ Q, long ldq,
-                                                            long qstride, int m, int n, int k,
-                                                            int lower, int ncut)
+__device__ __forceinline__ void gemm_lds64_body(unsigned char *smem, double *__restrict__ C,
+                                                long ldc, const double *__restrict__ P, long ldp,
+                                                const double *__restrict__ Q, long ldq, int m,
+                                                int n, int k, int lower, int ncut, int bx, int by)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.z;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (lower == 2)
-        tri_decode(blockIdx.x, bx, by);
-    C += (long)b * cstride;
-    P += (long)b * pstride;
-    Q += (long)b * qstride;
     const int R0 = bx * 64, C0 = by * 64;
     if (C0 >= ncut)
         return; // (the whole workgroup, before any barrier)
@@ -743,6 +733,24 @@ __global__ __launch_bounds__(256, 4) void gemm_lds64_kernel(double *__restrict__
     ct.store_neg(acc, lower);
 }
 
+template <bool QT>
+__global__ __launch_bounds__(256, 4) void gemm_lds64_kernel(double *__restrict__ C, long ldc,
+                                                            long cstride,
+                                                            const double *__restrict__ P, long ldp,
+                                                            long pstride,
+                                                            const double *__restrict__ Q, long ldq,
+                                                            long qstride, int m, int n, int k,
+                                                            int lower, int ncut)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.z;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (lower == 2)
+        tri_decode(blockIdx.x, bx, by);
+    gemm_lds64_body<QT>(smem, C + (long)b * cstride, ldc, P + (long)b * pstride, ldp,
+                        Q + (long)b * qstride, ldq, m, n, k, lower, ncut, bx, by);
+}
+
 
 // ---------------------------------------------------------------------------
 // C (m x n) -= P (m x k) Q for the SMALL products of the row sweeps over a resident factor
@@ -821,12 +829,10 @@ __global__ __launch_bounds__(256) void gemm_splitk_kernel(double *__restrict__ C
 // 16 x 16 block w.  grid (rows / 32, a.ny + b.ny).
 // ---------------------------------------------------------------------------
 // (struct RowsJob: types.h)
-__global__ __launch_bounds__(256) void rows_step_kernel(RowsJob ja, RowsJob jb)
+// one 32 x 32 tile (bx, by) of a job; red: 32 KiB of LDS
+__device__ __forceinline__ void rows_job_tile(const RowsJob &j, int bx, int by,
+                                              double (*red)[4][4][64])
 {
-    __shared__ double red[4][4][4][64];
-    const bool first = (int)blockIdx.y < ja.ny;
-    const RowsJob &j = first ? ja : jb;
-    const int by = first ? blockIdx.y : blockIdx.y - ja.ny;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -841,7 +847,7 @@ __global__ __launch_bounds__(256) void rows_step_kernel(RowsJob ja, RowsJob jb)
         // a 16-column chunk lies in one of the two operand pairs (k1 is a multiple of 16)
         const bool p1 = ks < j.k1;
         const int kk = p1 ? ks : ks - j.k1;
-        const double *pp = (p1 ? j.P1 : j.P2) + (long)blockIdx.x * 32 + l15 +
+        const double *pp = (p1 ? j.P1 : j.P2) + (long)bx * 32 + l15 +
                            (long)(kk + l4) * (p1 ? j.ldp1 : j.ldp2);
         const long qsj = p1 ? j.qsj1 : j.qsj2, qsk = p1 ? j.qsk1 : j.qsk2;
         const long ldp = p1 ? j.ldp1 : j.ldp2;
@@ -872,8 +878,7 @@ __global__ __launch_bounds__(256) void rows_step_kernel(RowsJob ja, RowsJob jb)
                 red[wave][2 * jb2 + ib][r][lane] = acc[jb2][ib][r];
     __syncthreads();
     const int jq = wave >> 1, iq = wave & 1;
-    double *cp = j.C + (long)blockIdx.x * 32 + 16 * iq + l15 +
-                 ((long)by * 32 + 16 * jq + l4) * j.ldc;
+    double *cp = j.C + (long)bx * 32 + 16 * iq + l15 + ((long)by * 32 + 16 * jq + l4) * j.ldc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const double s = (red[0][wave][r][lane] + red[1][wave][r][lane]) +
@@ -883,4 +888,37 @@ __global__ __launch_bounds__(256) void rows_step_kernel(RowsJob ja, RowsJob jb)
         else
             cp[(long)(4 * r) * j.ldc] -= s;
     }
+}
+
+__global__ __launch_bounds__(256) void rows_step_kernel(RowsJob ja, RowsJob jb)
+{
+    __shared__ double red[4][4][4][64];
+    const bool first = (int)blockIdx.y < ja.ny;
+    rows_job_tile(first ? ja : jb, blockIdx.x, first ? blockIdx.y : blockIdx.y - ja.ny, red);
+}
+
+// ---------------------------------------------------------------------------
+// One step of the row sweep over a LARGE resident factor in one launch: the small, latency-
+// bound product of the step (job `ja`, the diagonal block's solve with the T_J / U_J coupling:
+// 32 x 32 split-k tiles as in rows_step_kernel) in the first nd workgroups, and the previous
+// block's solution applied to everything beyond (C -= P Q^T on the 64 x 64 LDS-staged tiles of
+// gemm_lds64_kernel) in the rest.  The two depend on the previous step only, not on each other;
+// in one grid the short job's workgroups are dispatched first and finish beside the update's --
+// on a stream of their own they waited for slots behind them.  grid (nd + (m / 64) (n / 64)).
+// ---------------------------------------------------------------------------
+template <bool QT>
+__global__ __launch_bounds__(256, 4) void rows_fused_kernel(RowsJob ja, int nd, int ndx,
+                                                            double *__restrict__ C, long ldc,
+                                                            const double *__restrict__ P, long ldp,
+                                                            const double *__restrict__ Q, long ldq,
+                                                            int m, int n, int k)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int bid = blockIdx.x;
+    if (bid < nd) {
+        rows_job_tile(ja, bid % ndx, bid / ndx, reinterpret_cast<double (*)[4][4][64]>(smem));
+        return;
+    }
+    const int tix = bid - nd, mt = m / 64;
+    gemm_lds64_body<QT>(smem, C, ldc, P, ldp, Q, ldq, m, n, k, 0, 0x7fffffff, tix % mt, tix / mt);
 }

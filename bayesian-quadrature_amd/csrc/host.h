@@ -281,6 +281,8 @@ int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const dou
 int launch_gemm_rows(bq_ctx *c, int cls, double *C, long ldc, const double *P, long ldp,
                      const double *Q, long qsj, long qsk, int m, int n, int k);
 int launch_rows_step(bq_ctx *c, int mrows, const RowsJob &a, const RowsJob &b, double work);
+int launch_rows_fused(bq_ctx *c, int mrows, const RowsJob &a, double *C, long ldc, const double *P,
+                      long ldp, const double *Q, long ldq, int n, int k, bool qt, double work);
 
 // ---- k_reduce.hip ---------------------------------------------------------------------
 int launch_finalize(bq_ctx *c, const double *A, long lda, long astride, Layout L, double *scal,

@@ -13,6 +13,10 @@ int gemm_init(bq_ctx *c)
                                   hipFuncAttributeMaxDynamicSharedMemorySize, BQ_L64_BYTES));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lds64_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, BQ_L64_BYTES));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(rows_fused_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, BQ_L64_BYTES));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(rows_fused_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, BQ_L64_BYTES));
     return BQ_OK;
 }
 
@@ -161,6 +165,25 @@ int launch_gemm_rows(bq_ctx *c, int cls, double *C, long ldc, const double *P, l
         return BQ_OK;
     }
     return launch_gemm(c, cls, C, ldc, 0, P, ldp, 0, Q, qsj, qsk, 0, m, n, k, 0, 1);
+}
+
+// one step of the row sweep over a large resident factor in one launch (rows_fused_kernel):
+// job a in 32 x 32 split-k tiles + C(m x n) -= P(m x k) Q^T in 64 x 64 LDS-staged tiles
+// (qt: Q k-contiguous, Q(j, k) at Q[j ldq + k]; else Q(j, k) at Q[j + k ldq])
+int launch_rows_fused(bq_ctx *c, int mrows, const RowsJob &a, double *C, long ldc, const double *P,
+                      long ldp, const double *Q, long ldq, int n, int k, bool qt, double work)
+{
+    Bracket br(c, BQ_K_GEMM, work);
+    const int ndx = mrows / 32, nd = ndx * a.ny;
+    const int nu = (n > 0 && k > 0) ? (mrows / 64) * (n / 64) : 0;
+    if (qt)
+        hipLaunchKernelGGL(rows_fused_kernel<true>, dim3(nd + nu), dim3(256), BQ_L64_BYTES, c->cur,
+                           a, nd, ndx, C, ldc, P, ldp, Q, ldq, mrows, n, k);
+    else
+        hipLaunchKernelGGL(rows_fused_kernel<false>, dim3(nd + nu), dim3(256), BQ_L64_BYTES, c->cur,
+                           a, nd, ndx, C, ldc, P, ldp, Q, ldq, mrows, n, k);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
 }
 
 // one forward step of the row sweep over a resident factor in one launch (rows_step_kernel)

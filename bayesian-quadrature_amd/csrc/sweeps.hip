@@ -159,13 +159,78 @@ int enqueue_forward_rows_blk(bq_ctx *c, double *X, long ldx, int mrows, const do
     return BQ_OK;
 }
 
+// whether the one-launch steps of rows_step_kernel (32 x 32 split-k tiles for everything) serve
+// a row sweep: systems too small to give 64 x 64 LDS-staged tiles half a chip of workgroups
+static bool rows_small(const bq_ctx *c, int mrows, int npad, const WideInv &w)
+{
+    return (mrows % 32) == 0 && (w.B % 64) == 0 &&
+           (long)(mrows / 32) * (npad / 32) <= 4L * c->cus &&
+           ((mrows % 64) != 0 || !c->gemm_lds64 || (long)(mrows / 64) * (npad / 64) < c->cus / 2);
+}
+
+// A large system's sweep, one launch per step (rows_fused_kernel).  With T_J = W_J L[J, J-B]
+// (forward; U_J = L[J+B, J] W_J backward) a step's small product -- the diagonal block's solve,
+//     Y_J = X_J W_J^T - Y_{J-B} T_J^T,
+// latency-bound -- and its big one -- Y_{J-B} applied to everything beyond block J, MFMA-bound --
+// depend on the PREVIOUS step only, not on each other: they share a launch, and a step costs
+// the longer of the two instead of their sum plus a launch gap.  (On two streams with events
+// the small product waited for workgroup slots behind the big one: slower than in sequence.)
+static int rows_fused(bq_ctx *c, bool forward, double *Xin, double *Xout, long ldx, int mrows,
+                      const double *L, long ldl, int npad, const WideInv &w)
+{
+    const int last = (npad - 1) / w.B * w.B;
+    for (int step = 0; step * w.B < npad; ++step) {
+        const int J = forward ? step * w.B : last - step * w.B;
+        const int bJ = std::min(w.B, npad - J);
+        const int Jp = forward ? J - w.B : J + w.B; // the block solved one step earlier
+        const bool first = step == 0;
+        const int bp = first ? 0 : std::min(w.B, npad - Jp);
+        RowsJob a{};
+        a.C = Xout + (long)J * ldx;
+        a.ldc = ldx;
+        a.P1 = Xin + (long)J * ldx;
+        a.ldp1 = ldx;
+        a.Q1 = (forward ? w.nt : w.nr) + (size_t)J * w.B;
+        a.qsj1 = 1;
+        a.qsk1 = w.B;
+        a.k1 = bJ;
+        a.ny = bJ / 32;
+        a.write = 1;
+        // (an unused second pair points at valid memory: k2 = 0 never dereferences it)
+        a.P2 = a.P1, a.Q2 = a.Q1, a.ldp2 = ldx, a.qsj2 = 1, a.qsk2 = w.B;
+        double *Cu = Xin;
+        const double *Pu = Xin, *Qu = L;
+        long ldq = ldl;
+        int nu = 0;
+        if (!first) {
+            a.P2 = Xout + (long)Jp * ldx;
+            a.k2 = bp;
+            Pu = a.P2;
+            if (forward) {
+                a.Q2 = w.t + (size_t)J * w.B; // T_J (bJ x B), rows contiguous
+                nu = npad - J - bJ;           // Xin[:, J + bJ:] -= Y_Jp L[J + bJ:, Jp ..)^T
+                Cu = Xin + (long)(J + bJ) * ldx;
+                Qu = L + J + bJ + (long)Jp * ldl;
+            } else {
+                a.Q2 = w.uu + (size_t)J * w.B; // U_J (bp x B): Q2(j, k) = U_J[k, j]
+                a.qsj2 = w.B;
+                a.qsk2 = 1;
+                nu = J;                        // Xin[:, 0:J] -= Z_Jp L[Jp .., 0:J]  (Q k-contiguous)
+                Qu = L + Jp;
+            }
+        }
+        BQCHK(launch_rows_fused(c, mrows, a, Cu, ldx, Pu, ldx, Qu, ldq, nu, bp, !forward,
+                                2.0 * mrows * ((double)bJ * (a.k1 + a.k2) + (double)nu * bp)));
+    }
+    return BQ_OK;
+}
+
 // Xout <- Xin L^-T; Xin is overwritten with partial sums
 int enqueue_forward_rows(bq_ctx *c, double *Xin, double *Xout, long ldx, int mrows,
                          const double *L, long ldl, int npad, WideInv w)
 {
     // small systems: one launch per step (rows_step_kernel), every entry of Xout written
-    if ((mrows % 32) == 0 && (w.B % 64) == 0 &&
-        (long)(mrows / 32) * (npad / 32) <= 4L * c->cus) {
+    if (rows_small(c, mrows, npad, w)) {
         for (int J = 0; J < npad; J += w.B) {
             const int bJ = std::min(w.B, npad - J), rest = npad - J - bJ;
             RowsJob a{}, b{};
@@ -205,6 +270,8 @@ int enqueue_forward_rows(bq_ctx *c, double *Xin, double *Xout, long ldx, int mro
         }
         return BQ_OK;
     }
+    if (c->gemm_lds64 && (mrows % 64) == 0 && (w.B % 64) == 0 && (ldl & 1) == 0)
+        return rows_fused(c, true, Xin, Xout, ldx, mrows, L, ldl, npad, w);
     HIPCHK(c, hipMemsetAsync(Xout, 0, sizeof(double) * (size_t)ldx * npad, c->cur));
     for (int J = 0; J < npad; J += w.B) {
         const int bJ = std::min(w.B, npad - J);
@@ -220,10 +287,13 @@ int enqueue_forward_rows(bq_ctx *c, double *Xin, double *Xout, long ldx, int mro
     return BQ_OK;
 }
 
-// Xout (zeroed here) <- Xin L^-1 (the L^T sweep of dpotrs in row form); Xin is overwritten
+// Xout <- Xin L^-1 (the L^T sweep of dpotrs in row form); Xin is overwritten
 int enqueue_backward_rows(bq_ctx *c, double *Xin, double *Xout, long ldx, int mrows,
                           const double *L, long ldl, int npad, WideInv w)
 {
+    if (!rows_small(c, mrows, npad, w) && c->gemm_lds64 && (mrows % 64) == 0 &&
+        (w.B % 64) == 0 && (ldl & 1) == 0)
+        return rows_fused(c, false, Xin, Xout, ldx, mrows, L, ldl, npad, w);
     HIPCHK(c, hipMemsetAsync(Xout, 0, sizeof(double) * (size_t)ldx * npad, c->cur));
     const int last = (npad - 1) / w.B * w.B;
     for (int J = last; J >= 0; J -= w.B) {
