@@ -893,8 +893,11 @@ __device__ __forceinline__ void rows_job_tile(const RowsJob &j, int bx, int by,
 __global__ __launch_bounds__(256) void rows_step_kernel(RowsJob ja, RowsJob jb)
 {
     __shared__ double red[4][4][4][64];
-    const bool first = (int)blockIdx.y < ja.ny;
-    rows_job_tile(first ? ja : jb, blockIdx.x, first ? blockIdx.y : blockIdx.y - ja.ny, red);
+    // (two calls: selecting the argument struct dynamically parks a copy of it in scratch)
+    if ((int)blockIdx.y < ja.ny)
+        rows_job_tile(ja, blockIdx.x, blockIdx.y, red);
+    else
+        rows_job_tile(jb, blockIdx.x, blockIdx.y - ja.ny, red);
 }
 
 // ---------------------------------------------------------------------------
