@@ -26,7 +26,12 @@
  * tests/test_gauss_c.py).  log_lh is pinned through its argmax: the printed
  * E[Z] / V(Z) of docs/ipynb/gaussian-example.ipynb after fit_hypers(['h','w'])
  * (tests/test_bq_object.py::test_gaussian_example_notebook, six printed
- * digits).  The noise form s^2 I has no printed value anywhere in the
+ * digits).  The variance chain (L_tl, the quadratic form of bq_c.pyx:264-355)
+ * is pinned to 12 digits by the printed E[Z] = 1.81816144454e-05 /
+ * V(Z) = 4.95413041126e-09 of docs/ipynb/active-sampling-example.ipynb's first
+ * step (tests/test_bq_object.py::test_active_sampling_example_notebook; the
+ * later steps of that notebook depend on libc rand() and the optimiser's path
+ * and are not reproducible).  The noise form s^2 I has no printed value anywhere in the
  * reference (every fixture has s = 0): for s != 0 parity is UNPINNED (see
  * DESIGN.md).
  *
