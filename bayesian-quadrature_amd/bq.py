@@ -316,17 +316,22 @@ class BQ(object):
 
     def sample_hypers(self, params, n=1, nburn=10):
         """Slice-sample new hyper-parameters for both GPs; returns the samples for
-        GP1 and GP2 (bq.py:565-598).  The GPs are left at the last evaluated point."""
+        GP1 and GP2 (bq.py:565-598).  The GPs are left at the last evaluated point.  The chain
+        is the reference's, draw for draw; its log-pdf requests are evaluated several at a time
+        in batched device passes (util._slice_sample_batched)."""
         nparam = len(params)
         window = 2 * nparam
         p0 = self._current_params(params)
         f = self._make_llh_params(params)
         if f(p0) < MIN:
-            pn = util.find_good_parameters(f, p0, self.options["optim_method"])
+            pn = util.find_good_parameters(f, p0, self.options["optim_method"],
+                                           logpdf_batch=self._make_llh_batch(params))
             if pn is None:
                 raise RuntimeError("couldn't find good starting parameters")
             p0 = pn
-        hypers = util.slice_sample(f, nburn + n, window, p0, nburn=nburn, freq=1)
+        hypers = util.slice_sample(f, nburn + n, window, p0, nburn=nburn, freq=1,
+                                   logpdf_batch=self._make_llh_batch(params))
+        f(hypers[-1])  # the chain's last evaluated point, as the sequential sampler leaves it
         return hypers[:, :nparam], hypers[:, nparam:]
 
     # --------------------------------------------------------- active sampling

@@ -31,6 +31,28 @@ __global__ __launch_bounds__(256) void pair_targets_kernel(const double *__restr
     y2[(long)b * ystride + i] = v;
 }
 
+// One record per parameter set for a single read-back of bq_pair_llh:
+// out[b * (5 + nc) + {0..4}] = log-ML of GP1, log-ML of GP2, GP1's failure flag, GP2's, the
+// overflow flag; then the nc candidate values.  grid (S), block 64.
+__global__ void pair_collect_kernel(const double *__restrict__ scal1,
+                                    const double *__restrict__ scal2,
+                                    const int *__restrict__ info1, const int *__restrict__ info2,
+                                    const int *__restrict__ flag, const double *__restrict__ y2,
+                                    long ystride, int ns, int nc, double *__restrict__ out)
+{
+    const int b = blockIdx.x;
+    double *o = out + (long)b * (5 + nc);
+    if (threadIdx.x == 0) {
+        o[0] = scal1[4 * b];
+        o[1] = scal2[4 * b];
+        o[2] = (double)info1[b];
+        o[3] = (double)info2[b];
+        o[4] = (double)flag[b];
+    }
+    for (int i = threadIdx.x; i < nc; i += blockDim.x)
+        o[5 + i] = y2[(long)b * ystride + ns + i];
+}
+
 // int K_b(x_i, x) N(x | mu, sigma^2) dx = h_b^2 N(x_i | mu, w_b^2 + sigma^2) for the 1-D kernels of
 // S parameter sets (gauss_c.pyx:95-164 with d = 1): out[b * n + i].  par[b] = {h^2, 1 / sqrt(C),
 // -(log 2 pi + log C) / 2} with C = w^2 + sigma^2, the host's GaussForm<1> of int_K_kernel.

@@ -23,7 +23,24 @@ struct bq_pair {
     bq_plan *p1 = nullptr; // GP1: n = ns, M = nc + ma
     bq_plan *p2 = nullptr; // GP2: n = nsc, M = 0 (the objective; the acquisition has its own systems)
     DevBuf l_s, x_sc, x_a, y2, flag;
+    // stage 2 of bq_pair_esm, kept between calls (choose_next calls it once per step with the
+    // same shapes; allocating and releasing its tens of GB per call costs more than the pass)
+    DevBuf gpd, pard, ik, ika, dj1, dj2, Ad, dinv, info, outd, panel;
+    int64_t chunk = 0;
     std::vector<double> hx_s, hx_c, hx_a;
+    // bq_pair_llh runs hundreds of times per optimisation / chain on tiny systems, where the
+    // host's share of a pass matters: parameters go up from PINNED staging (asynchronous for
+    // real), results come back as one record per set
+    GaussParams *hpar = nullptr; // 2 S (pinned)
+    double *hres = nullptr;      // S (5 + nc) (pinned)
+    DevBuf dres;
+    ~bq_pair()
+    {
+        if (hpar)
+            (void)hipHostFree(hpar);
+        if (hres)
+            (void)hipHostFree(hres);
+    }
 };
 
 namespace {
@@ -130,6 +147,12 @@ extern "C" int bq_pair_create(bq_ctx *c, const double *x_s, const double *tl_s, 
         H(pr->flag.alloc(sizeof(int) * S));
         if (ma)
             H(pr->y2.alloc(sizeof(double) * (size_t)S * nsc));
+        else {
+            H(pr->dres.alloc(sizeof(double) * (size_t)S * (5 + nc)));
+            H(hipHostMalloc(reinterpret_cast<void **>(&pr->hpar), sizeof(GaussParams) * 2 * S));
+            H(hipHostMalloc(reinterpret_cast<void **>(&pr->hres),
+                            sizeof(double) * (size_t)S * (5 + nc)));
+        }
     }
     if (st == BQ_OK) {
         H(hipMemcpyAsync(pr->l_s.p, l_s, sizeof(double) * ns, hipMemcpyHostToDevice, c->stream));
@@ -179,39 +202,41 @@ extern "C" int bq_pair_llh(bq_ctx *c, bq_pair *pr, const double *p_tl, const dou
     BQCHK(check_params(c, p_tl, S, "pair_llh (GP1)"));
     BQCHK(check_params(c, p_l, S, "pair_llh (GP2)"));
     HIPCHK(c, hipSetDevice(c->device));
-    BQCHK(run_stage1(c, pr, p_tl, pr->p2->y.d(), pr->p2->L.npad));
-    std::vector<double> h((size_t)S), w((size_t)S), s((size_t)S);
+    const int ns = pr->ns, nc = pr->nc;
+    // both plans' kernel parameters from pinned staging
     for (int b = 0; b < S; ++b) {
-        h[(size_t)b] = p_l[3 * b];
-        w[(size_t)b] = p_l[3 * b + 1];
-        s[(size_t)b] = p_l[3 * b + 2];
+        const double w1[1] = {p_tl[3 * b + 1]}, w2[1] = {p_l[3 * b + 1]};
+        pr->hpar[b] = make_params(1, p_tl[3 * b], w1, p_tl[3 * b + 2]);
+        pr->hpar[S + b] = make_params(1, p_l[3 * b], w2, p_l[3 * b + 2]);
     }
-    BQCHK(plan_set_params(c, pr->p2, h.data(), w.data(), s.data()));
+    HIPCHK(c, hipMemcpyAsync(pr->p1->gp.p, pr->hpar, sizeof(GaussParams) * S,
+                             hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(pr->p2->gp.p, pr->hpar + S, sizeof(GaussParams) * S,
+                             hipMemcpyHostToDevice, c->stream));
+    BQCHK(bq_plan_run(c, pr->p1));
+    HIPCHK(c, hipMemsetAsync(pr->flag.p, 0, sizeof(int) * S, c->stream));
+    const long ms = std::max(nc, 1), ys = pr->p2->L.npad;
+    hipLaunchKernelGGL(pair_targets_kernel, dim3((nsc + 255) / 256, S), dim3(256), 0, c->stream,
+                       pr->l_s.d(), ns, nc, pr->p1->mean.d(), pr->p1->var.d(), ms, max_log(),
+                       pr->p2->y.d(), ys, pr->flag.i());
+    HIPCHK(c, hipGetLastError());
     BQCHK(bq_plan_run(c, pr->p2));
-    std::vector<double> s1((size_t)S * 4), s2((size_t)S * 4), y2;
-    std::vector<int> i1((size_t)S), i2((size_t)S), fl((size_t)S);
-    HIPCHK(c, hipMemcpyAsync(s1.data(), pr->p1->scal.p, sizeof(double) * 4 * S,
+    hipLaunchKernelGGL(pair_collect_kernel, dim3(S), dim3(64), 0, c->stream, pr->p1->scal.d(),
+                       pr->p2->scal.d(), pr->p1->info.i(), pr->p2->info.i(), pr->flag.i(),
+                       pr->p2->y.d(), ys, ns, nc, pr->dres.d());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(pr->hres, pr->dres.p, sizeof(double) * (size_t)S * (5 + nc),
                              hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(s2.data(), pr->p2->scal.p, sizeof(double) * 4 * S,
-                             hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(i1.data(), pr->p1->info.p, sizeof(int) * S, hipMemcpyDeviceToHost,
-                             c->stream));
-    HIPCHK(c, hipMemcpyAsync(i2.data(), pr->p2->info.p, sizeof(int) * S, hipMemcpyDeviceToHost,
-                             c->stream));
-    HIPCHK(c, hipMemcpyAsync(fl.data(), pr->flag.p, sizeof(int) * S, hipMemcpyDeviceToHost,
-                             c->stream));
-    if (l_c && pr->nc)
-        HIPCHK(c, hipMemcpy2DAsync(l_c, sizeof(double) * pr->nc, pr->p2->y.d() + pr->ns,
-                                   sizeof(double) * pr->p2->L.npad, sizeof(double) * pr->nc, S,
-                                   hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    (void)nsc;
     for (int b = 0; b < S; ++b) {
-        const int st = i1[(size_t)b] ? 1 : (fl[(size_t)b] ? 2 : (i2[(size_t)b] ? 3 : 0));
+        const double *r = pr->hres + (size_t)b * (5 + nc);
+        const int st = r[2] != 0.0 ? 1 : (r[4] != 0.0 ? 2 : (r[3] != 0.0 ? 3 : 0));
         if (status)
             status[b] = st;
-        llh[b] = st ? -std::numeric_limits<double>::infinity()
-                    : s1[(size_t)b * 4] + s2[(size_t)b * 4];
+        llh[b] = st ? -std::numeric_limits<double>::infinity() : r[0] + r[1];
+        if (l_c)
+            for (int i = 0; i < nc; ++i)
+                l_c[(size_t)b * nc + i] = r[5 + i];
     }
     return BQ_OK;
 }
@@ -268,10 +293,30 @@ extern "C" int bq_pair_esm(bq_ctx *c, bq_pair *pr, const double *p_tl, const dou
     const int64_t E = (int64_t)S * ma;
     const size_t per = sizeof(double) * ((size_t)lda * L.ntot + panel_ws_doubles(L.ntot, 1) +
                                          BQ_DINV_STRIDE + 2) + sizeof(int);
-    size_t freeb = 0, totalb = 0;
-    HIPCHK(c, hipMemGetInfo(&freeb, &totalb));
-    int64_t chunk = std::max<int64_t>(1, (int64_t)((freeb / 2) / per));
-    chunk = std::min<int64_t>(std::min<int64_t>(chunk, E), 32768);
+    if (pr->chunk == 0) {
+        size_t freeb = 0, totalb = 0;
+        HIPCHK(c, hipMemGetInfo(&freeb, &totalb));
+        int64_t ch = std::max<int64_t>(1, (int64_t)((freeb / 2) / per));
+        ch = std::min<int64_t>(std::min<int64_t>(ch, E), 32768);
+        HIPCHK(c, pr->gpd.alloc(sizeof(GaussParams) * S));
+        HIPCHK(c, pr->pard.alloc(sizeof(double) * 3 * S));
+        HIPCHK(c, pr->ik.alloc(sizeof(double) * (size_t)S * nsc));
+        HIPCHK(c, pr->ika.alloc(sizeof(double) * (size_t)E));
+        HIPCHK(c, pr->dj1.alloc(sizeof(double) * (size_t)E));
+        HIPCHK(c, pr->dj2.alloc(sizeof(double) * (size_t)E));
+        HIPCHK(c, pr->Ad.alloc(sizeof(double) * (size_t)lda * L.ntot * (size_t)ch));
+        HIPCHK(c, pr->dinv.alloc(sizeof(double) * BQ_DINV_STRIDE * (size_t)ch));
+        HIPCHK(c, pr->panel.alloc(panel_ws_useful(c, L.ntot, (int)ch)
+                                      ? sizeof(double) * panel_ws_doubles(L.ntot, (int)ch)
+                                      : 0));
+        HIPCHK(c, pr->info.alloc(sizeof(int) * (size_t)ch));
+        HIPCHK(c, pr->outd.alloc(sizeof(double) * 2 * (size_t)ch));
+        pr->chunk = ch;
+    }
+    const int64_t chunk = pr->chunk;
+    DevBuf &gpd = pr->gpd, &pard = pr->pard, &ik = pr->ik, &ika = pr->ika, &dj1 = pr->dj1,
+           &dj2 = pr->dj2, &Ad = pr->Ad, &dinv = pr->dinv, &info = pr->info, &outd = pr->outd,
+           &panel = pr->panel;
     // per set: kernel parameters of GP2 (no noise term), the closed form of int K p;
     // per element: the jitter exactly as two successive improve_covariance_conditioning calls
     // produce it (bq.py:470-476)
@@ -295,20 +340,6 @@ extern "C" int bq_pair_esm(bq_ctx *c, bq_pair *pr, const double *p_tl, const dou
             j2[(size_t)b * ma + a] = std::max(eps, gps[(size_t)b].c + first) * 1e-4;
         }
     }
-    DevBuf gpd, pard, ik, ika, dj1, dj2, Ad, dinv, info, outd, panel;
-    HIPCHK(c, gpd.alloc(sizeof(GaussParams) * S));
-    HIPCHK(c, pard.alloc(sizeof(double) * 3 * S));
-    HIPCHK(c, ik.alloc(sizeof(double) * (size_t)S * nsc));
-    HIPCHK(c, ika.alloc(sizeof(double) * (size_t)E));
-    HIPCHK(c, dj1.alloc(sizeof(double) * (size_t)E));
-    HIPCHK(c, dj2.alloc(sizeof(double) * (size_t)E));
-    HIPCHK(c, Ad.alloc(sizeof(double) * (size_t)lda * L.ntot * (size_t)chunk));
-    HIPCHK(c, dinv.alloc(sizeof(double) * BQ_DINV_STRIDE * (size_t)chunk));
-    HIPCHK(c, panel.alloc(panel_ws_useful(c, L.ntot, (int)chunk)
-                              ? sizeof(double) * panel_ws_doubles(L.ntot, (int)chunk)
-                              : 0));
-    HIPCHK(c, info.alloc(sizeof(int) * (size_t)chunk));
-    HIPCHK(c, outd.alloc(sizeof(double) * 2 * (size_t)chunk));
     HIPCHK(c, hipMemcpyAsync(gpd.p, gps.data(), sizeof(GaussParams) * S, hipMemcpyHostToDevice,
                              c->stream));
     HIPCHK(c, hipMemcpyAsync(pard.p, par.data(), sizeof(double) * 3 * S, hipMemcpyHostToDevice,

@@ -105,12 +105,111 @@ def _slice_sample(samples, logpdf, xval, w, verbose=False):
                 right = loc
 
 
-def slice_sample(logpdf, niter, w, xval, nburn=1, freq=1):
+def _slice_sample_batched(samples, logpdf_batch, xval, w, spec=4):
+    """The same chain as ``_slice_sample`` -- the same random draws in the same order, the same
+    comparisons -- with the log-pdf evaluated in BATCHES of ``spec + 2`` points per device pass.
+
+    The sequential sampler spends at least four dependent evaluations per state: the current
+    point, the two ends of the window, one proposal or more.  What it will ask for next is
+    largely known in advance: the current point's value is the accepted proposal's; both ends are
+    always needed; and the shrinkage proposals depend on the random draws and on the SIGN of the
+    rejected ones only, not on their values -- so the next ``spec`` proposals can be read off a
+    copy of the generator without disturbing it.  One pass evaluates the ends and those proposals
+    together; the chain then runs as written and finds (almost) every value it asks for in the
+    cache.  A window that has to step out, or more than ``spec`` rejections, costs further
+    passes; never a different result."""
+    n, d = samples.shape
+    S = spec + 2
+    cache = {}
+
+    def fetch(x0, direction, ts):
+        """one pass: the values at x0 + t direction for the listed t (padded to S points)"""
+        ts = [t for t in ts if t not in cache][:S]
+        if not ts:
+            return
+        pad = ts + [ts[0]] * (S - len(ts))
+        X = np.array([x0 + t * direction for t in pad])
+        vals = np.asarray(logpdf_batch(X), dtype=np.float64)
+        for t, v in zip(ts, vals):
+            cache[t] = float(v)
+
+    def peek(left, right, k):
+        """the next k shrinkage proposals if every one of them is rejected"""
+        rs = np.random.RandomState()
+        rs.set_state(np.random.get_state())
+        out = []
+        for _ in range(k):
+            if (right - left) < 1e-9:
+                break
+            loc = rs.uniform(left, right)
+            out.append(loc)
+            if loc < 0:
+                left = loc
+            else:
+                right = loc
+        return out
+
+    xpr = float(np.asarray(logpdf_batch(np.repeat(samples[0][None, :], S, axis=0)))[0])
+    i = 0
+    while i < n - 1:
+        if xpr == -np.inf:
+            raise RuntimeError("zero probability encountered")
+        x0 = samples[i]
+        yval = np.random.uniform(0, np.exp(xpr))
+        logyval = np.log(yval) if yval > 0 else -np.inf
+        direction = np.random.rand(d) - 0.5
+        direction /= np.linalg.norm(direction)
+        left, right = -w, w
+        cache.clear()
+        cache[0.0] = xpr
+
+        def val(t, ahead=()):
+            if t not in cache:
+                fetch(x0, direction, [t] + list(ahead))
+            return cache[t]
+
+        # both ends and, should neither have to move, the first proposals: one pass
+        fetch(x0, direction, [left, right] + peek(left, right, spec))
+        def steps(t, dw, k):
+            """the next k positions of a window end that keeps stepping out (as it will add them)"""
+            out = []
+            for _ in range(k):
+                t = t + dw
+                out.append(t)
+            return out
+
+        for _ in range(101):
+            if val(left, steps(left, -w, 2) + [right] + steps(right, w, 2)) < logyval:
+                break
+            left -= w
+        for _ in range(101):
+            if val(right, steps(right, w, spec + 1)) < logyval:
+                break
+            right += w
+        while True:
+            if (right - left) < 1e-9:
+                break  # window collapsed: redraw the slice height at the same point
+            loc = np.random.uniform(left, right)
+            samples[i + 1] = x0 + loc * direction
+            nl, nr = (loc, right) if loc < 0 else (left, loc)
+            v = val(loc, peek(nl, nr, spec + 1) if loc not in cache else ())
+            if v > logyval:
+                i += 1
+                xpr = v
+                break
+            left, right = nl, nr
+
+
+def slice_sample(logpdf, niter, w, xval, nburn=1, freq=1, logpdf_batch=None):
     """Draw ``niter`` states starting at ``xval``; drops the first ``nburn`` and
-    keeps every ``freq``-th of the rest."""
+    keeps every ``freq``-th of the rest.  ``logpdf_batch`` (S x d array -> S values): evaluate
+    the chain's requests in batched device passes (``_slice_sample_batched``)."""
     xval = np.asarray(xval, dtype=np.float64)
     samples = np.empty((niter, xval.size))
     samples[0] = xval
     verbose = (logger.level != 0) and (logger.level < 10)
-    _slice_sample(samples, logpdf, xval, float(w), verbose)
+    if logpdf_batch is not None:
+        _slice_sample_batched(samples, logpdf_batch, xval, float(w))
+    else:
+        _slice_sample(samples, logpdf, xval, float(w), verbose)
     return samples[nburn:][::freq]

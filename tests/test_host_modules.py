@@ -235,6 +235,40 @@ def test_slice_sample_uniform():
     assert (np.abs(hist - 1) < 0.05).all()
 
 
+@pytest.mark.parametrize("w", [0.3, 1.5, 6.0])
+def test_slice_sample_batched_is_the_same_chain(w):
+    """The batched sampler (several log-pdf requests per pass: both ends of the window and the
+    next shrinkage proposals, read off a copy of the generator) produces the sequential sampler's
+    chain draw for draw -- narrow windows that must step out, wide ones that shrink many times,
+    a hard wall -- and leaves the generator in the same state; it needs far fewer passes."""
+    from bayesian_quadrature_amd import util
+    calls = {"seq": 0, "bat": 0}
+
+    def logpdf(x):
+        calls["seq"] += 1
+        if x[1] > 2.5:
+            return -np.inf
+        return float(-0.5 * (x[0] ** 2 + 2.0 * (x[1] - 0.5) ** 2 + 0.3 * x[0] * x[1] + x[2] ** 2))
+
+    def logpdf_batch(X):
+        calls["bat"] += 1
+        assert X.shape == (6, 3)
+        return np.array([logpdf(x) for x in X])
+
+    np.random.seed(11)
+    seq = util.slice_sample(logpdf, 300, w, xval=np.zeros(3), nburn=5)
+    after_seq = np.random.uniform()
+    nseq, calls["seq"] = calls["seq"], 0
+    np.random.seed(11)
+    bat = util.slice_sample(logpdf, 300, w, xval=np.zeros(3), nburn=5, logpdf_batch=logpdf_batch)
+    assert np.array_equal(seq, bat)
+    assert np.random.uniform() == after_seq
+    assert calls["bat"] < (0.45 if w > 1 else 0.55) * nseq
+    with pytest.raises(RuntimeError):
+        util.slice_sample(None, 5, 1.0, xval=np.zeros(3),
+                          logpdf_batch=lambda X: np.full(len(X), -np.inf))
+
+
 def test_slice_sample_zero_probability_start():
     from bayesian_quadrature_amd import util
     with pytest.raises(RuntimeError):

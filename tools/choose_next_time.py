@@ -15,13 +15,14 @@ from bayesian_quadrature_amd import workloads as wl  # noqa: E402
 params = ["h", "w"]
 for ns in (20, 1000):
     np.random.seed(8728)
-    x = np.linspace(-5, 5, ns)
+    # ns = 20: the reference fixture's regime (spacing ~1, w_tl = 2, w_l = 1.3: tests/util.py:43)
+    x = np.linspace(-10, 10, ns) if ns == 20 else np.linspace(-5, 5, ns)
     dx = 10.0 / (ns - 1)
     b = bqa.BQ(x, np.exp(wl.norm_logpdf(x)), n_candidate=10, x_mean=0.0, x_var=10.0,
-               candidate_thresh=0.2 if ns == 20 else 0.003, kernel=bqa.GaussianKernel,
+               candidate_thresh=0.5 if ns == 20 else 0.003, kernel=bqa.GaussianKernel,
                optim_method="L-BFGS-B")
     if ns == 20:
-        b.init(params_tl=(15.0, 1.0, 0.0), params_l=(0.2, 0.7, 0.0))
+        b.init(params_tl=(15.0, 2.0, 0.0), params_l=(0.2, 1.3, 0.0))
     else:
         b.init(params_tl=(15.0, 1.3 * dx, 1e-3), params_l=(0.2, 1.3 * dx, 0.0))
     x_a = np.sort(np.random.uniform(-10, 10, 20))
@@ -61,6 +62,24 @@ for ns in (20, 1000):
         t0 = time.perf_counter()
         b.choose_next(x_a, n, params)
         t_cn = time.perf_counter() - t0
+        # the slice sampler alone: the reference's sequential chain against the same chain with
+        # its log-pdf requests batched (identical draws)
+        from bayesian_quadrature_amd import util
+        f, fb = b._make_llh_params(params), b._make_llh_batch(params)
+        p0 = b._current_params(params)
+        res = {}
+        for mode in ("sequential", "batched"):
+            np.random.seed(5)
+            f(p0)
+            t0 = time.perf_counter()
+            hy = util.slice_sample(f, n + 1, 2 * len(params), p0, nburn=1,
+                                   logpdf_batch=fb if mode == "batched" else None)
+            res[mode] = (time.perf_counter() - t0, hy)
+        f(p0)
+        same = np.abs(res["sequential"][1] - res["batched"][1]).max()
+        print("      slice sampler, %d states: sequential %.1f ms, batched %.1f ms (%.1fx), chains "
+              "differ by %.1e" % (n, res["sequential"][0] * 1e3, res["batched"][0] * 1e3,
+                                  res["sequential"][0] / res["batched"][0], same), flush=True)
     print("ns=%d nc=%d: slice sampling of %d settings %.1f ms; acquisition under them: loop %.1f ms, "
           "batched %.1f ms (%.1fx), max rel diff %.1e; whole choose_next %.1f ms"
           % (ns, b.nc, n, t_sample * 1e3, t_loop * 1e3, t_batch * 1e3, t_loop / t_batch, err,
