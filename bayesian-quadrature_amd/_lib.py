@@ -96,6 +96,7 @@ SIGNATURES = {
                               _i32p]),
     "bq_probe_hbm": (C.c_int, [_vp, C.c_size_t, _dp, _dp]),
     "bq_probe_hbm_read8": (C.c_int, [_vp, C.c_size_t, _i64, _dp]),
+    "bq_probe_gemm": (C.c_int, [_vp, _i64, _i64, _i64, C.c_int, _i64, C.c_int, _i64, _dp]),
     "bq_probe_mfma_variant": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     "bq_probe_mfma444_layout": (C.c_int, [_vp, C.c_int, C.c_int, _i32p]),
     "bq_probe_rsq": (C.c_int, [_vp, _dp, _i64, _dp]),

@@ -549,6 +549,9 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C
 #define BQ_LDS_READ_Q(BUF_, ST_, TN_, QF)                                                          \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) QF[s] = *reinterpret_cast<const double *>(       \
         qview[s] + (BUF_) * BQ_LDS_STAGE + (ST_) * 4 * BQ_LDS_ROW + (TN_) * 128);
+#define BQ_LDS_LANDED(QF, PF)                                                                      \
+    asm volatile("" ::"v"(QF[0]), "v"(QF[1]), "v"(QF[2]), "v"(QF[3]), "v"(PF[0]), "v"(PF[1]),      \
+                 "v"(PF[2]), "v"(PF[3]));
 #define BQ_LDS_CHUNK(BUF_, CH_)                                                                    \
     {                                                                                              \
         __syncthreads();                                                                           \
@@ -560,6 +563,11 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C
             _Pragma("unroll") for (int j = 0; j < 16; ++j)                                         \
             {                                                                                      \
                 const int st = j >> 2, tn = j & 3;                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                 \
+                /* the fragments of THIS sub-step are waited for here, before the next ones are  */ \
+                /* requested: hipcc waits with lgkmcnt(0) whatever is in flight, and placed after */ \
+                /* the new requests that wait exposed their full latency every sub-step           */ \
+                BQ_LDS_LANDED(qf[j & 1], pf[st & 1])                                               \
                 __builtin_amdgcn_sched_barrier(0);                                                 \
                 if (j < 15)                                                                        \
                     BQ_LDS_READ_Q(BUF_, (j + 1) >> 2, (j + 1) & 3, qf[(j + 1) & 1])                \
@@ -587,6 +595,7 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C
     }
 #undef BQ_LDS_READ_P
 #undef BQ_LDS_READ_Q
+#undef BQ_LDS_LANDED
 #undef BQ_LDS_CHUNK
 #undef BQ_LDS_FILL
 
@@ -696,6 +705,11 @@ __device__ __forceinline__ void gemm_lds64_body(unsigned char *smem, double *__r
             _Pragma("unroll") for (int j = 0; j < 8; ++j)                                          \
             {                                                                                      \
                 const int st = j >> 1, tn = j & 1;                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                 \
+                /* (this sub-step's fragments are waited for BEFORE the next are requested:       */ \
+                /* see gemm_lds_kernel)                                                            */ \
+                asm volatile("" ::"v"(qf[j & 1][0]), "v"(qf[j & 1][1]), "v"(qf[j & 1][2]),         \
+                             "v"(qf[j & 1][3]), "v"(pf[st & 1][0]), "v"(pf[st & 1][1]));           \
                 __builtin_amdgcn_sched_barrier(0);                                                 \
                 if (j < 7)                                                                         \
                     BQ_L64_READ_Q(BUF_, (j + 1) >> 1, (j + 1) & 1, qf[(j + 1) & 1])                \

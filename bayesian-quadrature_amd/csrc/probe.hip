@@ -106,6 +106,37 @@ extern "C" int bq_probe_hbm_read8(bq_ctx *c, size_t bytes, int64_t reps, double 
     return BQ_OK;
 }
 
+// C (m x n) -= P (m x k) Q (n x k)^T on scratch operands through launch_gemm (the engine's own
+// kernel selection): average ms over `reps` back-to-back launches.  qt: Q given k-contiguous.
+extern "C" int bq_probe_gemm(bq_ctx *c, int64_t m, int64_t n, int64_t k, int lower, int64_t batch,
+                             int qt, int64_t reps, double *ms_out)
+{
+    if (!c || !ms_out || m < 16 || n < 16 || k < 8 || batch < 1 || reps < 1)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf C, P, Q;
+    const long ldc = m, ldp = m, ldq = qt ? k : n;
+    HIPCHK(c, C.alloc(sizeof(double) * (size_t)ldc * n * batch));
+    HIPCHK(c, P.alloc(sizeof(double) * (size_t)ldp * k * batch));
+    HIPCHK(c, Q.alloc(sizeof(double) * (size_t)n * k * batch));
+    HIPCHK(c, hipMemsetAsync(C.p, 0, C.bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(P.p, 0, P.bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(Q.p, 0, Q.bytes, c->stream));
+    auto run = [&]() {
+        return launch_gemm(c, BQ_K_GEMM, C.d(), ldc, ldc * n, P.d(), ldp, ldp * k, Q.d(),
+                           qt ? ldq : 1, qt ? 1 : ldq, (long)n * k, (int)m, (int)n, (int)k, lower,
+                           (int)batch);
+    };
+    BQCHK(run());
+    float ms = 0;
+    BQCHK(bq_timer_start(c));
+    for (int64_t i = 0; i < reps; ++i)
+        BQCHK(run());
+    BQCHK(bq_timer_stop_ms(c, &ms));
+    *ms_out = ms / (double)reps;
+    return BQ_OK;
+}
+
 // kind 0: v_mfma_f64_16x16x4_f64, 1: v_mfma_f64_4x4x4_4b_f64; nacc in {1,2,4,8};
 // blocks_per_cu 256-thread blocks per CU (= waves per SIMD)
 extern "C" int bq_probe_mfma_variant(bq_ctx *c, int kind, int nacc, int blocks_per_cu,

@@ -412,6 +412,14 @@ class Engine(object):
                                                  C.cast(C.byref(v), _dp)))
         return float(v.value)
 
+    def probe_gemm(self, m, n, k, lower=0, batch=1, qt=False, reps=20):
+        """ms per launch of C (m x n) -= P Q^T (k columns) through the engine's kernel selection."""
+        v = C.c_double()
+        self._check(self._lib.bq_probe_gemm(self._ctx, int(m), int(n), int(k), int(lower),
+                                            int(batch), 1 if qt else 0, int(reps),
+                                            C.cast(C.byref(v), _dp)))
+        return float(v.value)
+
     def probe_launch(self, n=2000):
         v = C.c_double()
         self._check(self._lib.bq_probe_launch(self._ctx, int(n), C.cast(C.byref(v), _dp)))

@@ -294,6 +294,11 @@ int bq_probe_mfma_f64(bq_ctx *ctx, double *tflops);
 int bq_probe_fma_f64(bq_ctx *ctx, double *tflops);
 /* streaming fp64 write / copy bandwidth in GB/s over `bytes` */
 int bq_probe_hbm(bq_ctx *ctx, size_t bytes, double *write_gbs, double *copy_gbs);
+/* C (m x n) -= P (m x k) Q (n x k)^T on scratch operands through the engine's own kernel
+ * selection (lower: only the lower trapezoid; qt: Q given k-contiguous): average ms over `reps`
+ * back-to-back launches -- the tuning probe behind tools/gemm_probe.py */
+int bq_probe_gemm(bq_ctx *ctx, int64_t m, int64_t n, int64_t k, int lower, int64_t batch, int qt,
+                  int64_t reps, double *ms);
 /* `reps` read-only passes over `bytes` with 8-byte-per-lane loads, 512 contiguous bytes per
  * wave (the access pattern of the single-vector sweeps): a known byte count for calibrating
  * the profiler's FETCH_SIZE counter on that pattern; read_gbs may be NULL */
