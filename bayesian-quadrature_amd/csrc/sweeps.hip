@@ -163,9 +163,12 @@ int enqueue_forward_rows_blk(bq_ctx *c, double *X, long ldx, int mrows, const do
 // a row sweep: systems too small to give 64 x 64 LDS-staged tiles half a chip of workgroups
 static bool rows_small(const bq_ctx *c, int mrows, int npad, const WideInv &w)
 {
+    // (with 256-column steps -- npad < 2048 -- the split-k tiles stay ahead: the posterior at
+    // 1000 points over N = 1024 takes 77 us with them, 90 us with the fused large-system steps)
     return (mrows % 32) == 0 && (w.B % 64) == 0 &&
            (long)(mrows / 32) * (npad / 32) <= 4L * c->cus &&
-           ((mrows % 64) != 0 || !c->gemm_lds64 || (long)(mrows / 64) * (npad / 64) < c->cus / 2);
+           ((mrows % 64) != 0 || !c->gemm_lds64 || npad < 2048 ||
+            (long)(mrows / 64) * (npad / 64) < c->cus / 2);
 }
 
 // A large system's sweep, one launch per step (rows_fused_kernel).  With T_J = W_J L[J, J-B]
