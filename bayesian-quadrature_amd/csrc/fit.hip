@@ -21,7 +21,14 @@ static int fit_factor(bq_ctx *c, bq_fit *f, double *pm = nullptr, double *pv = n
     f->have_alpha = false;
     f->have_wide = false;
     f->have_dw = false;
-    HIPCHK(c, hipMemcpyAsync(f->gp.p, &f->g, sizeof f->g, hipMemcpyHostToDevice, c->stream));
+    // pinned staging: [0, 136) results, then the kernel parameters, then border points
+    constexpr size_t HF_PAR = 8 + 128, HF_PTS = HF_PAR + (sizeof(GaussParams) + 7) / 8;
+    if (!f->hfit)
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&f->hfit),
+                                sizeof(double) * (HF_PTS + 64 * BQ_MAXD)));
+    std::memcpy(f->hfit + HF_PAR, &f->g, sizeof f->g);
+    HIPCHK(c, hipMemcpyAsync(f->gp.p, f->hfit + HF_PAR, sizeof f->g, hipMemcpyHostToDevice,
+                             c->stream));
     double *scratch = f->dinv.d() + f->npad;
     FirstStep fs;
     const bool fuse = sweep_is_slab(c, ntot, f->npad, 1, f->panel.bytes / sizeof(double));
@@ -40,7 +47,7 @@ static int fit_factor(bq_ctx *c, bq_fit *f, double *pm = nullptr, double *pv = n
                                 f->panel.d(), f->panel.bytes / sizeof(double), fuse));
     BQCHK(launch_finalize(c, f->A.d(), f->ldl, 0L, f->L, scal, pm, pv, 64L, 1));
     // one read-back: misc = [info (int, 8 bytes) | pad | scal[4] | pad | mean[64] | var[64]]
-    double hm[8 + 128];
+    double *hm = f->hfit;
     HIPCHK(c, hipMemcpyAsync(hm, f->misc.p, sizeof(double) * (hpost ? 8 + 128 : 6),
                              hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -106,6 +113,9 @@ int fit_vec(bq_ctx *c, bq_fit *f)
 {
     if (f->vec.bytes < sizeof(double) * 2 * (size_t)f->npad)
         HIPCHK(c, f->vec.alloc(sizeof(double) * 2 * (size_t)f->npad));
+    if (!f->hvec)
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&f->hvec),
+                                sizeof(double) * (size_t)f->npad));
     return BQ_OK;
 }
 
@@ -265,8 +275,15 @@ extern "C" int bq_gp_refit_predict(bq_ctx *c, bq_fit *f, double h, const double 
         f->w[k] = w[k];
     f->g = make_params(f->d, h, w, s);
     f->L = make_layout(f->n, (int)M, true); // same ntot: the points share the y row's block
-    HIPCHK(c, hipMemcpyAsync(f->pts.d() + (size_t)f->d * f->npad, xo, sizeof(double) * f->d * M,
-                             hipMemcpyHostToDevice, c->stream));
+    {
+        constexpr size_t HF_PTS = 8 + 128 + (sizeof(GaussParams) + 7) / 8;
+        if (!f->hfit)
+            HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&f->hfit),
+                                    sizeof(double) * (HF_PTS + 64 * BQ_MAXD)));
+        std::memcpy(f->hfit + HF_PTS, xo, sizeof(double) * f->d * M);
+        HIPCHK(c, hipMemcpyAsync(f->pts.d() + (size_t)f->d * f->npad, f->hfit + HF_PTS,
+                                 sizeof(double) * f->d * M, hipMemcpyHostToDevice, c->stream));
+    }
     double hv[128];
     BQCHK(fit_factor(c, f, f->misc.d() + 8, f->misc.d() + 8 + 64, hv));
     for (int64_t i = 0; i < M; ++i) {
@@ -360,7 +377,19 @@ extern "C" int bq_gp_predict(bq_ctx *c, bq_fit *f, const double *xo, int64_t M, 
     DevBuf &xod = f->wx, &out = f->wout;
     HIPCHK(c, grow(xod, sizeof(double) * d * M));
     HIPCHK(c, grow(out, sizeof(double) * 2 * (size_t)Mp));
-    HIPCHK(c, hipMemcpyAsync(xod.p, xo, sizeof(double) * d * M, hipMemcpyHostToDevice, c->stream));
+    // points up and results down through pinned staging (asynchronous for real)
+    const size_t need = (size_t)d * M + 2 * (size_t)Mp;
+    if (f->hio_len < need) {
+        if (f->hio)
+            (void)hipHostFree(f->hio);
+        f->hio = nullptr;
+        f->hio_len = 0;
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&f->hio), sizeof(double) * need));
+        f->hio_len = need;
+    }
+    std::memcpy(f->hio, xo, sizeof(double) * d * M);
+    HIPCHK(c, hipMemcpyAsync(xod.p, f->hio, sizeof(double) * d * M, hipMemcpyHostToDevice,
+                             c->stream));
     GaussParams g = f->g;
     if (!var && !cov) {
         // mean only: fused cross-Gram x alpha
@@ -401,12 +430,13 @@ extern "C" int bq_gp_predict(bq_ctx *c, bq_fit *f, const double *xo, int64_t M, 
         }
         HIPCHK(c, hipStreamSynchronize(c->stream)); // Cd goes out of scope
     }
-    if (mean)
-        HIPCHK(c, hipMemcpyAsync(mean, out.p, sizeof(double) * M, hipMemcpyDeviceToHost,
-                                 c->stream));
-    if (var)
-        HIPCHK(c, hipMemcpyAsync(var, out.d() + Mp, sizeof(double) * M, hipMemcpyDeviceToHost,
-                                 c->stream));
+    double *hres = f->hio + (size_t)d * M; // [mean (Mp) | var (Mp)], one copy
+    HIPCHK(c, hipMemcpyAsync(hres, out.p, sizeof(double) * 2 * (size_t)Mp, hipMemcpyDeviceToHost,
+                             c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (mean)
+        std::memcpy(mean, hres, sizeof(double) * M);
+    if (var)
+        std::memcpy(var, hres + Mp, sizeof(double) * M);
     return BQ_OK;
 }

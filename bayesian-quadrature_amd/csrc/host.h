@@ -395,11 +395,24 @@ struct bq_fit {
     // chains -- [0] solve (forward + backward), [1] backward into alpha, [2] forward; the
     // pointers survive a refit, so the graphs do too
     DevBuf vec;
+    double *hvec = nullptr; // pinned staging of one vector in / out (npad doubles): a copy from
+                            // pageable memory is staged and synchronised by the runtime, which
+                            // was half of a single-vector solve's wall time at N = 4096
+    double *hio = nullptr;  // pinned staging of a prediction's points in and mean / variance out
+    size_t hio_len = 0;
+    double *hfit = nullptr; // pinned staging of a (re)fit: [results 8 + 128 | GaussParams | 63 d
+                            // border points] -- the hyper-parameter loop's body is three small copies
     hipGraph_t vgraph[3] = {nullptr, nullptr, nullptr};
     hipGraphExec_t vgexec[3] = {nullptr, nullptr, nullptr};
     bool vg_failed[3] = {false, false, false};
     ~bq_fit()
     {
+        if (hvec)
+            (void)hipHostFree(hvec);
+        if (hio)
+            (void)hipHostFree(hio);
+        if (hfit)
+            (void)hipHostFree(hfit);
         for (int i = 0; i < 3; ++i) {
             if (vgexec[i])
                 (void)hipGraphExecDestroy(vgexec[i]);

@@ -389,15 +389,18 @@ extern "C" int bq_gp_solve(bq_ctx *c, bq_fit *f, const double *B, int64_t nrhs, 
         BQCHK(fit_wide(c, f, wv));
         BQCHK(fit_vec(c, f));
         double *x = f->vec.d(), *y = f->vec.d() + npad;
-        if (npad > n)
-            HIPCHK(c, hipMemsetAsync(x + n, 0, sizeof(double) * (npad - n), c->stream));
-        HIPCHK(c, hipMemcpyAsync(x, B, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        // through the fit's pinned staging vector (zero padded): truly asynchronous copies
+        std::memcpy(f->hvec, B, sizeof(double) * n);
+        std::memset(f->hvec + n, 0, sizeof(double) * (npad - n));
+        HIPCHK(c, hipMemcpyAsync(x, f->hvec, sizeof(double) * npad, hipMemcpyHostToDevice,
+                                 c->stream));
         BQCHK(fit_replay(c, f, 0, [&]() -> int {
             BQCHK(enqueue_forward_vec(c, x, y, f->A.d(), f->ldl, npad, wv));
             return enqueue_backward_vec(c, y, x, f->A.d(), f->ldl, npad, wv);
         }));
-        HIPCHK(c, hipMemcpyAsync(X, x, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(f->hvec, x, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::memcpy(X, f->hvec, sizeof(double) * n);
         return BQ_OK;
     }
     WideInv wi;
