@@ -368,6 +368,12 @@ struct bq_plan {
     hipGraphExec_t gexec = nullptr;
     int graph_state = 0; // 0 = not tried, 1 = ready, -1 = unavailable (eager launches)
     int graph_nb = 0, graph_la = 0, graph_pw = 0;
+    double *hres = nullptr; // pinned staging of bq_plan_results: [scal 4 nb | info nb | mean | var]
+    ~bq_plan()
+    {
+        if (hres)
+            (void)hipHostFree(hres);
+    }
 };
 
 struct bq_fit {

@@ -279,19 +279,27 @@ extern "C" int bq_plan_results(bq_ctx *c, bq_plan *p, double *mean, double *var,
         return fail(c, BQ_ERR_BAD_ARG, "null plan handle");
     const int nb = p->nprob, M = p->M;
     HIPCHK(c, hipSetDevice(c->device));
-    std::vector<double> scal((size_t)nb * 4);
-    std::vector<int> info((size_t)nb);
-    HIPCHK(c, hipMemcpyAsync(scal.data(), p->scal.p, sizeof(double) * 4 * nb,
-                             hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(info.data(), p->info.p, sizeof(int) * nb, hipMemcpyDeviceToHost,
+    // through pinned staging: [scal 4 nb | info nb (as doubles' storage) | mean M nb | var M nb]
+    const size_t o_info = (size_t)4 * nb, o_mean = o_info + (size_t)nb, o_var = o_mean + (size_t)M * nb;
+    if (!p->hres)
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&p->hres),
+                                sizeof(double) * (o_var + (size_t)M * nb + 1)));
+    double *scal = p->hres;
+    int *info = reinterpret_cast<int *>(p->hres + o_info);
+    HIPCHK(c, hipMemcpyAsync(scal, p->scal.p, sizeof(double) * 4 * nb, hipMemcpyDeviceToHost,
                              c->stream));
+    HIPCHK(c, hipMemcpyAsync(info, p->info.p, sizeof(int) * nb, hipMemcpyDeviceToHost, c->stream));
     if (mean && M)
-        HIPCHK(c, hipMemcpyAsync(mean, p->mean.p, sizeof(double) * (size_t)M * nb,
+        HIPCHK(c, hipMemcpyAsync(p->hres + o_mean, p->mean.p, sizeof(double) * (size_t)M * nb,
                                  hipMemcpyDeviceToHost, c->stream));
     if (var && M)
-        HIPCHK(c, hipMemcpyAsync(var, p->var.p, sizeof(double) * (size_t)M * nb,
+        HIPCHK(c, hipMemcpyAsync(p->hres + o_var, p->var.p, sizeof(double) * (size_t)M * nb,
                                  hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (mean && M)
+        std::memcpy(mean, p->hres + o_mean, sizeof(double) * (size_t)M * nb);
+    if (var && M)
+        std::memcpy(var, p->hres + o_var, sizeof(double) * (size_t)M * nb);
     for (int b = 0; b < nb; ++b) {
         if (status)
             status[b] = info[b];
