@@ -84,7 +84,7 @@ struct bq_ctx {
     hipEvent_t ev_panel = nullptr, ev_next = nullptr, ev_fork = nullptr;
     int lookahead = 1;
     int split_batch = 1; // halves of a mid-sized batch on the two streams (BQ_SPLIT=0: lock-step)
-    int la_min = 4096;   // look-ahead only while the bulk update has at least this many rows (BQ_LA_MIN)
+    int la_min = 3072;   // look-ahead only while the bulk update has at least this many rows (BQ_LA_MIN)
     DevBuf panel_ws;     // scratch panel columns of the eager linalg entry points
     DevBuf scratch;      // per-call temporaries of the acquisition / moment entry points, kept
                          // between calls (hipFree synchronises the device); bq_ctx_trim frees it

@@ -64,7 +64,7 @@ int bq_set_block(bq_ctx *ctx, int nb);
  * environment variable BQ_LOOKAHEAD=0 also disables it) */
 int bq_set_lookahead(bq_ctx *ctx, int on);
 /* the look-ahead runs while the bulk trailing update still has at least `min_rows` rows;
- * below that the sweep continues with sequential launches (default 4096, the measured
+ * below that the sweep continues with sequential launches (default 3072, the measured
  * cross-over on MI355X; 0 = look-ahead to the end; also BQ_LA_MIN) */
 int bq_set_lookahead_rows(bq_ctx *ctx, int min_rows);
 /* bq_batch_fit_predict and bq_gp_logml_grid keep their device workspace (up to half of
