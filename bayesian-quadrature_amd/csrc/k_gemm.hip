@@ -34,25 +34,56 @@ int gemm_init(bq_ctx *c)
 // register-streaming kernel, which is slower by more than a potf2 launch costs).
 #define BQ_LDS_MIN_TILES 96
 // 0: no; 128 / 64: the workgroup tile of the LDS-staged kernel that takes the product.
-// 128 x 128 tiles when there are at least BQ_LDS_MIN_TILES of them; products that cannot fill
-// the chip with those -- a few hundred rows against a long operand (the row sweeps), the late
-// updates of a batch -- take the 64 x 64 form (gemm_lds64_kernel) when that gives at least a
-// workgroup per CU.
+//
+// Measured on MI355X with random operands and launches repeated for 150 ms (bq_probe_gemm; a
+// product of zeros, or a single launch, runs at clocks a real sweep never sees -- it had the
+// 64-tile ahead everywhere): a chip FULL of 128 x 128 tiles sustains about 1.1x the rate of one
+// full of 64 x 64 tiles (k = 320, batch 100, m = 2816: 57.9 against 52.5 TFLOP/s; N = 8192
+// alone: 59.7 / 57.3) -- half the LDS traffic per flop.  The 64-tile wins where the larger one
+// cannot fill the chip (m = 4096 alone: 54.8 against 44.1) or pads ragged edges and the diagonal
+// of a triangular update with more than that tenth (m = 1088 at batch 32: 48.8 / 46.3; m = 704
+// at batch 128: 46.8 / 44.9).  Hence: 128 when there are at least 4.5 tiles per CU and they
+// cover at most 1.12x the area of the 64-tiles; 64 when those give a workgroup per two CUs;
+// else whatever fits.  That is the rule for a product that has the chip to itself
+// (c->sharing == 0).  Otherwise:
+//   * many small systems of a whole number of 128-tiles (m <= 512 at batch >= 64) stay with 128;
+//   * while the two streams of a look-ahead share the chip (sharing == 1) every product with two
+//     128-tiles per CU takes those.  Four 64-tile workgroups (88 VGPRs) fill a CU's register
+//     file in quarters, and a retiring one never frees the 250+ VGPRs a panel_step_kernel
+//     workgroup on the other stream needs: the panel chain starved until the update had drained
+//     (N = 16384: 27.0 instead of 26.0 ms).  The 128-tile kernel holds a CU in halves;
+//   * while the two halves of a batch share it (sharing == 2) the 64-tile goes first: one
+//     half's update beside the other half's panel chain was faster in small workgroups whatever
+//     its size (C5 shard 5.85 ms against 6.00 with the rule above and 6.17 with 128-tiles
+//     first; 256 x C2: 4.68 / 4.79 / 4.85).
+// BQ_GEMM_TILE=64|128 forces a tile where its kernel can run (measurements only).
 static int gemm_lds_tile(const bq_ctx *c, int m, int n, int k, int lower, int batch)
 {
     if (!c->gemm_lds || (m % 64) || (n % 64) || (k % 32))
         return 0;
-    long a = (long)((m + 127) / 128) * ((n + 127) / 128) * batch;
-    long a64 = (long)(m / 64) * (n / 64) * batch;
-    if (lower) {
-        a = a / 2 + 1;
-        a64 = a64 / 2 + 1;
-    }
-    if (n >= 128 && a >= 2L * c->cus)
-        return 128;
-    if (c->gemm_lds64 && a64 >= c->cus / 2 && k >= 64)
+    const bool tri = lower && m == n;
+    auto tiles = [&](int t) {
+        const long gm = (m + t - 1) / t, gn = (n + t - 1) / t;
+        const long per = tri ? gm * (gm + 1) / 2 : (lower ? gm * gn / 2 + 1 : gm * gn);
+        return per * batch;
+    };
+    const long a = tiles(128), a64 = tiles(64);
+    const bool can64 = c->gemm_lds64 && k >= 64, can128 = n >= 128;
+    static const int forced = std::getenv("BQ_GEMM_TILE") ? std::atoi(std::getenv("BQ_GEMM_TILE")) : 0;
+    if (forced == 64 && can64)
         return 64;
-    return (n >= 128 && a >= BQ_LDS_MIN_TILES) ? 128 : 0;
+    if (forced == 128 && can128)
+        return 128;
+    const bool small128 = tri && (m % 128) == 0 && m <= 512 && a >= 2L * c->cus;
+    const bool full128 =
+        c->sharing == 1 ? a >= 2L * c->cus
+                        : c->sharing == 0 && 2 * a >= 9L * c->cus &&
+                              4.0 * (double)a <= 1.12 * (double)a64;
+    if (can128 && (small128 || full128))
+        return 128;
+    if (can64 && a64 >= c->cus / 2)
+        return 64;
+    return (can128 && a >= BQ_LDS_MIN_TILES) ? 128 : 0;
 }
 
 bool gemm_uses_lds(const bq_ctx *c, int m, int n, int k, int lower, int batch)

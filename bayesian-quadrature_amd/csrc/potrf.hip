@@ -164,6 +164,14 @@ static int enqueue_slab_sweep(bq_ctx *c, double *A, long lda, long astride, int 
     return BQ_OK;
 }
 
+// (tile choice while two streams share the chip: gemm_lds_tile)
+struct Sharing {
+    bq_ctx *c;
+    int prev;
+    Sharing(bq_ctx *c_, int how) : c(c_), prev(c_->sharing) { c->sharing = how; }
+    ~Sharing() { c->sharing = prev; }
+};
+
 // nb_forced: the outer block of the whole batch when this call factors one half of it
 // whether a factorisation of these sizes goes to the one-launch slab sweep from its first column
 bool sweep_is_slab(const bq_ctx *c, int ntot, int ncols, int batch, size_t panel_ws_len)
@@ -200,6 +208,7 @@ static int enqueue_potrf_group(bq_ctx *c, double *A, long lda, long astride, int
             return st;
         HIPCHK(c, hipEventRecord(c->ev_panel, c->aux));
         bool have_b = false; // a trailing update is in flight on the main stream
+        Sharing la_scope(c, 1);
         for (; K0 < ncols && st == BQ_OK; K0 += NB) {
             const int KB = std::min(NB, ncols - K0);
             const int r0 = K0 + KB;
@@ -311,6 +320,7 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
     if (c->split_batch && c->lookahead && c->aux && c->cur == c->stream && batch >= 8 &&
         NB >= 128 && !la) {
         const int b0 = batch / 2, b1 = batch - b0;
+        Sharing halves(c, 2);
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
         c->cur = c->aux;

@@ -140,6 +140,20 @@ __global__ void probe_layout444_kernel(int *out)
     }
 }
 
+// pseudo-random values in (-1, 1): operands of all zeros draw far less MFMA power than real
+// data, and a product timed on them runs at clocks the real sweep never sees
+__global__ __launch_bounds__(256) void probe_fill_kernel(double *dst, size_t n, unsigned seed)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long h = (i + seed) * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29;
+        h *= 0xBF58476D1CE4E5B9ull;
+        h ^= h >> 32;
+        dst[i] = (double)(long long)h * (1.0 / 9223372036854775808.0);
+    }
+}
+
 __global__ void probe_empty_kernel(double *out)
 {
     if (out == nullptr && threadIdx.x == 9999)

@@ -120,8 +120,11 @@ extern "C" int bq_probe_gemm(bq_ctx *c, int64_t m, int64_t n, int64_t k, int low
     HIPCHK(c, P.alloc(sizeof(double) * (size_t)ldp * k * batch));
     HIPCHK(c, Q.alloc(sizeof(double) * (size_t)n * k * batch));
     HIPCHK(c, hipMemsetAsync(C.p, 0, C.bytes, c->stream));
-    HIPCHK(c, hipMemsetAsync(P.p, 0, P.bytes, c->stream));
-    HIPCHK(c, hipMemsetAsync(Q.p, 0, Q.bytes, c->stream));
+    hipLaunchKernelGGL(probe_fill_kernel, dim3(2048), dim3(256), 0, c->stream, P.d(),
+                       P.bytes / sizeof(double), 1u);
+    hipLaunchKernelGGL(probe_fill_kernel, dim3(2048), dim3(256), 0, c->stream, Q.d(),
+                       Q.bytes / sizeof(double), 77u);
+    HIPCHK(c, hipGetLastError());
     auto run = [&]() {
         return launch_gemm(c, BQ_K_GEMM, C.d(), ldc, ldc * n, P.d(), ldp, ldp * k, Q.d(),
                            qt ? ldq : 1, qt ? 1 : ldq, (long)n * k, (int)m, (int)n, (int)k, lower,

@@ -70,6 +70,8 @@ __device__ __forceinline__ void slab_solve16(const double (&t)[4][4], const doub
 // accumulator that is never stored.  (A third MFMA under `if (wave < 2)` was miscompiled into
 // a wrong block (3, 1): an MFMA ignores EXEC, so it must never sit under anything but a scalar
 // branch, and the redundant one costs nothing -- the other two waves issue three anyway.)
+// doubles of LDS behind the tile for the fragments of L_jj (6 blocks) and W (4 blocks)
+#define BQ_SLAB_FW (10 * 256)
 #define DIAG_NB(w) ((w) < 2 ? 3 : 2)
 #define DIAG_RB(w, s) ((w) == 0 ? ((s) > 0 ? 1 : 0) : ((w) == 1 ? 2 : 3))
 #define DIAG_CB(w, s) ((w) == 0 ? ((s) == 2 ? 1 : 0) : (((w) == 3 ? 2 : 0) + ((w) >= 2 && (s) == 2 ? 1 : (s))))
@@ -97,10 +99,15 @@ __global__ __launch_bounds__(256, 2) void slab_step_kernel(double *__restrict__ 
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
     BQ_SSTAMP(0, 0)
-    // Q rows of the tile, [k][row] (A-fragment reads are contiguous over rows)
-    __shared__ __attribute__((aligned(16))) double Qs[64 * 64];
-    // workgroup 0: the updated diagonal block on its way to the factor, and the factor's LDS
-    __shared__ __attribute__((aligned(16))) double plds[BQ_POTF2_LDS_DOUBLES];
+    // One region, 52 KiB -- a workgroup of this kernel must fit into what ONE retiring workgroup
+    // of the 64-tile product frees on a CU (36 KiB + the 16 KiB four of them leave over), or it
+    // starves behind a trailing update running on the other stream.  First 4096 doubles: the Q
+    // rows of the tile, [k][row] (A-fragment reads are contiguous over rows); afterwards, in
+    // workgroup 0, the updated diagonal block on its way to the factor and the factor's panel
+    // slots.  Behind them: the fragments of L_jj and W (BQ_SLAB_FW doubles), later the factor's
+    // diagonal sub-blocks.
+    __shared__ __attribute__((aligned(16))) double plds[4096 + BQ_SLAB_FW];
+    double *const Qs = plds;
     double *const Ts = plds; // the block sits where the factor's panel slots will be
     __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.z;
@@ -130,8 +137,8 @@ __global__ __launch_bounds__(256, 2) void slab_step_kernel(double *__restrict__ 
         // LDS (10 doubles per thread; the region is the diagonal factor's, free until the
         // tile update is over) instead of 64 doubles per lane from L2 -- a CU takes in about
         // 40 B per cycle and the fragment loads were half of the launch's 190 KB.
-        double *Fs = plds;          // block (c, bb), c > bb, at 256 ((c (c - 1)) / 2 + bb)
-        double *Ws = plds + 6 * 256; // W blocks as in global memory
+        double *Fs = plds + 4096;          // block (c, bb), c > bb, at 256 ((c (c - 1)) / 2 + bb)
+        double *Ws = plds + 4096 + 6 * 256; // W blocks as in global memory
         {
             const int t = threadIdx.x, ti = t & 15, tk = t >> 4;
             const double *L11 = A + j0 + (long)j0 * lda + ti + (long)tk * lda;
@@ -260,7 +267,9 @@ __global__ __launch_bounds__(256, 2) void slab_step_kernel(double *__restrict__ 
     // which workgroup 0 factors in place, and the Schur complement of the last step stay in A)
     if (blockIdx.x == 0 && factor_next) {
         // the next diagonal block never touches memory between its update and its factor
-        // (only the ten lower blocks: the factor never reads a lane above its column's own)
+        // (only the ten lower blocks: the factor never reads a lane above its column's own);
+        // it lands where the Q rows were: every wave must be through with them
+        __syncthreads();
 #pragma unroll
         for (int sb = 0; sb < 3; ++sb)
             if (sb < DIAG_NB(wave)) {
@@ -379,9 +388,11 @@ __global__ __launch_bounds__(256) void panel_step_kernel(double *__restrict__ A,
                                                          double *__restrict__ SL,
                                                          int *__restrict__ info)
 {
-    __shared__ __attribute__((aligned(16))) double Qs[64 * 64];
+    // 40 KiB (see slab_step_kernel): the solved Q rows, then -- workgroup 0 -- the next diagonal
+    // block and the factor's slots in the same 4096 doubles
     __shared__ __attribute__((aligned(16))) double plds[BQ_POTF2_LDS_DOUBLES];
-    double *const Ts = plds; // the block sits where the factor's panel slots will be
+    double *const Qs = plds;
+    double *const Ts = plds;
     __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63;
@@ -518,6 +529,7 @@ __global__ __launch_bounds__(256) void panel_step_kernel(double *__restrict__ A,
                 acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(qrow[16 * cb], pf, acc[cb], 0, 0, 0);
         }
     if (blockIdx.x == 0) {
+        __syncthreads(); // Ts is where the Q rows were
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
