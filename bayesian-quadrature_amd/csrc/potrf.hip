@@ -164,6 +164,9 @@ static int enqueue_slab_sweep(bq_ctx *c, double *A, long lda, long astride, int 
     return BQ_OK;
 }
 
+// the look-ahead pays up to this many matrices per batch (enqueue_potrf_partial)
+#define BQ_LA_MAX_BATCH 48
+
 // (tile choice while two streams share the chip: gemm_lds_tile)
 struct Sharing {
     bq_ctx *c;
@@ -191,7 +194,7 @@ static int enqueue_potrf_group(bq_ctx *c, double *A, long lda, long astride, int
     if (NB == 64 && ws && ncols >= 64)
         return enqueue_slab_sweep(c, A, lda, astride, batch, ntot, ncols, dinv, info, ws, 0,
                                   first_done);
-    const bool la = c->lookahead && c->aux && NB >= 128 && ncols > NB;
+    const bool la = c->lookahead && c->aux && NB >= 128 && ncols > NB && batch <= BQ_LA_MAX_BATCH;
     int K0 = 0;
     bool panel_done = false; // panel K0 was already factored by the look-ahead phase
     int st = BQ_OK;
@@ -315,10 +318,13 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
     if ((ntot & 63) || (ncols & 63) || ncols > ntot)
         return fail(c, BQ_ERR_BAD_ARG, "potrf: sizes must be multiples of 64");
     const int NB = auto_nb(c, ntot, batch);
-    const bool la = c->lookahead && c->aux && NB >= 128 && ncols > NB &&
-                    ntot - std::min(NB, ncols) >= c->la_min;
+    // large systems (a look-ahead's size) in a batch that fills the chip many times over run
+    // as ONE sequential group: the product is power-bound, beside it the
+    // panel chain only takes clock away (C3, 100 x N = 4096: 189.8 ms with the look-ahead,
+    // 198 in two halves, 186.3 sequential; up to 32 matrices the look-ahead still gains 1-2 %)
+    const bool big = ncols > NB && ntot - std::min(NB, ncols) >= c->la_min;
     if (c->split_batch && c->lookahead && c->aux && c->cur == c->stream && batch >= 8 &&
-        NB >= 128 && !la) {
+        NB >= 128 && !big) {
         const int b0 = batch / 2, b1 = batch - b0;
         Sharing halves(c, 2);
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));

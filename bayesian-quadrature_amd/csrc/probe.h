@@ -78,7 +78,9 @@ __global__ __launch_bounds__(256) void probe_mfma_var_kernel(double *out, int it
 
 // The GEMM inner step without memory: 4 P-fragments x 4 Q-fragments, 64 four-block MFMAs
 // per step, with (ROT = 1) or without (ROT = 0) the three DPP quad rotations per Q fragment.
-template <int ROT>
+// RND: operands with random mantissas (a hash of the lane), as real data has -- the power an
+// MFMA draws, and with it the clock the chip sustains, depends on the bits that toggle.
+template <int ROT, int RND = 0>
 __global__ __launch_bounds__(256, 2) void probe_mfma_step_kernel(double *out, int iters)
 {
     double acc[4][4][4];
@@ -94,11 +96,21 @@ __global__ __launch_bounds__(256, 2) void probe_mfma_step_kernel(double *out, in
     for (int a = 0; a < 4; ++a) {
         pf[a] = 1.0 + threadIdx.x * 1e-9 + a;
         qf[a] = 1.0 - threadIdx.x * 1e-9 - a;
+        if (RND) {
+            unsigned long long h = (threadIdx.x * 8 + a + 1) * 0x9E3779B97F4A7C15ull;
+            h ^= h >> 29;
+            h *= 0xBF58476D1CE4E5B9ull;
+            h ^= h >> 32;
+            pf[a] = (double)(long long)h * (1.0 / 9223372036854775808.0);
+            h *= 0x94D049BB133111EBull;
+            h ^= h >> 31;
+            qf[a] = (double)(long long)h * (1.0 / 9223372036854775808.0);
+        }
     }
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) {
-            qf[tn] += 1e-12; // keeps the rotations inside the loop
+            qf[tn] += RND ? 0.000123456789 * pf[tn] : 1e-12; // keeps the rotations inside the loop
             const double q0 = qf[tn];
             const double q1 = ROT ? row_ror_quads<1>(q0) : q0;
             const double q2 = ROT ? row_ror_quads<2>(q0) : q0;

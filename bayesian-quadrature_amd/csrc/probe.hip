@@ -150,16 +150,35 @@ extern "C" int bq_probe_mfma_variant(bq_ctx *c, int kind, int nacc, int blocks_p
     HIPCHK(c, hipSetDevice(c->device));
     DevBuf o;
     HIPCHK(c, o.alloc(64));
+    if (kind == 4 || kind == 5) {
+        // the GEMM inner step SUSTAINED: 300 launches of ~1 ms back to back, the last 200 timed;
+        // kind 4: operands near 1.0 (few mantissa bits set), kind 5: random mantissas
+        const int it = 1024, blocks = c->cus * blocks_per_cu;
+        float ms = 0;
+        for (int rep = 0; rep < 300; ++rep) {
+            if (rep == 100)
+                BQCHK(bq_timer_start(c));
+            if (kind == 4)
+                hipLaunchKernelGGL((probe_mfma_step_kernel<0, 0>), dim3(blocks), dim3(256), 0,
+                                   c->stream, o.d(), it);
+            else
+                hipLaunchKernelGGL((probe_mfma_step_kernel<0, 1>), dim3(blocks), dim3(256), 0,
+                                   c->stream, o.d(), it);
+        }
+        BQCHK(bq_timer_stop_ms(c, &ms));
+        *tflops = 200.0 * (double)blocks * 4 * (double)it * 64 * 512.0 / (ms * 1e-3) / 1e12;
+        return BQ_OK;
+    }
     if (kind >= 2) { // the GEMM inner step, kind 2: no rotations, 3: with rotations
         const int it = 512, blocks = c->cus * blocks_per_cu;
         float ms = 0;
         for (int rep = 0; rep < 2; ++rep) {
             BQCHK(bq_timer_start(c));
             if (kind == 2)
-                hipLaunchKernelGGL(probe_mfma_step_kernel<0>, dim3(blocks), dim3(256), 0,
+                hipLaunchKernelGGL((probe_mfma_step_kernel<0, 0>), dim3(blocks), dim3(256), 0,
                                    c->stream, o.d(), it);
             else
-                hipLaunchKernelGGL(probe_mfma_step_kernel<1>, dim3(blocks), dim3(256), 0,
+                hipLaunchKernelGGL((probe_mfma_step_kernel<1, 0>), dim3(blocks), dim3(256), 0,
                                    c->stream, o.d(), it);
             BQCHK(bq_timer_stop_ms(c, &ms));
         }

@@ -6,6 +6,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bayesian_quadrature_amd import Engine, workloads as wl
 e = Engine(0)
+if os.environ.get("C3_NB"):
+    e.set_block(int(os.environ["C3_NB"]))
 c3 = wl.c3()
 ts = []
 for rep in range(7):
