@@ -102,6 +102,8 @@ static int ctx_init(bq_ctx *c, int device)
         c->gemm_lds = std::atoi(e);
     if (const char *e = std::getenv("BQ_GEMM_LDS64"))
         c->gemm_lds64 = std::atoi(e);
+    if (const char *e = std::getenv("BQ_GEMM_TILE"))
+        c->gemm_tile = std::atoi(e);
     if (const char *e = std::getenv("BQ_GRAPH"))
         c->use_graph = std::atoi(e);
     return BQ_OK;

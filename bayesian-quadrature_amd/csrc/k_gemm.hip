@@ -56,7 +56,7 @@ int gemm_init(bq_ctx *c)
 //     half's update beside the other half's panel chain was faster in small workgroups whatever
 //     its size (C5 shard 5.85 ms against 6.00 with the rule above and 6.17 with 128-tiles
 //     first; 256 x C2: 4.68 / 4.79 / 4.85).
-// BQ_GEMM_TILE=64|128 forces a tile where its kernel can run (measurements only).
+// BQ_GEMM_TILE=64|128 (read when a context is created) forces a tile where its kernel can run.
 static int gemm_lds_tile(const bq_ctx *c, int m, int n, int k, int lower, int batch)
 {
     if (!c->gemm_lds || (m % 64) || (n % 64) || (k % 32))
@@ -69,7 +69,7 @@ static int gemm_lds_tile(const bq_ctx *c, int m, int n, int k, int lower, int ba
     };
     const long a = tiles(128), a64 = tiles(64);
     const bool can64 = c->gemm_lds64 && k >= 64, can128 = n >= 128;
-    static const int forced = std::getenv("BQ_GEMM_TILE") ? std::atoi(std::getenv("BQ_GEMM_TILE")) : 0;
+    const int forced = c->gemm_tile;
     if (forced == 64 && can64)
         return 64;
     if (forced == 128 && can128)

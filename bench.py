@@ -466,6 +466,11 @@ def extras(eng, nb_override):
     out.update(solve_predict_rooflines(eng))
     out.update(hyper_loop_body(eng))
     out.update(batched_configs(eng))
+    try:
+        out.update(sustained_clock(eng))
+    except Exception as exc:  # context only: never fail the bench line for it
+        out["sustained_clock"] = None
+        out["sustained_clock_note"] = "not measured: %r" % (exc,)
     # the same C2 problem through the host-buffer entry point (allocation, PCIe both
     # ways, synchronisation inside every call): never the headline `value`
     c2 = wl.c2()
@@ -599,6 +604,62 @@ def hyper_loop_body(eng):
         g1.close()
         g2.close()
     return out
+
+
+def _hwmon_sample():
+    """(watts, sclk MHz) of the busiest card that exposes a hwmon node: plain sysfs reads
+    (power1_input in microwatts, freq1_input in Hz), no child process."""
+    import glob
+    best = None
+    for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+        try:
+            w = int(open(h + "/power1_input").read()) / 1e6
+            f = int(open(h + "/freq1_input").read()) / 1e6
+        except (OSError, ValueError):
+            continue
+        if best is None or w > best[0]:
+            best = (w, f)
+    return best
+
+
+def sustained_clock(eng):
+    """What the chip sustains while the product runs: socket power and shader clock sampled from
+    sysfs during ~1.5 s of (a) the fp64 MFMA loop without memory and (b) the trailing-update
+    kernel on random operands.  The MFMA peak of MICROARCH.md (78.6 TFLOP/s) is quoted at
+    2.4 GHz; under the power cap the product runs below that clock, and `peak_at_clock` is what
+    the matrix cores could deliver at the clock it actually had.  Context for the fractions
+    above, never a replacement for them."""
+    import threading
+    if _hwmon_sample() is None:
+        return {"sustained_clock": None, "sustained_clock_note": "no hwmon node readable"}
+
+    def watch(fn):
+        res, seen = {}, []
+        th = threading.Thread(target=lambda: res.setdefault("v", fn()))
+        th.start()
+        time.sleep(0.5)
+        while th.is_alive():
+            seen.append(_hwmon_sample())
+            time.sleep(0.2)
+        th.join()
+        seen = seen[:-1] or seen
+        return res["v"], sum(x[0] for x in seen) / len(seen), sum(x[1] for x in seen) / len(seen)
+
+    out = {"at_entry": dict(zip(("watts", "sclk_mhz"), _hwmon_sample()))}
+    v, w, f = watch(lambda: [eng.probe_mfma_variant(5, 8, 2) for _ in range(6)])
+    out["mfma_loop_no_memory"] = {"tflops": sum(v) / len(v), "watts": w, "sclk_mhz": f}
+    for tag, m, k, b, reps in (("trailing_update_m16064_k256", 16064, 256, 1, 1400),
+                               ("trailing_update_m2048_k320_batch32", 2048, 320, 32, 1800)):
+        ms, w, f = watch(lambda: eng.probe_gemm(m, m, k, 1, b, False, reps))
+        tf = float(m) * m * k * b / ms / 1e9
+        peak = PEAK_FP64_TFLOPS * f / 2400.0
+        out[tag] = {"tflops": tf, "watts": w, "sclk_mhz": f, "peak_at_clock": peak,
+                    "frac_of_peak_at_clock": tf / peak, "frac": tf / PEAK_FP64_TFLOPS,
+                    "note": "random operands, %d launches back to back" % reps}
+    out["note"] = ("sysfs power1_input / freq1_input sampled every 0.2 s while the kernel runs; "
+                   "the product is power-bound: it holds the socket at its cap and the clock "
+                   "below 2.4 GHz, the MFMA loop without memory does not")
+    return {"sustained_clock": out}
 
 
 def batched_configs(eng):

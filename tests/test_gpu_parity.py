@@ -620,6 +620,9 @@ def _potrf_dev(eng, x, c, n, nb=0, la=True):
     ({"BQ_GEMM_LDS": "0"}, 256, False),
     ({"BQ_LA_MIN": "0"}, 0, True),       # look-ahead to the last panel (no hand-over)
     ({"BQ_LA_MIN": "0"}, 128, True),
+    ({"BQ_GEMM_TILE": "64"}, 0, True),   # the 64 x 64 LDS tile wherever it can run
+    ({"BQ_GEMM_TILE": "64"}, 320, False),
+    ({"BQ_GEMM_TILE": "128"}, 0, False),  # the 128 x 128 tile wherever it can run
 ])
 def test_trailing_update_variants_agree(engine, env, nb, la):
     """Every blocking / scheduling of the factorisation, and the one reference kernel variant
