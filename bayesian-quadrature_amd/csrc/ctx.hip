@@ -102,6 +102,8 @@ static int ctx_init(bq_ctx *c, int device)
         c->gemm_lds = std::atoi(e);
     if (const char *e = std::getenv("BQ_GEMM_LDS64"))
         c->gemm_lds64 = std::atoi(e);
+    if (const char *e = std::getenv("BQ_GEMM_KSPLIT"))
+        c->gemm_ksplit = std::atoi(e);
     if (const char *e = std::getenv("BQ_GEMM_TILE"))
         c->gemm_tile = std::atoi(e);
     if (const char *e = std::getenv("BQ_GRAPH"))

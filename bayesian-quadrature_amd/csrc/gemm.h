@@ -630,14 +630,19 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C
 #define BQ_L64_BYTES (2 * BQ_L64_STAGE)
 
 // the workgroup tile (bx, by); C, P, Q point at the batch element
-template <bool QT>
+// KS = 2: the workgroup has EIGHT waves, two groups of four that split every chunk's k range
+// (group g takes k-steps 2g, 2g + 1 of the four) and meet in LDS at the end: the form the tile
+// takes inside rows_fused_kernel's eight-wave workgroups (whose job tiles gain from eight waves;
+// this tile neither gains nor loses).
+template <bool QT, int KS = 1>
 __device__ __forceinline__ void gemm_lds64_body(unsigned char *smem, double *__restrict__ C,
                                                 long ldc, const double *__restrict__ P, long ldp,
                                                 const double *__restrict__ Q, long ldq, int m,
                                                 int n, int k, int lower, int ncut, int bx, int by)
 {
     const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wave = wave8 & 3, grp = wave8 >> 2; // place in the 2 x 2 wave layout; k group
     const int R0 = bx * 64, C0 = by * 64;
     if (C0 >= ncut)
         return; // (the whole workgroup, before any barrier)
@@ -645,8 +650,10 @@ __device__ __forceinline__ void gemm_lds64_body(unsigned char *smem, double *__r
     const int row0 = R0 + wr, col0 = C0 + wc;
     const bool active = row0 < m && col0 < n && col0 < ncut && !(lower && col0 >= row0 + 32);
 
-    const bool stq = wave >= 2;
-    const int dma0 = 4 * (wave & 1); // this wave's first DMA row of its operand
+    // staging: 8 DMA rows of P and 8 of Q per chunk, dealt to the 4 KS waves
+    constexpr int NDMA = 4 / KS; // DMA rows per wave and chunk
+    const bool stq = wave8 >= 2 * KS;
+    const int dma0 = NDMA * (wave8 & (2 * KS - 1)); // this wave's first DMA row of its operand
     // lane i: operand rows 2 (i & 31), + 1 of k row (dma row) + 8 (i >> 5);
     // QT operand: operand row i, k rows 2 (dma row), + 1
     const double *gsrc;
@@ -665,20 +672,23 @@ __device__ __forceinline__ void gemm_lds64_body(unsigned char *smem, double *__r
     const int srow = ((stq ? 8 : 0) + dma0) * BQ_LDS_ROW;
 
     const int l15 = lane & 15, l4 = lane >> 4;
-    const unsigned char *pview = smem + l4 * BQ_LDS_ROW + (wr + l15) * 8;
+    // (KS = 2: group g's k-steps are 2g, 2g + 1 -- the half of the DMA rows at + 512 B, and for
+    // a k-contiguous Q the DMA rows from 4g on: folded into the view bases)
+    const unsigned char *pview = smem + l4 * BQ_LDS_ROW + (wr + l15) * 8 + (KS == 2 ? grp * 512 : 0);
     const unsigned char *qview[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-        qview[s] = QT ? smem + (8 + (l4 >> 1)) * BQ_LDS_ROW +
+        qview[s] = QT ? smem + (8 + (l4 >> 1) + (KS == 2 ? 4 * grp : 0)) * BQ_LDS_ROW +
                             (wc + ((l15 - 4 * s) & 15)) * 16 + (l4 & 1) * 8
-                      : smem + (8 + l4) * BQ_LDS_ROW + (wc + ((l15 - 4 * s) & 15)) * 8;
+                      : smem + (8 + l4) * BQ_LDS_ROW + (wc + ((l15 - 4 * s) & 15)) * 8 +
+                            (KS == 2 ? grp * 512 : 0);
 
     double acc[2][2][4];
 
 #define BQ_L64_FILL(BUF_, CH_)                                                                     \
     {                                                                                              \
         const double *g_ = gsrc + (long)(CH_) * schunk;                                            \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) __builtin_amdgcn_global_load_lds(            \
+        _Pragma("unroll") for (int r = 0; r < NDMA; ++r) __builtin_amdgcn_global_load_lds(         \
             (global_cvoid_t *)(g_ + (long)r * sld),                                                \
             (lds_void_t *)(smem + (BUF_) * BQ_L64_STAGE + srow + r * BQ_LDS_ROW), 16, 0, 0);       \
     }
@@ -702,7 +712,7 @@ __device__ __forceinline__ void gemm_lds64_body(unsigned char *smem, double *__r
         if (active) {                                                                              \
             BQ_L64_READ_P(BUF_, 0, pf[0])                                                          \
             BQ_L64_READ_Q(BUF_, 0, 0, qf[0])                                                       \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j)                                          \
+            _Pragma("unroll") for (int j = 0; j < 8 / KS; ++j)                                     \
             {                                                                                      \
                 const int st = j >> 1, tn = j & 1;                                                 \
                 __builtin_amdgcn_sched_barrier(0);                                                 \
@@ -711,9 +721,9 @@ __device__ __forceinline__ void gemm_lds64_body(unsigned char *smem, double *__r
                 asm volatile("" ::"v"(qf[j & 1][0]), "v"(qf[j & 1][1]), "v"(qf[j & 1][2]),         \
                              "v"(qf[j & 1][3]), "v"(pf[st & 1][0]), "v"(pf[st & 1][1]));           \
                 __builtin_amdgcn_sched_barrier(0);                                                 \
-                if (j < 7)                                                                         \
+                if (j < 8 / KS - 1)                                                                \
                     BQ_L64_READ_Q(BUF_, (j + 1) >> 1, (j + 1) & 1, qf[(j + 1) & 1])                \
-                if (tn == 1 && j < 7)                                                              \
+                if (tn == 1 && j < 8 / KS - 1)                                                     \
                     BQ_L64_READ_P(BUF_, st + 1, pf[(st + 1) & 1])                                  \
                 __builtin_amdgcn_sched_barrier(0);                                                 \
                 _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                   \
@@ -727,10 +737,22 @@ __device__ __forceinline__ void gemm_lds64_body(unsigned char *smem, double *__r
 
     double pf[2][2], qf[2][4];
     const int nchunk = k / 16; // even
-    BQ_L64_FILL(0, 0)
     const Tile444<2, 2> ct(C, ldc, row0, col0, lane);
-    if (active)
+    // (KS = 2 measured with four stages and counted vmcnt waits as well: no faster -- with the
+    // LDS-DMA removed a chunk takes 0.54 us, with it 0.52-0.55: the k loop is MFMA-bound at 80 %
+    // of a CU's rate whether four waves walk it or eight; what the eight gain is the job tiles')
+    BQ_L64_FILL(0, 0)
+    if (active && (KS == 1 || grp == 0))
         ct.load_neg(acc);
+    else if (KS == 2) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc[a][b2][s] = 0.0;
+    }
     for (int ch = 0; ch < nchunk; ch += 2) {
         BQ_L64_CHUNK(0, ch)
         BQ_L64_CHUNK(1, ch + 1)
@@ -742,27 +764,51 @@ __device__ __forceinline__ void gemm_lds64_body(unsigned char *smem, double *__r
 #undef BQ_L64_OFF
 #undef BQ_L64_QOFF
 
+    if (KS == 2) {
+        // group 1's partial sums -> LDS (16 doubles per lane, 32 KiB: the staging buffers are
+        // free once every wave is past its last chunk) -> group 0
+        double *red = reinterpret_cast<double *>(smem) + wave * 1024 + lane;
+        __syncthreads();
+        if (grp == 1 && active) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        red[64 * (8 * a + 4 * b2 + s)] = acc[a][b2][s];
+        }
+        __syncthreads();
+        if (grp == 1 || !active)
+            return;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc[a][b2][s] += red[64 * (8 * a + 4 * b2 + s)];
+        ct.store_neg(acc, lower);
+        return;
+    }
     if (!active)
         return;
     ct.store_neg(acc, lower);
 }
 
-template <bool QT>
-__global__ __launch_bounds__(256, 4) void gemm_lds64_kernel(double *__restrict__ C, long ldc,
-                                                            long cstride,
-                                                            const double *__restrict__ P, long ldp,
-                                                            long pstride,
-                                                            const double *__restrict__ Q, long ldq,
-                                                            long qstride, int m, int n, int k,
-                                                            int lower, int ncut)
+template <bool QT, int KS = 1>
+__global__ __launch_bounds__(256 * KS, 4 / KS) void gemm_lds64_kernel(
+    double *__restrict__ C, long ldc, long cstride, const double *__restrict__ P, long ldp,
+    long pstride, const double *__restrict__ Q, long ldq, long qstride, int m, int n, int k,
+    int lower, int ncut)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.z;
     int bx = blockIdx.x, by = blockIdx.y;
     if (lower == 2)
         tri_decode(blockIdx.x, bx, by);
-    gemm_lds64_body<QT>(smem, C + (long)b * cstride, ldc, P + (long)b * pstride, ldp,
-                        Q + (long)b * qstride, ldq, m, n, k, lower, ncut, bx, by);
+    gemm_lds64_body<QT, KS>(smem, C + (long)b * cstride, ldc, P + (long)b * pstride, ldp,
+                            Q + (long)b * qstride, ldq, m, n, k, lower, ncut, bx, by);
 }
 
 
@@ -844,13 +890,16 @@ __global__ __launch_bounds__(256) void gemm_splitk_kernel(double *__restrict__ C
 // ---------------------------------------------------------------------------
 // (struct RowsJob: types.h)
 // one 32 x 32 tile (bx, by) of a job; red: 32 KiB of LDS
+// NW = 8: eight waves split the k range (k1 + k2 a multiple of 128); waves 4-7 hand their
+// sums to waves 0-3 through the same 32 KiB before the four-way reduction
+template <int NW = 4>
 __device__ __forceinline__ void rows_job_tile(const RowsJob &j, int bx, int by,
                                               double (*red)[4][4][64])
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int kq = (j.k1 + j.k2) >> 2;
+    const int kq = (j.k1 + j.k2) / NW;
     double4_t acc[2][2];
 #pragma unroll
     for (int jb2 = 0; jb2 < 2; ++jb2)
@@ -883,14 +932,40 @@ __device__ __forceinline__ void rows_job_tile(const RowsJob &j, int bx, int by,
                     acc[jb2][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][jb2], a[u][ib],
                                                                         acc[jb2][ib], 0, 0, 0);
     }
+    if (NW == 8) {
+        if (wave >= 4) {
 #pragma unroll
-    for (int jb2 = 0; jb2 < 2; ++jb2)
+            for (int jb2 = 0; jb2 < 2; ++jb2)
 #pragma unroll
-        for (int ib = 0; ib < 2; ++ib)
+                for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                red[wave][2 * jb2 + ib][r][lane] = acc[jb2][ib][r];
+                    for (int r = 0; r < 4; ++r)
+                        red[wave - 4][2 * jb2 + ib][r][lane] = acc[jb2][ib][r];
+        }
+        __syncthreads();
+        if (wave < 4) {
+#pragma unroll
+            for (int jb2 = 0; jb2 < 2; ++jb2)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[jb2][ib][r] += red[wave][2 * jb2 + ib][r][lane];
+        }
+        __syncthreads();
+    }
+    if (NW == 4 || wave < 4) {
+#pragma unroll
+        for (int jb2 = 0; jb2 < 2; ++jb2)
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    red[wave][2 * jb2 + ib][r][lane] = acc[jb2][ib][r];
+    }
     __syncthreads();
+    if (NW == 8 && wave >= 4)
+        return;
     const int jq = wave >> 1, iq = wave & 1;
     double *cp = j.C + (long)bx * 32 + 16 * iq + l15 + ((long)by * 32 + 16 * jq + l4) * j.ldc;
 #pragma unroll
@@ -904,14 +979,15 @@ __device__ __forceinline__ void rows_job_tile(const RowsJob &j, int bx, int by,
     }
 }
 
-__global__ __launch_bounds__(256) void rows_step_kernel(RowsJob ja, RowsJob jb)
+template <int NW = 4>
+__global__ __launch_bounds__(64 * NW) void rows_step_kernel(RowsJob ja, RowsJob jb)
 {
     __shared__ double red[4][4][4][64];
     // (two calls: selecting the argument struct dynamically parks a copy of it in scratch)
     if ((int)blockIdx.y < ja.ny)
-        rows_job_tile(ja, blockIdx.x, blockIdx.y, red);
+        rows_job_tile<NW>(ja, blockIdx.x, blockIdx.y, red);
     else
-        rows_job_tile(jb, blockIdx.x, blockIdx.y - ja.ny, red);
+        rows_job_tile<NW>(jb, blockIdx.x, blockIdx.y - ja.ny, red);
 }
 
 // ---------------------------------------------------------------------------
@@ -923,19 +999,21 @@ __global__ __launch_bounds__(256) void rows_step_kernel(RowsJob ja, RowsJob jb)
 // in one grid the short job's workgroups are dispatched first and finish beside the update's --
 // on a stream of their own they waited for slots behind them.  grid (nd + (m / 64) (n / 64)).
 // ---------------------------------------------------------------------------
-template <bool QT>
-__global__ __launch_bounds__(256, 4) void rows_fused_kernel(RowsJob ja, int nd, int ndx,
-                                                            double *__restrict__ C, long ldc,
-                                                            const double *__restrict__ P, long ldp,
-                                                            const double *__restrict__ Q, long ldq,
-                                                            int m, int n, int k)
+// KS = 2: eight waves per workgroup, both kinds of job split k twice as far (for steps whose
+// grid gives a CU at most two workgroups: the step's time is then ONE workgroup's k loop).
+template <bool QT, int KS = 1>
+__global__ __launch_bounds__(256 * KS, 4 / KS) void rows_fused_kernel(
+    RowsJob ja, int nd, int ndx, double *__restrict__ C, long ldc, const double *__restrict__ P,
+    long ldp, const double *__restrict__ Q, long ldq, int m, int n, int k)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int bid = blockIdx.x;
     if (bid < nd) {
-        rows_job_tile(ja, bid % ndx, bid / ndx, reinterpret_cast<double (*)[4][4][64]>(smem));
+        rows_job_tile<4 * KS>(ja, bid % ndx, bid / ndx,
+                              reinterpret_cast<double (*)[4][4][64]>(smem));
         return;
     }
     const int tix = bid - nd, mt = m / 64;
-    gemm_lds64_body<QT>(smem, C, ldc, P, ldp, Q, ldq, m, n, k, 0, 0x7fffffff, tix % mt, tix / mt);
+    gemm_lds64_body<QT, KS>(smem, C, ldc, P, ldp, Q, ldq, m, n, k, 0, 0x7fffffff, tix % mt,
+                            tix / mt);
 }

@@ -9,14 +9,16 @@ int gemm_init(bq_ctx *c)
 {
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lds_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, BQ_LDS_BYTES));
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lds64_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, BQ_L64_BYTES));
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lds64_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, BQ_L64_BYTES));
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(rows_fused_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, BQ_L64_BYTES));
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(rows_fused_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, BQ_L64_BYTES));
+#define BQ_L64_ATTR(F_, B_)                                                                        \
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(F_),                              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, B_))
+    BQ_L64_ATTR((gemm_lds64_kernel<false, 1>), BQ_L64_BYTES);
+    BQ_L64_ATTR((gemm_lds64_kernel<true, 1>), BQ_L64_BYTES);
+    BQ_L64_ATTR((rows_fused_kernel<false, 1>), BQ_L64_BYTES);
+    BQ_L64_ATTR((rows_fused_kernel<true, 1>), BQ_L64_BYTES);
+    BQ_L64_ATTR((rows_fused_kernel<false, 2>), BQ_L64_BYTES);
+    BQ_L64_ATTR((rows_fused_kernel<true, 2>), BQ_L64_BYTES);
+#undef BQ_L64_ATTR
     return BQ_OK;
 }
 
@@ -143,7 +145,7 @@ int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const dou
                            ccut > 0 ? ccut : 0x7fffffff);
     } else if (ldst == 64) {
         dim3 g = grid_for(64);
-        hipLaunchKernelGGL(gemm_lds64_kernel<false>, g, dim3(256), BQ_L64_BYTES, c->cur, C, ldc,
+        hipLaunchKernelGGL((gemm_lds64_kernel<false, 1>), g, dim3(256), BQ_L64_BYTES, c->cur, C, ldc,
                            cstride, P, ldp, pstride, Q, qsk, qstride, m, n, k, mode,
                            ccut > 0 ? ccut : 0x7fffffff);
     } else if (qsk == 1 && (qsj & 1) == 0 && fuse_j0 < 0 && (m % 64) == 0 &&
@@ -151,7 +153,7 @@ int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const dou
                tiles(64) >= c->cus / 2) {
         // Q given k-contiguous (the backward row sweep): the 64-tile kernel's transposed staging
         dim3 g = grid_for(64);
-        hipLaunchKernelGGL(gemm_lds64_kernel<true>, g, dim3(256), BQ_L64_BYTES, c->cur, C, ldc,
+        hipLaunchKernelGGL((gemm_lds64_kernel<true, 1>), g, dim3(256), BQ_L64_BYTES, c->cur, C, ldc,
                            cstride, P, ldp, pstride, Q, qsj, qstride, m, n, k, mode,
                            ccut > 0 ? ccut : 0x7fffffff);
     } else if (tiles(128) >= cu && n >= 128) {
@@ -207,12 +209,24 @@ int launch_rows_fused(bq_ctx *c, int mrows, const RowsJob &a, double *C, long ld
     Bracket br(c, BQ_K_GEMM, work);
     const int ndx = mrows / 32, nd = ndx * a.ny;
     const int nu = (n > 0 && k > 0) ? (mrows / 64) * (n / 64) : 0;
-    if (qt)
-        hipLaunchKernelGGL(rows_fused_kernel<true>, dim3(nd + nu), dim3(256), BQ_L64_BYTES, c->cur,
-                           a, nd, ndx, C, ldc, P, ldp, Q, ldq, mrows, n, k);
+    // a grid of at most two workgroups per CU: eight waves per workgroup.  The split-k job
+    // tiles walk their k range in half the steps (the last step of an N = 4096 sweep, job tiles
+    // only: 24 -> 16 us; a posterior variance at N = 1024: 0.067 -> 0.060 ms); the LDS tiles are
+    // MFMA-bound either way
+    const bool ks2 = c->gemm_ksplit && nd + nu <= 2 * c->cus && ((a.k1 + a.k2) % 128) == 0 &&
+                     (nu == 0 || k >= 32);
+#define BQ_ROWS_FUSED(QT_, KS_)                                                                    \
+    hipLaunchKernelGGL((rows_fused_kernel<QT_, KS_>), dim3(nd + nu), dim3(256 * KS_),              \
+                       BQ_L64_BYTES, c->cur, a, nd, ndx, C, ldc, P, ldp, Q, ldq, mrows, n, k)
+    if (qt && ks2)
+        BQ_ROWS_FUSED(true, 2);
+    else if (qt)
+        BQ_ROWS_FUSED(true, 1);
+    else if (ks2)
+        BQ_ROWS_FUSED(false, 2);
     else
-        hipLaunchKernelGGL(rows_fused_kernel<false>, dim3(nd + nu), dim3(256), BQ_L64_BYTES, c->cur,
-                           a, nd, ndx, C, ldc, P, ldp, Q, ldq, mrows, n, k);
+        BQ_ROWS_FUSED(false, 1);
+#undef BQ_ROWS_FUSED
     HIPCHK(c, hipGetLastError());
     return BQ_OK;
 }
@@ -221,7 +235,15 @@ int launch_rows_fused(bq_ctx *c, int mrows, const RowsJob &a, double *C, long ld
 int launch_rows_step(bq_ctx *c, int mrows, const RowsJob &a, const RowsJob &b, double work)
 {
     Bracket br(c, BQ_K_GEMM, work);
-    hipLaunchKernelGGL(rows_step_kernel, dim3(mrows / 32, a.ny + b.ny), dim3(256), 0, c->cur, a, b);
+    const bool nw8 = c->gemm_ksplit && ((a.k1 + a.k2) % 128) == 0 &&
+                     (b.ny == 0 || ((b.k1 + b.k2) % 128) == 0) &&
+                     (long)(mrows / 32) * (a.ny + b.ny) <= 2L * c->cus;
+    if (nw8)
+        hipLaunchKernelGGL(rows_step_kernel<8>, dim3(mrows / 32, a.ny + b.ny), dim3(512), 0, c->cur,
+                           a, b);
+    else
+        hipLaunchKernelGGL(rows_step_kernel<4>, dim3(mrows / 32, a.ny + b.ny), dim3(256), 0, c->cur,
+                           a, b);
     HIPCHK(c, hipGetLastError());
     return BQ_OK;
 }

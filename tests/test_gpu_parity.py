@@ -1067,6 +1067,46 @@ def test_predict_m1000_at_benched_size(engine, oracle):
     fit.close()
 
 
+def test_ksplit_variants_agree(engine):
+    """The eight-wave forms of the sweeps' step kernels (rows_step_kernel<8>,
+    rows_fused_kernel<., 2>; BQ_GEMM_KSPLIT, read when a context is created) against the
+    four-wave forms: a posterior variance at C2's size and a 256-column solve on an N = 4096
+    factor differ only in summation order."""
+    import os
+    from bayesian_quadrature_amd import Engine
+    old = os.environ.get("BQ_GEMM_KSPLIT")
+    os.environ["BQ_GEMM_KSPLIT"] = "0"
+    try:
+        eng4 = Engine(0)
+    finally:
+        if old is None:
+            os.environ.pop("BQ_GEMM_KSPLIT", None)
+        else:
+            os.environ["BQ_GEMM_KSPLIT"] = old
+    try:
+        c = wl.c2()
+        xo = np.linspace(-5.0, 5.0, 256) + 1e-3
+        res = []
+        for eng in (engine, eng4):
+            fit = eng.gp_fit(c["x"], c["y"], c["h"], c["w"], c["s"])
+            res.append(fit.predict(xo))
+            fit.close()
+        k0 = float(c["h"]) ** 2
+        assert relmax(res[0][0], res[1][0]) < 1e-12
+        assert relmax(res[0][1], res[1][1], scale=k0) < 1e-11
+        n = 4096
+        c4 = wl.c4(n)
+        B = np.asfortranarray(np.random.RandomState(5).randn(n, 256))
+        X = []
+        for eng in (engine, eng4):
+            fit = eng.gp_fit(c4["x"], wl.norm_logpdf(c4["x"]), c4["h"], c4["w"], c4["s"])
+            X.append(fit.solve(B))
+            fit.close()
+        assert relmax(X[0], X[1]) < 1e-9  # (cond(K) ~ 1e6: both are within it of the solution)
+    finally:
+        eng4.close()
+
+
 def test_cho_solve_mat_square_multi_block(engine, oracle):
     """``la.cho_solve_mat`` as the reference uses it -- B square (linalg_c.pyx:166) -- at
     n = 1100: several 256-column steps of the row sweeps AND many right-hand sides (a partial
