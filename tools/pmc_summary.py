@@ -163,7 +163,12 @@ def main():
                      "counters only); mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 "
                      "XCDs x 256 CUs x 4 SIMDs)", "passes": {}}
     for p in ("potrf256", "c5"):
-        m = counters(os.path.join(O, "m_" + p)).get("gemm_lds_kernel")
+        cs = counters(os.path.join(O, "m_" + p))
+        # the kernel that carries the pass's trailing updates: the 128-tile LDS kernel for the
+        # N = 16384 factorisation, the 64-tile one for the half-batches of a C5 shard
+        kname = "gemm_lds_kernel" if p == "potrf256" else next(
+            (k for k in cs if k.startswith("gemm_lds64_kernel<false")), "gemm_lds_kernel")
+        m = cs.get(kname)
         if not m:
             continue
         n = len(m["GRBM_GUI_ACTIVE"])
@@ -173,7 +178,7 @@ def main():
             sel = range(min(n, nbulk))
         s = {c: sum(v[i] for i in sel) for c, v in m.items()}
         mu["passes"][p] = {
-            "kernel": "gemm_lds_kernel", "launches": len(sel), "sums": s,
+            "kernel": kname, "launches": len(sel), "sums": s,
             "mfma_util": s["SQ_VALU_MFMA_BUSY_CYCLES"] / (s["GRBM_GUI_ACTIVE"] / 8 * 256 * 4),
             "flop_from_MOPS": s["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0,
             "algorithmic_flop": summary.get("bulk", {}).get("flop") if p == "potrf256" else None}

@@ -1,9 +1,7 @@
-"""Socket power and shader clock (rocm-smi) WHILE a kernel runs for seconds: the fp64 MFMA loop
+"""Socket power and shader clock (hwmon) WHILE a kernel runs for seconds: the fp64 MFMA loop
 without memory, and the LDS-staged trailing-update kernel on random operands -- the evidence for
 DESIGN.md's "the product is power-bound" paragraph.  BQ_GEMM_TILE=64|128 python tools/power_probe.py"""
 import os
-import re
-import subprocess
 import sys
 import threading
 import time
@@ -15,11 +13,10 @@ e = Engine(0)
 
 
 def smi():
-    out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True,
-                         text=True).stdout
-    sclk = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
-    pw = re.search(r"Power \(W\): ([\d.]+)", out)
-    return (int(sclk.group(1)) if sclk else -1, float(pw.group(1)) if pw else -1.0)
+    """(sclk MHz, socket watts) from the card's hwmon node (bench.py's sampler: plain sysfs reads)"""
+    import bench
+    v = bench._hwmon_sample()
+    return (int(v[1]), v[0]) if v else (-1, -1.0)
 
 
 def watch(name, fn, rate):

@@ -29,4 +29,8 @@ python3 tools/pmc_summary.py $O r03 > $O/summary.txt 2>&1 || { echo summary-fail
 find $O -name "*agent_info.csv" -delete
 find $O -name "*kernel_trace.csv" -size +3M -delete
 du -sh $O
+BQ_GEMM_TILE=128 python tools/power_probe.py > $O/power_probe_tile128.txt 2>&1 || echo power-128-failed
+BQ_GEMM_TILE=64 python tools/power_probe.py > $O/power_probe_tile64.txt 2>&1 || echo power-64-failed
+python tools/mfma_sustained.py > $O/mfma_sustained.txt 2>&1 || echo mfma-sustained-failed
+python tools/gemm_probe.py > $O/gemm_probe.txt 2>&1 || echo gemm-probe-failed
 python bench.py > $O/bench.json 2> $O/bench2.err; echo bench rc=$?
