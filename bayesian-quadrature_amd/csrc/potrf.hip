@@ -32,11 +32,24 @@ int auto_nb(const bq_ctx *c, int ntot, int batch)
         // update (N = 8192: 5.43 / 5.56 ms with 256 / 512, 12288: 13.55 / 13.11, 16384: 28.0 / 26.9)
         return ntot < 12000 ? 256 : 512;
     }
+    // A few small matrices (the stacked parameter sets of the hyper-parameter loops: 5-6 systems
+    // of the sample count) are a chain of dependent launches like one matrix is, and the
+    // one-launch steps stay the shortest chain while a step's workgroups -- batch x T (T + 1) / 2
+    // tiles, each with its redundant panel solves -- fit the chip about five times over
+    // (tools/nb_sweep.py, ms with blocks 64 / 128 / 256: 5 x N=1024 0.377 / 0.475 / 0.512,
+    // 12 x 1024 0.564 / 0.611 / 0.664, 16 x 1024 0.667 / 0.648 / 0.697, 8 x 1536 0.940 / 0.953 /
+    // 0.977, 5 x 2048 1.237 / 1.138 / 1.185; the hyper-parameter objective + gradient at 1024
+    // samples 0.99 -> 0.78 ms)
+    const long T = ntot / 64;
+    if ((long)batch * T * (T + 1) / 2 <= 2500)
+        return 64;
     // (batches of mid-sized matrices, recursive panels: C5 shard 6.55 / 6.42 / 6.70 / 6.57 ms
-    // with 256 / 320 / 384 / 512; 256 x C2 5.72 / 5.47 / 5.64 ms with 256 / 320 / 448)
-    if (ntot >= 1024 && mb >= 100.0)
+    // with 256 / 320 / 384 / 512; 256 x C2 5.72 / 5.47 / 5.64 ms with 256 / 320 / 448; below
+    // half a gigabyte 128 is still ahead: 12 x N=2048 1.694 / 1.716, 16 x 2048 2.024 / 1.954,
+    // 5 x 3072 2.250 / 2.272, 8 x 3072 3.069 / 2.856 with 128 / 256)
+    if (ntot >= 1024 && mb >= 500.0)
         return 320;
-    if (ntot >= 512 && mb >= 30.0)
+    if (ntot >= 512)
         return 128;
     return 64;
 }

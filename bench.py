@@ -226,18 +226,6 @@ def make_workload(name, batch, rank):
                 B=B, desc=desc)
 
 
-def auto_nb(ntot, override, batch=1):
-    """Mirror of auto_nb() in csrc/potrf.hip (outer Cholesky block)."""
-    if override:
-        return override
-    mb = 8.0 * ntot * ntot * batch / 1e6
-    if ntot >= 1024 and mb >= 100.0:
-        return 256
-    if ntot >= 512 and mb >= 30.0:
-        return 128
-    return 64
-
-
 def run_main(eng, wk, steps, warmup, dist):
     plan = eng.plan(wk["B"], wk["d"], wk["n"], wk["M"])
     plan.set_inputs(wk["x"], wk["y"], wk["xo"], wk["h"], wk["w"], wk["s"])
