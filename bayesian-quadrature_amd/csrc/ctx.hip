@@ -102,6 +102,10 @@ static int ctx_init(bq_ctx *c, int device)
         c->gemm_lds = std::atoi(e);
     if (const char *e = std::getenv("BQ_GEMM_LDS64"))
         c->gemm_lds64 = std::atoi(e);
+    if (const char *e = std::getenv("BQ_SLAB_NB_MAX"))
+        c->slab_nb_max = std::atoi(e);
+    if (const char *e = std::getenv("BQ_SLAB_MAX"))
+        c->slab_max = std::atoi(e);
     if (const char *e = std::getenv("BQ_GEMM_KSPLIT"))
         c->gemm_ksplit = std::atoi(e);
     if (const char *e = std::getenv("BQ_GEMM_TILE"))

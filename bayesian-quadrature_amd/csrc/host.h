@@ -90,6 +90,8 @@ struct bq_ctx {
                          // between calls (hipFree synchronises the device); bq_ctx_trim frees it
     int gemm_lds = 1;    // LDS-staged 128x128 trailing update (BQ_GEMM_LDS)
     int gemm_lds64 = 1;  // its 64x64-tile form for products that cannot fill the chip (BQ_GEMM_LDS64)
+    int slab_nb_max = 3072; // one or two matrices below this size: one-launch steps throughout (BQ_SLAB_NB_MAX)
+    int slab_max = 4800;    // ... and the last rows of a larger one, from this many on (BQ_SLAB_MAX)
     int gemm_ksplit = 1; // eight-wave k-split forms of the 64-tile / job kernels (BQ_GEMM_KSPLIT)
     int gemm_tile = 0;   // 64 / 128: force the LDS kernel's workgroup tile (BQ_GEMM_TILE; measurements)
     int sharing = 0;     // how the chip is shared while the launches being queued run (gemm_lds_tile):

@@ -5,11 +5,6 @@
 
 namespace bqh {
 
-// below this size one or two matrices sweep with the one-launch steps of outer block 64
-// (tools/potrf_sizes.py, ms with blocks 64 / 128 / 256: N = 2048 0.57 / 0.76 / 0.80,
-// 4096 1.69 / 1.93 / 1.92, 6144 4.21 / 3.72 / 3.57)
-#define BQ_SLAB_MAX 4800
-
 int auto_nb(const bq_ctx *c, int ntot, int batch)
 {
     if (c->nb_override > 0)
@@ -22,10 +17,13 @@ int auto_nb(const bq_ctx *c, int ntot, int batch)
     if (batch <= 2) {
         // One or two matrices cannot fill the chip with a 64-column panel: the sweep is a
         // chain of dependent launches and the one-launch step of outer block 64 (slab.h) is
-        // the shortest chain until the k = 64 updates cost more than it saves
-        // (tools/potrf_sizes.py on one matrix: N=2048 0.73 / 0.81 ms, 3072 1.24 / 1.31,
-        // 4096 2.03 / 2.00, 6144 4.37 / 3.83 with blocks 64 / 128; 8192 6.49 / 6.44 with 128 / 256)
-        if (ntot < BQ_SLAB_MAX)
+        // the shortest chain until the k = 64 updates cost more than it saves.  Re-measured in
+        // round 3 with the 64-tile trailing updates (tools/potrf_sizes.py on one matrix, ms with
+        // blocks 64 / 256: N=2560 0.761 / 0.774, 3072 1.013 / 0.995, 3584 1.346 / 1.318, 4096
+        // 1.776 / 1.617, 4608 2.311 / 1.967): from 3072 rows the first panels are blocked (with
+        // the look-ahead once there is room for it) and the LAST rows go to the one-launch steps
+        // (slab_max / la_min, enqueue_potrf_group)
+        if (ntot < c->slab_nb_max)
             return 64;
         // a wider block halves the trailing update's C traffic per flop (60 instead of 56
         // TFLOP/s at k = 512); it pays once the panel it lengthens hides behind the bulk
@@ -297,7 +295,7 @@ static int enqueue_potrf_group(bq_ctx *c, double *A, long lda, long astride, int
         // The last rows of a large matrix are a small factorisation of their own -- the
         // Schur complement once this block's update is in --, and for one or two matrices
         // the one-launch steps are its shortest chain: hand the rest to the slab sweep.
-        const bool to_slab = batch <= 2 && ws && NB > 64 && r0 < ncols && ntot - r0 < BQ_SLAB_MAX;
+        const bool to_slab = batch <= 2 && ws && NB > 64 && r0 < ncols && ntot - r0 < c->slab_max;
         if (r0 < ntot) {
             const double *P = A + r0 + (long)K0 * lda;
             // the trailing update also factors the next diagonal block if there is one
