@@ -27,8 +27,10 @@ int auto_nb(const bq_ctx *c, int ntot, int batch)
             return 64;
         // a wider block halves the trailing update's C traffic per flop (60 instead of 56
         // TFLOP/s at k = 512); it pays once the panel it lengthens hides behind the bulk
-        // update (N = 8192: 5.43 / 5.56 ms with 256 / 512, 12288: 13.55 / 13.11, 16384: 28.0 / 26.9)
-        return ntot < 12000 ? 256 : 512;
+        // update (round 3, ms with 256 / 320 / 384 / 512: N = 5120 2.354 / 2.330 / 2.289 / 2.378,
+        // 8192 5.432 / 5.357 / 5.306 / 5.416, 10240 8.687 / 8.552 / 8.441 / 8.422, 12288 13.29 /
+        // 12.92 / 12.79 / 12.71, 16384 27.36 / 26.72 / 26.19 / 26.00)
+        return ntot < 9216 ? 384 : 512;
     }
     // A few small matrices (the stacked parameter sets of the hyper-parameter loops: 5-6 systems
     // of the sample count) are a chain of dependent launches like one matrix is, and the
