@@ -22,6 +22,10 @@ struct bq_pair {
     int ns = 0, nc = 0, ma = 0, S = 0, nsc = 0;
     bq_plan *p1 = nullptr; // GP1: n = ns, M = nc + ma
     bq_plan *p2 = nullptr; // GP2: n = nsc, M = 0 (the objective; the acquisition has its own systems)
+    // nc = 0 (every candidate filtered out: dense samples) and no acquisition points: GP2's
+    // targets are the samples' own values, nothing of it depends on GP1, and both have ns
+    // points -- ONE plan of 2 S systems (p1; first S: GP1, last S: GP2), one sweep instead of two
+    bool merged = false;
     DevBuf l_s, x_sc, x_a, y2, flag;
     // stage 2 of bq_pair_esm, kept between calls (choose_next calls it once per step with the
     // same shapes; allocating and releasing its tens of GB per call costs more than the pass)
@@ -130,11 +134,25 @@ extern "C" int bq_pair_create(bq_ctx *c, const double *x_s, const double *tl_s, 
         std::memcpy(xsc.data() + ns, x_c, sizeof(double) * nc);
     for (int64_t b = 0; b < S; ++b)
         std::memcpy(&xr2[(size_t)b * nsc], xsc.data(), sizeof(double) * nsc);
-    st = bq_plan_create(c, S, 1, ns, M1, &pr->p1);
-    if (st == BQ_OK)
-        st = bq_plan_set_inputs(c, pr->p1, xr.data(), yr.data(), M1 ? xo.data() : nullptr,
-                                one.data(), one.data(), zero.data());
-    if (st == BQ_OK && ma == 0) {
+    pr->merged = nc == 0 && ma == 0;
+    if (pr->merged) {
+        std::vector<double> x2((size_t)2 * S * ns), y2((size_t)2 * S * ns), one2((size_t)2 * S, 1.0),
+            zero2((size_t)2 * S, 0.0);
+        for (int64_t b = 0; b < 2 * S; ++b) {
+            std::memcpy(&x2[(size_t)b * ns], x_s, sizeof(double) * ns);
+            std::memcpy(&y2[(size_t)b * ns], b < S ? tl_s : l_s, sizeof(double) * ns);
+        }
+        st = bq_plan_create(c, 2 * S, 1, ns, 0, &pr->p1);
+        if (st == BQ_OK)
+            st = bq_plan_set_inputs(c, pr->p1, x2.data(), y2.data(), nullptr, one2.data(),
+                                    one2.data(), zero2.data());
+    } else {
+        st = bq_plan_create(c, S, 1, ns, M1, &pr->p1);
+        if (st == BQ_OK)
+            st = bq_plan_set_inputs(c, pr->p1, xr.data(), yr.data(), M1 ? xo.data() : nullptr,
+                                    one.data(), one.data(), zero.data());
+    }
+    if (st == BQ_OK && ma == 0 && !pr->merged) {
         st = bq_plan_create(c, S, 1, nsc, 0, &pr->p2);
         if (st == BQ_OK)
             st = bq_plan_set_inputs(c, pr->p2, xr2.data(), yr2.data(), nullptr, one.data(),
@@ -196,7 +214,7 @@ extern "C" int bq_pair_llh(bq_ctx *c, bq_pair *pr, const double *p_tl, const dou
         return BQ_ERR_BAD_ARG;
     if (!pr || !p_tl || !p_l || !llh)
         return fail(c, BQ_ERR_BAD_ARG, "illegal value");
-    if (!pr->p2)
+    if (pr->ma)
         return fail(c, BQ_ERR_BAD_ARG, "pair was created for the acquisition (ma > 0)");
     const int S = pr->S, nsc = pr->nsc;
     BQCHK(check_params(c, p_tl, S, "pair_llh (GP1)"));
@@ -209,22 +227,36 @@ extern "C" int bq_pair_llh(bq_ctx *c, bq_pair *pr, const double *p_tl, const dou
         pr->hpar[b] = make_params(1, p_tl[3 * b], w1, p_tl[3 * b + 2]);
         pr->hpar[S + b] = make_params(1, p_l[3 * b], w2, p_l[3 * b + 2]);
     }
-    HIPCHK(c, hipMemcpyAsync(pr->p1->gp.p, pr->hpar, sizeof(GaussParams) * S,
-                             hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(pr->p2->gp.p, pr->hpar + S, sizeof(GaussParams) * S,
-                             hipMemcpyHostToDevice, c->stream));
-    BQCHK(bq_plan_run(c, pr->p1));
-    HIPCHK(c, hipMemsetAsync(pr->flag.p, 0, sizeof(int) * S, c->stream));
-    const long ms = std::max(nc, 1), ys = pr->p2->L.npad;
-    hipLaunchKernelGGL(pair_targets_kernel, dim3((nsc + 255) / 256, S), dim3(256), 0, c->stream,
-                       pr->l_s.d(), ns, nc, pr->p1->mean.d(), pr->p1->var.d(), ms, max_log(),
-                       pr->p2->y.d(), ys, pr->flag.i());
-    HIPCHK(c, hipGetLastError());
-    BQCHK(bq_plan_run(c, pr->p2));
-    hipLaunchKernelGGL(pair_collect_kernel, dim3(S), dim3(64), 0, c->stream, pr->p1->scal.d(),
-                       pr->p2->scal.d(), pr->p1->info.i(), pr->p2->info.i(), pr->flag.i(),
-                       pr->p2->y.d(), ys, ns, nc, pr->dres.d());
-    HIPCHK(c, hipGetLastError());
+    if (pr->merged) {
+        // one plan of 2 S systems: [GP1 under the S sets | GP2 under the S sets]
+        HIPCHK(c, hipMemcpyAsync(pr->p1->gp.p, pr->hpar, sizeof(GaussParams) * 2 * S,
+                                 hipMemcpyHostToDevice, c->stream));
+        BQCHK(bq_plan_run(c, pr->p1));
+        HIPCHK(c, hipMemsetAsync(pr->flag.p, 0, sizeof(int) * S, c->stream));
+        hipLaunchKernelGGL(pair_collect_kernel, dim3(S), dim3(64), 0, c->stream, pr->p1->scal.d(),
+                           pr->p1->scal.d() + 4 * S, pr->p1->info.i(), pr->p1->info.i() + S,
+                           pr->flag.i(), pr->p1->y.d(), (long)pr->p1->L.npad, ns, 0,
+                           pr->dres.d());
+        HIPCHK(c, hipGetLastError());
+    } else {
+        HIPCHK(c, hipMemcpyAsync(pr->p1->gp.p, pr->hpar, sizeof(GaussParams) * S,
+                                 hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(pr->p2->gp.p, pr->hpar + S, sizeof(GaussParams) * S,
+                                 hipMemcpyHostToDevice, c->stream));
+        BQCHK(bq_plan_run(c, pr->p1));
+        HIPCHK(c, hipMemsetAsync(pr->flag.p, 0, sizeof(int) * S, c->stream));
+        const long ms = std::max(nc, 1), ys = pr->p2->L.npad;
+        hipLaunchKernelGGL(pair_targets_kernel, dim3((nsc + 255) / 256, S), dim3(256), 0,
+                           c->stream, pr->l_s.d(), ns, nc, pr->p1->mean.d(), pr->p1->var.d(), ms,
+                           max_log(), pr->p2->y.d(), ys, pr->flag.i());
+        HIPCHK(c, hipGetLastError());
+        BQCHK(bq_plan_run(c, pr->p2));
+        hipLaunchKernelGGL(pair_collect_kernel, dim3(S), dim3(64), 0, c->stream,
+                           pr->p1->scal.d(), pr->p2->scal.d(), pr->p1->info.i(),
+                           pr->p2->info.i(), pr->flag.i(), pr->p2->y.d(), ys, ns, nc,
+                           pr->dres.d());
+        HIPCHK(c, hipGetLastError());
+    }
     HIPCHK(c, hipMemcpyAsync(pr->hres, pr->dres.p, sizeof(double) * (size_t)S * (5 + nc),
                              hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
