@@ -329,8 +329,12 @@ class BQ(object):
             if pn is None:
                 raise RuntimeError("couldn't find good starting parameters")
             p0 = pn
+        # points per device pass: sixteen stacked systems of a few dozen points cost what six do
+        # (a pass is launch-bound there), and a window that steps out far is walked six
+        # positions per end and pass instead of two; large systems keep the narrow pass
+        spec = 14 if self.ns + self.nc <= 128 else 4
         hypers = util.slice_sample(f, nburn + n, window, p0, nburn=nburn, freq=1,
-                                   logpdf_batch=self._make_llh_batch(params))
+                                   logpdf_batch=self._make_llh_batch(params), spec=spec)
         f(hypers[-1])  # the chain's last evaluated point, as the sequential sampler leaves it
         return hypers[:, :nparam], hypers[:, nparam:]
 

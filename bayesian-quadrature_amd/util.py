@@ -105,6 +105,9 @@ def _slice_sample(samples, logpdf, xval, w, verbose=False):
                 right = loc
 
 
+_PEEK_RS = np.random.RandomState(0)
+
+
 def _slice_sample_batched(samples, logpdf_batch, xval, w, spec=4):
     """The same chain as ``_slice_sample`` -- the same random draws in the same order, the same
     comparisons -- with the log-pdf evaluated in BATCHES of ``spec + 2`` points per device pass.
@@ -135,7 +138,7 @@ def _slice_sample_batched(samples, logpdf_batch, xval, w, spec=4):
 
     def peek(left, right, k):
         """the next k shrinkage proposals if every one of them is rejected"""
-        rs = np.random.RandomState()
+        rs = _PEEK_RS  # (constructing a RandomState seeds it from the OS: 50 us a time)
         rs.set_state(np.random.get_state())
         out = []
         for _ in range(k):
@@ -178,8 +181,10 @@ def _slice_sample_batched(samples, logpdf_batch, xval, w, spec=4):
                 out.append(t)
             return out
 
+        # (a window that keeps stepping out: half of a pass for each end's next positions)
+        half = max(2, (S - 2) // 2)
         for _ in range(101):
-            if val(left, steps(left, -w, 2) + [right] + steps(right, w, 2)) < logyval:
+            if val(left, steps(left, -w, half) + [right] + steps(right, w, half)) < logyval:
                 break
             left -= w
         for _ in range(101):
@@ -200,16 +205,17 @@ def _slice_sample_batched(samples, logpdf_batch, xval, w, spec=4):
             left, right = nl, nr
 
 
-def slice_sample(logpdf, niter, w, xval, nburn=1, freq=1, logpdf_batch=None):
+def slice_sample(logpdf, niter, w, xval, nburn=1, freq=1, logpdf_batch=None, spec=4):
     """Draw ``niter`` states starting at ``xval``; drops the first ``nburn`` and
     keeps every ``freq``-th of the rest.  ``logpdf_batch`` (S x d array -> S values): evaluate
-    the chain's requests in batched device passes (``_slice_sample_batched``)."""
+    the chain's requests in batched device passes of ``spec + 2`` points
+    (``_slice_sample_batched``)."""
     xval = np.asarray(xval, dtype=np.float64)
     samples = np.empty((niter, xval.size))
     samples[0] = xval
     verbose = (logger.level != 0) and (logger.level < 10)
     if logpdf_batch is not None:
-        _slice_sample_batched(samples, logpdf_batch, xval, float(w))
+        _slice_sample_batched(samples, logpdf_batch, xval, float(w), spec)
     else:
         _slice_sample(samples, logpdf, xval, float(w), verbose)
     return samples[nburn:][::freq]
