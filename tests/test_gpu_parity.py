@@ -411,12 +411,15 @@ def test_batch_fit_predict(engine, oracle):
         assert abs(logml[i] - lmo) <= RTOL * abs(lmo)
 
 
-def test_batch_fit_predict_mid_block(engine, oracle):
-    """24 x (N = 600, M = 40): the batch regime with outer block 128 (recursive panels, results
+@pytest.mark.parametrize("n", [600, 900])
+def test_batch_fit_predict_mid_block(engine, oracle, n):
+    """24 x (N = 900, M = 40): the batch regime with outer block 128 (recursive panels, results
     read off the border rows, most updates too small for the kernel that skips the border
-    block) -- between the one-launch steps of small systems and the C5-sized batches."""
+    block) -- between the one-launch steps of small systems and the C5-sized batches; 24 x
+    (N = 600): since round 3 still on the one-launch steps (a step's 24 x 66 workgroups fit
+    the chip a few times over: auto_nb)."""
     probs = list(range(24))
-    c = wl.c5(probs, n=600, m=40)
+    c = wl.c5(probs, n=n, m=40)
     mean, var, logml, status = engine.batch_fit_predict(c["x"], c["y"], c["h"], c["w"] * 3,
                                                         c["s"], c["xo"])
     assert (status == 0).all()
