@@ -47,8 +47,10 @@ int auto_nb(const bq_ctx *c, int ntot, int batch)
     // with 256 / 320 / 384 / 512; 256 x C2 5.72 / 5.47 / 5.64 ms with 256 / 320 / 448; below
     // half a gigabyte 128 is still ahead: 12 x N=2048 1.694 / 1.716, 16 x 2048 2.024 / 1.954,
     // 5 x 3072 2.250 / 2.272, 8 x 3072 3.069 / 2.856 with 128 / 256)
+    // (re-measured at the end of round 3, 320 against 448 in one box: C3 190.4 / 187.0 ms,
+    // 256 x C2 5.23 / 5.16, C5 shard 5.82 / 5.80)
     if (ntot >= 1024 && mb >= 500.0)
-        return 320;
+        return 448;
     if (ntot >= 512)
         return 128;
     return 64;
