@@ -92,6 +92,8 @@ struct bq_ctx {
     int gemm_lds64 = 1;  // its 64x64-tile form for products that cannot fill the chip (BQ_GEMM_LDS64)
     int slab_nb_max = 3072; // one or two matrices below this size: one-launch steps throughout (BQ_SLAB_NB_MAX)
     int slab_max = 4800;    // ... and the last rows of a larger one, from this many on (BQ_SLAB_MAX)
+    int potf2_8w = 1;    // the one-launch steps' diagonal factor on eight waves where a step's workgroups
+                         // have a CU each (BQ_POTF2_8W)
     int gemm_ksplit = 1; // eight-wave k-split forms of the 64-tile / job kernels (BQ_GEMM_KSPLIT)
     int gemm_tile = 0;   // 64 / 128: force the LDS kernel's workgroup tile (BQ_GEMM_TILE; measurements)
     int sharing = 0;     // how the chip is shared while the launches being queued run (gemm_lds_tile):

@@ -47,7 +47,12 @@ int launch_potf2(bq_ctx *c, double *A, long lda, long astride, int j0, double *d
                  int *info, int batch)
 {
     Bracket br(c, BQ_K_POTF2, 64.0 * 64 * 64 / 3.0 * batch);
-    hipLaunchKernelGGL(potf2_kernel, dim3(1, 1, batch), dim3(256), 0, c->cur, A, lda, astride,
+    // (eight waves where every matrix of the batch has a CU: potf2f_body<8>)
+    if (c->potf2_8w && batch <= c->cus)
+        hipLaunchKernelGGL(potf2_kernel<8>, dim3(1, 1, batch), dim3(512), 0, c->cur, A, lda, astride,
+                           j0, dinv, dstride, info);
+    else
+        hipLaunchKernelGGL(potf2_kernel<4>, dim3(1, 1, batch), dim3(256), 0, c->cur, A, lda, astride,
                            j0, dinv, dstride, info);
     HIPCHK(c, hipGetLastError());
     return BQ_OK;
@@ -108,13 +113,25 @@ int launch_slab_step(bq_ctx *c, double *A, long lda, long astride, int batch, do
 {
     const int T = (ntot - j0 - 64) / 64;
     Bracket br(c, BQ_K_SYRK_SMALL, work);
-    if (stamps)
-        hipLaunchKernelGGL(slab_step_kernel<true>, dim3(T * (T + 1) / 2, 1, batch), dim3(256), 0,
+    const long wgs = (long)T * (T + 1) / 2 * batch;
+    const bool w8 = c->potf2_8w && fnext && wgs <= c->cus;
+    if (stamps && w8)
+        hipLaunchKernelGGL((slab_step_kernel<true, 8>), dim3(T * (T + 1) / 2, 1, batch), dim3(512), 0,
                            c->cur, A, lda, astride, Sin, Sout, lds, sstride, ntot, j0, dinv_in,
                            dinv_out, (long)BQ_DINV_STRIDE, fnext, last, info, col0, stamps);
-    else
-        hipLaunchKernelGGL(slab_step_kernel<false>, dim3(T * (T + 1) / 2, 1, batch), dim3(256), 0,
+    else if (stamps)
+        hipLaunchKernelGGL((slab_step_kernel<true, 4>), dim3(T * (T + 1) / 2, 1, batch), dim3(256), 0,
                            c->cur, A, lda, astride, Sin, Sout, lds, sstride, ntot, j0, dinv_in,
+                           dinv_out, (long)BQ_DINV_STRIDE, fnext, last, info, col0, stamps);
+    else if (w8)
+        // a CU per workgroup: 512 threads, the diagonal factor on eight waves
+        hipLaunchKernelGGL((slab_step_kernel<false, 8>), dim3(T * (T + 1) / 2, 1, batch), dim3(512),
+                           0, c->cur, A, lda, astride, Sin, Sout, lds, sstride, ntot, j0, dinv_in,
+                           dinv_out, (long)BQ_DINV_STRIDE, fnext, last, info, col0,
+                           (long long *)nullptr);
+    else
+        hipLaunchKernelGGL((slab_step_kernel<false, 4>), dim3(T * (T + 1) / 2, 1, batch), dim3(256),
+                           0, c->cur, A, lda, astride, Sin, Sout, lds, sstride, ntot, j0, dinv_in,
                            dinv_out, (long)BQ_DINV_STRIDE, fnext, last, info, col0,
                            (long long *)nullptr);
     HIPCHK(c, hipGetLastError());

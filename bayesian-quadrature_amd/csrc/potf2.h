@@ -20,9 +20,12 @@
 //     the next owner applying columns as they appear) were SLOWER: 24,500 cycles;
 //   * the block inverses and the write-back after the chain were 5,800 cycles, 41 LDS waits.
 // ===========================================================================
-struct Potf2F {
-    double a[4][4]; // a[q][s] = column 16q + 4w + s of row `lane`
+// NW waves (4, or 8: two per SIMD -- potf2f_body): panel P = columns 4P .. 4P + 3 belongs to wave
+// P % NW, which holds it as its group P / NW
+template <int NW> struct Potf2FT {
+    double a[16 / NW][4]; // a[g][s] = column 4 (NW g + w) + s of row `lane`
 };
+using Potf2F = Potf2FT<4>;
 
 // LDS of the factor: a ring of three panel slots (4 x 64 doubles each) inside the first 4096
 // doubles -- the region may hold the factor's own input block, which every wave has in
@@ -42,10 +45,10 @@ struct Potf2F {
 // no per-pivot selects, no failure bookkeeping -- a non-positive pivot makes r NaN or infinite
 // and everything after it NaN, and potf2f_body finds it afterwards as the first NaN on the
 // diagonal.
-template <int P>
-__device__ __forceinline__ void potf2f_factor(Potf2F &st, double *slot, int lane)
+template <int P, int NW = 4>
+__device__ __forceinline__ void potf2f_factor(Potf2FT<NW> &st, double *slot, int lane)
 {
-    constexpr int QP = P >> 2;
+    constexpr int QP = P / NW;
     double dn = st.a[QP][0];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -72,18 +75,19 @@ __device__ __forceinline__ void potf2f_factor(Potf2F &st, double *slot, int lane
 // panel's entries in this lane's row).  All multipliers of all groups are requested before
 // the first FMA (uniform ds_read_b128, two columns each): one LDS latency per call instead
 // of one per group -- the waves that only update were the slow ones of the early panels.
-template <int QMASK>
-__device__ __forceinline__ void potf2f_update(Potf2F &st, const double *slot,
+template <int QMASK, int NW = 4>
+__device__ __forceinline__ void potf2f_update(Potf2FT<NW> &st, const double *slot,
                                               const double (&li)[4], int w)
 {
-    double2_t lk[4][4][2];
+    constexpr int NG = 16 / NW;
+    double2_t lk[NG][4][2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < NG; ++q)
         if (QMASK & (1 << q)) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const double2_t *src =
-                    reinterpret_cast<const double2_t *>(slot + s * 64 + 16 * q + 4 * w);
+                    reinterpret_cast<const double2_t *>(slot + s * 64 + 4 * (NW * q + w));
                 lk[q][s][0] = src[0];
                 lk[q][s][1] = src[1];
             }
@@ -91,7 +95,7 @@ __device__ __forceinline__ void potf2f_update(Potf2F &st, const double *slot,
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NG; ++q)
             if (QMASK & (1 << q)) {
                 st.a[q][0] = __builtin_fma(-li[s], lk[q][s][0][0], st.a[q][0]);
                 st.a[q][1] = __builtin_fma(-li[s], lk[q][s][0][1], st.a[q][1]);
@@ -99,7 +103,7 @@ __device__ __forceinline__ void potf2f_update(Potf2F &st, const double *slot,
                 st.a[q][3] = __builtin_fma(-li[s], lk[q][s][1][1], st.a[q][3]);
             }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < NG; ++q)
         if (QMASK & (1 << q)) {
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc)
@@ -107,8 +111,8 @@ __device__ __forceinline__ void potf2f_update(Potf2F &st, const double *slot,
         }
 }
 
-// groups after Q: bits Q+1 .. 3
-#define BQ_LATER(Q) ((0xF << ((Q) + 1)) & 0xF)
+// groups after Q of NG: bits Q+1 .. NG-1
+#define BQ_LATER(Q, NG) (((1 << (NG)) - 1) & ~((1 << ((Q) + 1)) - 1))
 
 // Step P, entered with panel P factored by its owner (wave P & 3) and on its way to slot
 // P % 3 of the ring; ONE workgroup barrier per panel:
@@ -118,52 +122,58 @@ __device__ __forceinline__ void potf2f_update(Potf2F &st, const double *slot,
 //     before step P + 1) and applies its own panel P to its later groups;
 //   * the other two waves apply panel P to everything of theirs that lies behind it.
 // wst (profiling probe only): every wave's arrival at and release from barrier P.
-template <int P>
+template <int P, int NW = 4>
 struct Potf2FSteps {
-    static __device__ __forceinline__ void run(Potf2F &st, double *slots, int w, int lane,
+    static __device__ __forceinline__ void run(Potf2FT<NW> &st, double *slots, int w, int lane,
                                                long long *wst)
     {
-        constexpr int QP = P >> 2, WP = P & 3;
-        constexpr int PN = P < 15 ? P + 1 : 15, QN = PN >> 2, WN = PN & 3;
+        constexpr int NG = 16 / NW;
+        constexpr int QP = P / NW, WP = P % NW;
+        constexpr int PN = P < 15 ? P + 1 : 15, QN = PN / NW, WN = PN % NW;
+        constexpr int LATER = BQ_LATER(QP, NG);
         const double *slot = slots + (P % 3) * 256;
         if (wst && lane == 0)
-            wst[(4 * P + w) * 2] = (long long)__builtin_amdgcn_s_memtime();
+            wst[(NW * P + w) * 2] = (long long)__builtin_amdgcn_s_memtime();
         __syncthreads(); // panel P is published
         if (wst && lane == 0)
-            wst[(4 * P + w) * 2 + 1] = (long long)__builtin_amdgcn_s_memtime();
+            wst[(NW * P + w) * 2 + 1] = (long long)__builtin_amdgcn_s_memtime();
         double li[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s)
             li[s] = slot[s * 64 + lane];
         if (P < 15 && w == WN) {
-            potf2f_update<(1 << QN)>(st, slot, li, w);
-            potf2f_factor<PN>(st, slots + (PN % 3) * 256, lane);
+            potf2f_update<(1 << QN), NW>(st, slot, li, w);
+            potf2f_factor<PN, NW>(st, slots + (PN % 3) * 256, lane);
         } else if (w == WP) {
-            if (P >= 1 && BQ_LATER(QP) != 0) {
+            if (P >= 1 && LATER != 0) {
                 const double *prev = slots + ((P + 2) % 3) * 256;
                 double lp[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
                     lp[s] = prev[s * 64 + lane];
-                potf2f_update<BQ_LATER(QP)>(st, prev, lp, w);
+                potf2f_update<LATER, NW>(st, prev, lp, w);
             }
-            potf2f_update<BQ_LATER(QP)>(st, slot, li, w);
+            potf2f_update<LATER, NW>(st, slot, li, w);
         } else if (w > WP) {
-            potf2f_update<(1 << QP) | BQ_LATER(QP)>(st, slot, li, w);
+            potf2f_update<(1 << QP) | LATER, NW>(st, slot, li, w);
         } else {
-            potf2f_update<BQ_LATER(QP)>(st, slot, li, w);
+            potf2f_update<LATER, NW>(st, slot, li, w);
         }
-        Potf2FSteps<P + 1>::run(st, slots, w, lane, wst);
+        Potf2FSteps<P + 1, NW>::run(st, slots, w, lane, wst);
     }
 };
-template <>
-struct Potf2FSteps<16> {
-    static __device__ __forceinline__ void run(Potf2F &, double *, int, int, long long *) {}
+template <int NW>
+struct Potf2FSteps<16, NW> {
+    static __device__ __forceinline__ void run(Potf2FT<NW> &, double *, int, int, long long *) {}
 };
 
 // lds: BQ_POTF2F_LDS_DOUBLES doubles.  src (leading dimension lsrc): where the block is read
 // from when it is not in place; when src lies in the slots' LDS (the slab step's Ts), pass
 // src_in_slots so that nobody publishes before every wave has its columns.
+// NW = 8: the workgroup has EIGHT waves (512 threads), two per SIMD, two panels each: the waves
+// that only update have half the columns to bring up to date per panel (32 FMAs + 20 LDS reads
+// instead of 64 + 36), which is what paces the early panels.
+template <int NW = 4>
 __device__ __forceinline__ void potf2f_body(double *__restrict__ Ab, long lda, int j0,
                                             double *__restrict__ dinv_b,
                                             int *__restrict__ info_b, double *lds,
@@ -171,6 +181,7 @@ __device__ __forceinline__ void potf2f_body(double *__restrict__ Ab, long lda, i
                                             bool src_in_slots = false,
                                             long long *stamps = nullptr)
 {
+    constexpr int NG = 16 / NW;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #define BQ_STAMP(k)                                                                                \
@@ -179,30 +190,35 @@ __device__ __forceinline__ void potf2f_body(double *__restrict__ Ab, long lda, i
     BQ_STAMP(0);
     double *slots = lds;
     double *blk = lds + BQ_POTF2F_SLOTS;
-    Potf2F st;
+    Potf2FT<NW> st;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < NG; ++q)
 #pragma unroll
         for (int s = 0; s < 4; ++s)
-            st.a[q][s] = src ? src[lane + (long)(16 * q + 4 * w + s) * lsrc]
-                             : Ab[lane + (long)(16 * q + 4 * w + s) * lda];
+            st.a[q][s] = src ? src[lane + (long)(4 * (NW * q + w) + s) * lsrc]
+                             : Ab[lane + (long)(4 * (NW * q + w) + s) * lda];
     if (src_in_slots)
         __syncthreads(); // the ring overwrites the block: every wave has its columns first
     BQ_STAMP(1);
     if (w == 0)
-        potf2f_factor<0>(st, slots, lane);
-    Potf2FSteps<0>::run(st, slots, w, lane, stamps ? stamps + 8 : nullptr);
+        potf2f_factor<0, NW>(st, slots, lane);
+    // (per-wave barrier stamps: the four-wave probe only, and only when it asks for them with
+    // stamps[5] != 0 -- they cost the chain 2,500 cycles)
+    Potf2FSteps<0, NW>::run(st, slots, w, lane,
+                            (stamps && NW == 4 && stamps[5] != 0) ? stamps + 8 : nullptr);
     BQ_STAMP(2);
     // the four 16 x 16 diagonal sub-blocks into LDS from registers:
-    // blk[b][i + 16 k] = L[16 b + i][16 b + k]; my columns: k = 4 w + s of every block
+    // blk[b][i + 16 k] = L[16 b + i][16 b + k]; my columns c = 4 (NW q + w) + sc: block c >> 4
     {
         const int bq = lane >> 4, i16 = lane & 15;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NG; ++q)
 #pragma unroll
-            for (int sc = 0; sc < 4; ++sc)
-                if (bq == q)
-                    blk[256 * q + i16 + 16 * (4 * w + sc)] = st.a[q][sc];
+            for (int sc = 0; sc < 4; ++sc) {
+                const int c = 4 * (NW * q + w) + sc;
+                if (bq == (c >> 4))
+                    blk[256 * (c >> 4) + i16 + 16 * (c & 15)] = st.a[q][sc];
+            }
     }
     __syncthreads();
     BQ_STAMP(3);
@@ -211,14 +227,16 @@ __device__ __forceinline__ void potf2f_body(double *__restrict__ Ab, long lda, i
         double *pw = Ab + lane + (long)(4 * w) * lda;
         asm volatile("" : "+v"(pw));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NG; ++q) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                if (lane >= 16 * q + 4 * w + s)
+                if (lane >= 4 * (NW * q + w) + s)
                     pw[(long)s * lda] = st.a[q][s];
-            pw += 16 * lda;
+            pw += 4 * NW * lda;
         }
     }
+    if (NW > 4 && w >= 4)
+        return; // (no barrier follows: the reciprocals and the four inverses are waves 0-3's)
     // reciprocal pivots (lane = column) and the failure report: a non-positive pivot left a
     // NaN on the diagonal at its own column and at every later one
     {
@@ -281,10 +299,11 @@ __device__ __forceinline__ void potf2f_body(double *__restrict__ Ab, long lda, i
 // ---------------------------------------------------------------------------
 #define BQ_POTF2_LDS_DOUBLES BQ_POTF2F_LDS_DOUBLES
 
+template <int NW = 4>
 __device__ __forceinline__ void potf2_body(double *__restrict__ Ab, long lda, int j0,
                                            double *__restrict__ dinv_b, int *__restrict__ info_b,
                                            double *lds, const double *src = nullptr,
                                            long lsrc = 0, long long *stamps = nullptr)
 {
-    potf2f_body(Ab, lda, j0, dinv_b, info_b, lds, src, lsrc, src == lds, stamps);
+    potf2f_body<NW>(Ab, lda, j0, dinv_b, info_b, lds, src, lsrc, src == lds, stamps);
 }

@@ -258,7 +258,8 @@ __global__ void probe_layout_kernel(double *out)
 
 // timing probe: the factor alone on a block that is restored from Ain every launch;
 // stamps[0..4] of the last launch = s_memtime at entry / loaded / chain done / blocks in LDS / end
-__global__ __launch_bounds__(256) void potf2_probe_kernel(const double *__restrict__ Ain,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void potf2_probe_kernel(const double *__restrict__ Ain,
                                                           double *__restrict__ A, long lda,
                                                           double *__restrict__ dinv,
                                                           int *__restrict__ info,
@@ -269,14 +270,14 @@ __global__ __launch_bounds__(256) void potf2_probe_kernel(const double *__restri
     if (from_lds) {
         // as the slab step hands the block over: through LDS
         double *Ts = lds; // where the panel slots will be
-        for (int e = threadIdx.x; e < 4096; e += 256)
+        for (int e = threadIdx.x; e < 4096; e += 64 * NW)
             Ts[e] = Ain[(e & 63) + (long)(e >> 6) * lda];
         __syncthreads();
-        potf2_body(A, lda, 0, dinv, info, lds, Ts, 64, stamps);
+        potf2_body<NW>(A, lda, 0, dinv, info, lds, Ts, 64, stamps);
     } else {
-        for (int e = threadIdx.x; e < 4096; e += 256)
+        for (int e = threadIdx.x; e < 4096; e += 64 * NW)
             A[(e & 63) + (long)(e >> 6) * lda] = Ain[(e & 63) + (long)(e >> 6) * lda];
         __syncthreads();
-        potf2_body(A, lda, 0, dinv, info, lds, nullptr, 0, stamps);
+        potf2_body<NW>(A, lda, 0, dinv, info, lds, nullptr, 0, stamps);
     }
 }

@@ -299,9 +299,24 @@ extern "C" int bq_probe_potf2(bq_ctx *c, const double *A, int from_lds, int64_t 
     HIPCHK(c, hipMemcpyAsync(ain.p, A, sizeof(double) * 4096, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(inf.p, 0, 64, c->stream));
     HIPCHK(c, hipMemsetAsync(a.p, 0, sizeof(double) * 4096, c->stream));
+    // from_lds bit 2: per-wave barrier stamps as well (four-wave form; stamps[5] is the switch)
+    {
+        const long long flag = (from_lds & 4) ? 1 : 0;
+        HIPCHK(c, hipMemsetAsync(st.p, 0, sizeof(long long) * 136, c->stream));
+        HIPCHK(c, hipMemcpyAsync(static_cast<long long *>(st.p) + 5, &flag, sizeof flag,
+                                 hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     auto launch = [&]() {
-        hipLaunchKernelGGL(potf2_probe_kernel, dim3(1), dim3(256), 0, c->stream, ain.d(), a.d(),
-                           64L, dv.d(), inf.i(), static_cast<long long *>(st.p), from_lds);
+        // from_lds bit 1: the eight-wave form
+        if (from_lds & 2)
+            hipLaunchKernelGGL(potf2_probe_kernel<8>, dim3(1), dim3(512), 0, c->stream, ain.d(),
+                               a.d(), 64L, dv.d(), inf.i(), static_cast<long long *>(st.p),
+                               from_lds & 1);
+        else
+            hipLaunchKernelGGL(potf2_probe_kernel<4>, dim3(1), dim3(256), 0, c->stream, ain.d(),
+                               a.d(), 64L, dv.d(), inf.i(), static_cast<long long *>(st.p),
+                               from_lds & 1);
     };
     for (int i = 0; i < 5; ++i)
         launch();

@@ -78,8 +78,11 @@ __device__ __forceinline__ void slab_solve16(const double (&t)[4][4], const doub
 
 // STAMP: a profiling instantiation (tools/c2_timeline.py) whose workgroup 0 records s_memtime
 // at its phase boundaries; the shipped launches use STAMP = false and carry no stamp code.
-template <bool STAMP>
-__global__ __launch_bounds__(256, 2) void slab_step_kernel(double *__restrict__ A, long lda,
+// NW = 8 (launched when a step's workgroups have a CU each): 512 threads; waves 4-7 take no part
+// in the tile update -- they pass its barriers -- and in workgroup 0 join the diagonal factor as
+// its second wave per SIMD (potf2f_body<8>: the chain 16.5 k -> 13.2 k cycles).
+template <bool STAMP, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void slab_step_kernel(double *__restrict__ A, long lda,
                                                         long astride,
                                                         const double *__restrict__ Sin,
                                                         double *__restrict__ Sout, long lds,
@@ -123,6 +126,19 @@ __global__ __launch_bounds__(256, 2) void slab_step_kernel(double *__restrict__ 
     const int r0 = j0 + 64;
     const int Rb = r0 + 64 * bx, Cb = r0 + 64 * by;
     const int l15 = lane & 15, l4 = lane >> 4;
+    if (NW == 8 && wave >= 4) {
+        // the barriers of the tile update below, in their order: fragments staged; Q rows
+        // written; and for workgroup 0 with a next factor: Q rows read; diagonal block in LDS
+        __syncthreads();
+        __syncthreads();
+        if (blockIdx.x == 0 && factor_next) {
+            __syncthreads();
+            __syncthreads();
+            potf2_body<8>(A + r0 + (long)r0 * lda, lda, col0 + r0, dout, info + b, plds, Ts, 64,
+                          (long long *)nullptr);
+        }
+        return;
+    }
 
     // Every global load of the step is issued here, before the first MFMA: the fragments of
     // L_jj (blocks below its diagonal) and of the negated block inverses, the unsolved panel
@@ -280,8 +296,8 @@ __global__ __launch_bounds__(256, 2) void slab_step_kernel(double *__restrict__ 
             }
         __syncthreads();
         // (col0: the global column of this sweep's first column, for the failure report)
-        potf2_body(A + r0 + (long)r0 * lda, lda, col0 + r0, dout, info + b, plds, Ts, 64,
-                   (STAMP && blockIdx.z == 0) ? stamps + 5 : nullptr);
+        potf2_body<NW>(A + r0 + (long)r0 * lda, lda, col0 + r0, dout, info + b, plds, Ts, 64,
+                       (STAMP && blockIdx.z == 0) ? stamps + 5 : nullptr);
         return;
     }
     const bool to_s = by == 0 && bx > 0 && !last;

@@ -136,13 +136,15 @@ __global__ __launch_bounds__(256) void diag_winv_kernel(const double *__restrict
 // ---------------------------------------------------------------------------
 
 // the 64 x 64 diagonal factor as a launch of its own (potf2.h has the body)
-__global__ __launch_bounds__(256) void potf2_kernel(double *__restrict__ A, long lda, long astride,
-                                                    int j0, double *__restrict__ dinv,
-                                                    long dstride, int *__restrict__ info)
+template <int NW = 4>
+__global__ __launch_bounds__(64 * NW) void potf2_kernel(double *__restrict__ A, long lda,
+                                                        long astride, int j0,
+                                                        double *__restrict__ dinv, long dstride,
+                                                        int *__restrict__ info)
 {
     __shared__ __attribute__((aligned(16))) double lds[BQ_POTF2_LDS_DOUBLES];
     __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.z;
-    potf2_body(A + (long)b * astride + j0 + (long)j0 * lda, lda, j0, dinv + (long)b * dstride,
-               info + b, lds);
+    potf2_body<NW>(A + (long)b * astride + j0 + (long)j0 * lda, lda, j0,
+                   dinv + (long)b * dstride, info + b, lds);
 }

@@ -1070,6 +1070,48 @@ def test_predict_m1000_at_benched_size(engine, oracle):
     fit.close()
 
 
+def test_potf2_eight_waves_is_the_same_factor(engine):
+    """The one-launch steps' diagonal factor on eight waves (slab_step_kernel<., 8>,
+    potf2f_body<8>; BQ_POTF2_8W, read when a context is created) applies the same updates to
+    every column in the same order as the four-wave form: a C2 pass and a small failing
+    system give bit-identical results."""
+    import os
+    from bayesian_quadrature_amd import Engine
+    old = os.environ.get("BQ_POTF2_8W")
+    os.environ["BQ_POTF2_8W"] = "0"
+    try:
+        eng4 = Engine(0)
+    finally:
+        if old is None:
+            os.environ.pop("BQ_POTF2_8W", None)
+        else:
+            os.environ["BQ_POTF2_8W"] = old
+    try:
+        c = wl.c2()
+        res = []
+        for eng in (engine, eng4):
+            plan = eng.plan(1, 1, 1024, 256)
+            plan.set_inputs(c["x"][None], c["y"][None], c["xo"][None], c["h"], c["w"], c["s"])
+            plan.run()
+            res.append(plan.results())
+            plan.close()
+        for u, v in zip(res[0], res[1]):
+            assert np.array_equal(u, v)
+        # a system that stops being positive definite deep in the sweep: the same first failing
+        # column from both forms
+        n = 700
+        x = np.linspace(-5, 5, n)
+        x[500] = x[499]
+        y = np.sin(x)
+        for eng in (engine, eng4):
+            with pytest.raises(np.linalg.LinAlgError) as ei:
+                eng.gp_fit(x, y, 1.0, 0.2, 0.0)
+            res.append(str(ei.value))
+        assert res[-1] == res[-2]
+    finally:
+        eng4.close()
+
+
 def test_ksplit_variants_agree(engine):
     """The eight-wave forms of the sweeps' step kernels (rows_step_kernel<8>,
     rows_fused_kernel<., 2>; BQ_GEMM_KSPLIT, read when a context is created) against the

@@ -47,7 +47,9 @@ if __name__ == "__main__":
     R = rs.rand(64, 64)
     S = R + R.T + 64 * np.eye(64)
     for name, A in (("gauss", K), ("random_spd", S)):
-        for fl in (0, 1):
+        # bit 0: the block through LDS; bit 1: the eight-wave form; bit 2: per-wave barrier
+        # stamps as well (four waves only; they cost the chain ~2,500 cycles)
+        for fl in (0, 1, 2, 3, 5):
             Lo, dv, info, us, st = probe(e, A, fl)
             errL, errd, errW = check(A, Lo, dv)
             ph = (st[1:5] - st[:4]).tolist()
@@ -56,16 +58,17 @@ if __name__ == "__main__":
                 "us_per_launch": us, "info": info, "errL": errL, "err_dinv": errd, "err_W": errW,
                 "stamp_ticks_load_chain_blocks_tail": ph,
                 "cycles_in_kernel_total": int(st[4] - st[0]),
-                "barrier_arrive_by_wave": w[:, :, 0].tolist(),
-                "barrier_release_by_wave": w[:, :, 1].tolist()}
+                "barrier_arrive_by_wave": w[:, :, 0].tolist() if fl & 4 else None,
+                "barrier_release_by_wave": w[:, :, 1].tolist() if fl & 4 else None}
             assert info == 0 and errL < 1e-13 and errd < 1e-13 and errW < 1e-12, out
     # failure report: first non-positive pivot at column 37 (1-based 38)
     B = S.copy()
     Lr = np.linalg.cholesky(S)
     B[37, 37] = Lr[37, :37].dot(Lr[37, :37]) - 1e-3
-    Lo, dv, info, us, st = probe(e, B, 1, reps=3)
-    out["not_pd_info"] = info
-    assert info == 38, info
-    assert np.max(np.abs(np.tril(Lo)[:, :37] - Lr[:, :37])) < 1e-12
+    for fl in (1, 3):
+        Lo, dv, info, us, st = probe(e, B, fl, reps=3)
+        out["not_pd_info_%d" % fl] = info
+        assert info == 38, info
+        assert np.max(np.abs(np.tril(Lo)[:, :37] - Lr[:, :37])) < 1e-12
     print(json.dumps(out, indent=1))
     e.close()
