@@ -106,6 +106,8 @@ static int ctx_init(bq_ctx *c, int device)
         c->slab_nb_max = std::atoi(e);
     if (const char *e = std::getenv("BQ_SLAB_MAX"))
         c->slab_max = std::atoi(e);
+    if (const char *e = std::getenv("BQ_FOLD_READOUT"))
+        c->fold_readout = std::atoi(e);
     if (const char *e = std::getenv("BQ_POTF2_8W"))
         c->potf2_8w = std::atoi(e);
     if (const char *e = std::getenv("BQ_GEMM_KSPLIT"))

@@ -38,14 +38,22 @@ static int fit_factor(bq_ctx *c, bq_fit *f, double *pm = nullptr, double *pv = n
         fs.sstride = 64L * ntot;
         fs.dinv = scratch;
         fs.info = info;
+        fs.scal = c->fold_readout ? scal : nullptr;
     } else {
         HIPCHK(c, hipMemsetAsync(info, 0, sizeof(int), c->stream));
     }
     BQCHK(launch_assemble(c, f->d, f->pts.d(), 0, f->y.d(), 0, static_cast<GaussParams *>(f->gp.p),
                           0, f->A.d(), f->ldl, 0, f->L, 1, fs));
-    BQCHK(enqueue_potrf_partial(c, f->A.d(), f->ldl, 0, 1, ntot, f->npad, scratch, info,
-                                f->panel.d(), f->panel.bytes / sizeof(double), fuse));
-    BQCHK(launch_finalize(c, f->A.d(), f->ldl, 0L, f->L, scal, pm, pv, 64L, 1));
+    const bool folded = fuse && f->L.yrow >= 0 && c->fold_readout;
+    if (folded) // the one-launch sweep carries the read-out (SlabOut)
+        c->slab_out = SlabOut{scal, pm, pv, 64L, f->L.n, f->L.npad, f->L.M, f->L.yrow};
+    const int st_sweep = enqueue_potrf_partial(c, f->A.d(), f->ldl, 0, 1, ntot, f->npad, scratch,
+                                               info, f->panel.d(),
+                                               f->panel.bytes / sizeof(double), fuse);
+    c->slab_out = SlabOut{};
+    BQCHK(st_sweep);
+    if (!folded)
+        BQCHK(launch_finalize(c, f->A.d(), f->ldl, 0L, f->L, scal, pm, pv, 64L, 1));
     // one read-back: misc = [info (int, 8 bytes) | pad | scal[4] | pad | mean[64] | var[64]]
     double *hm = f->hfit;
     HIPCHK(c, hipMemcpyAsync(hm, f->misc.p, sizeof(double) * (hpost ? 8 + 128 : 6),

@@ -92,6 +92,8 @@ struct bq_ctx {
     int gemm_lds64 = 1;  // its 64x64-tile form for products that cannot fill the chip (BQ_GEMM_LDS64)
     int slab_nb_max = 3072; // one or two matrices below this size: one-launch steps throughout (BQ_SLAB_NB_MAX)
     int slab_max = 4800;    // ... and the last rows of a larger one, from this many on (BQ_SLAB_MAX)
+    int fold_readout = 1; // one-launch sweeps carry their read-out (SlabOut; BQ_FOLD_READOUT)
+    SlabOut slab_out{};  // set (scal != nullptr) by a caller whose slab sweep carries its read-out
     int potf2_8w = 1;    // the one-launch steps' diagonal factor on eight waves where a step's workgroups
                          // have a CU each (BQ_POTF2_8W)
     int gemm_ksplit = 1; // eight-wave k-split forms of the 64-tile / job kernels (BQ_GEMM_KSPLIT)
@@ -257,6 +259,7 @@ struct FirstStep {
     long lds = 0, sstride = 0;
     double *dinv = nullptr;
     int *info = nullptr;
+    double *scal = nullptr; // SlabOut::scal: log|K| starts at zero here
 };
 int launch_assemble(bq_ctx *c, int d, const double *pts, long pstride, const double *y,
                     long ystride, const GaussParams *gp, int gpstride, double *A, long lda,

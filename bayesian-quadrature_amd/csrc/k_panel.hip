@@ -17,7 +17,7 @@ void launch_assemble_d(bq_ctx *c, const double *pts, long pstride, const double 
     if (fs.S0)
         hipLaunchKernelGGL(assemble_first_kernel<D>, grid, dim3(256), 0, c->cur, pts, pstride, y,
                            ystride, gp, gpstride, A, lda, astride, L, fs.S0, fs.lds, fs.sstride,
-                           fs.dinv, (long)BQ_DINV_STRIDE, fs.info);
+                           fs.dinv, (long)BQ_DINV_STRIDE, fs.info, fs.scal);
     else
         hipLaunchKernelGGL(assemble_kernel<D>, grid, dim3(256), 0, c->cur, pts, pstride, y, ystride,
                            gp, gpstride, A, lda, astride, L);
@@ -118,22 +118,22 @@ int launch_slab_step(bq_ctx *c, double *A, long lda, long astride, int batch, do
     if (stamps && w8)
         hipLaunchKernelGGL((slab_step_kernel<true, 8>), dim3(T * (T + 1) / 2, 1, batch), dim3(512), 0,
                            c->cur, A, lda, astride, Sin, Sout, lds, sstride, ntot, j0, dinv_in,
-                           dinv_out, (long)BQ_DINV_STRIDE, fnext, last, info, col0, stamps);
+                           dinv_out, (long)BQ_DINV_STRIDE, fnext, last, info, col0, stamps, c->slab_out);
     else if (stamps)
         hipLaunchKernelGGL((slab_step_kernel<true, 4>), dim3(T * (T + 1) / 2, 1, batch), dim3(256), 0,
                            c->cur, A, lda, astride, Sin, Sout, lds, sstride, ntot, j0, dinv_in,
-                           dinv_out, (long)BQ_DINV_STRIDE, fnext, last, info, col0, stamps);
+                           dinv_out, (long)BQ_DINV_STRIDE, fnext, last, info, col0, stamps, c->slab_out);
     else if (w8)
         // a CU per workgroup: 512 threads, the diagonal factor on eight waves
         hipLaunchKernelGGL((slab_step_kernel<false, 8>), dim3(T * (T + 1) / 2, 1, batch), dim3(512),
                            0, c->cur, A, lda, astride, Sin, Sout, lds, sstride, ntot, j0, dinv_in,
                            dinv_out, (long)BQ_DINV_STRIDE, fnext, last, info, col0,
-                           (long long *)nullptr);
+                           (long long *)nullptr, c->slab_out);
     else
         hipLaunchKernelGGL((slab_step_kernel<false, 4>), dim3(T * (T + 1) / 2, 1, batch), dim3(256),
                            0, c->cur, A, lda, astride, Sin, Sout, lds, sstride, ntot, j0, dinv_in,
                            dinv_out, (long)BQ_DINV_STRIDE, fnext, last, info, col0,
-                           (long long *)nullptr);
+                           (long long *)nullptr, c->slab_out);
     HIPCHK(c, hipGetLastError());
     return BQ_OK;
 }

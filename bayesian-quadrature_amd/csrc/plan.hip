@@ -190,6 +190,7 @@ int plan_enqueue(bq_ctx *c, bq_plan *p)
         fs.sstride = 64L * p->L.ntot;
         fs.dinv = p->dinv.d();
         fs.info = p->info.i();
+        fs.scal = c->fold_readout ? p->scal.d() : nullptr;
     } else {
         HIPCHK(c, hipMemsetAsync(p->info.p, 0, sizeof(int) * p->nprob, c->stream));
     }
@@ -200,9 +201,19 @@ int plan_enqueue(bq_ctx *c, bq_plan *p)
     // border x border block in its trailing updates; the one-launch steps of small systems
     // update everything and read the Schur complement.
     const bool by_rows = !fuse && p->L.yrow >= 0 && auto_nb(c, p->L.ntot, p->nprob) >= 128;
-    BQCHK(enqueue_potrf_partial(c, p->A.d(), p->lda, p->astride, p->nprob, p->L.ntot, p->L.npad,
-                                p->dinv.d(), p->info.i(), p->panel.d(),
-                                p->panel.bytes / sizeof(double), fuse, by_rows));
+    // a sweep of one-launch steps carries the read-out itself (SlabOut: no finalize launch)
+    const bool folded = fuse && p->L.yrow >= 0 && c->fold_readout;
+    if (folded)
+        c->slab_out = SlabOut{p->scal.d(), p->mean.d(), p->var.d(), (long)std::max(p->M, 1),
+                              p->L.n, p->L.npad, p->L.M, p->L.yrow};
+    const int st_sweep =
+        enqueue_potrf_partial(c, p->A.d(), p->lda, p->astride, p->nprob, p->L.ntot, p->L.npad,
+                              p->dinv.d(), p->info.i(), p->panel.d(),
+                              p->panel.bytes / sizeof(double), fuse, by_rows);
+    c->slab_out = SlabOut{};
+    BQCHK(st_sweep);
+    if (folded)
+        return BQ_OK;
     if (by_rows)
         return launch_plan_readout(c, p->A.d(), p->lda, p->astride, p->L,
                                    static_cast<const GaussParams *>(p->gp.p), p->scal.d(),

@@ -179,7 +179,8 @@ __device__ __forceinline__ void potf2f_body(double *__restrict__ Ab, long lda, i
                                             int *__restrict__ info_b, double *lds,
                                             const double *src = nullptr, long lsrc = 0,
                                             bool src_in_slots = false,
-                                            long long *stamps = nullptr)
+                                            long long *stamps = nullptr,
+                                            double *logdet = nullptr)
 {
     constexpr int NG = 16 / NW;
     const int lane = threadIdx.x & 63;
@@ -235,8 +236,22 @@ __device__ __forceinline__ void potf2f_body(double *__restrict__ Ab, long lda, i
             pw += 4 * NW * lda;
         }
     }
-    if (NW > 4 && w >= 4)
+    // This block's share of log|K| = 2 sum log L_cc (SlabOut: the read-out rides in the sweep;
+    // one writer per launch, launches in order) -- an fp64 log is ~400 cycles of one wave: with
+    // eight waves wave 4 takes it while waves 0-3 run the inverses, with four it waits until
+    // wave 3 is through with its inverse (BQ_POTF2F_LOGDET below)
+#define BQ_POTF2F_LOGDET                                                                           \
+    {                                                                                              \
+        double lg = log(blk[256 * (lane >> 4) + 17 * (lane & 15)]);                                \
+        _Pragma("unroll") for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off, 64);   \
+        if (lane == 0)                                                                             \
+            *logdet += 2.0 * lg;                                                                   \
+    }
+    if (NW > 4 && w >= 4) {
+        if (logdet && w == 4)
+            BQ_POTF2F_LOGDET
         return; // (no barrier follows: the reciprocals and the four inverses are waves 0-3's)
+    }
     // reciprocal pivots (lane = column) and the failure report: a non-positive pivot left a
     // NaN on the diagonal at its own column and at every later one
     {
@@ -288,6 +303,9 @@ __device__ __forceinline__ void potf2f_body(double *__restrict__ Ab, long lda, i
                 Wb[i] = wc[i];
         }
     }
+    if (NW == 4 && logdet && w == 3)
+        BQ_POTF2F_LOGDET
+#undef BQ_POTF2F_LOGDET
     BQ_STAMP(4);
 #undef BQ_STAMP
 }
@@ -303,7 +321,8 @@ template <int NW = 4>
 __device__ __forceinline__ void potf2_body(double *__restrict__ Ab, long lda, int j0,
                                            double *__restrict__ dinv_b, int *__restrict__ info_b,
                                            double *lds, const double *src = nullptr,
-                                           long lsrc = 0, long long *stamps = nullptr)
+                                           long lsrc = 0, long long *stamps = nullptr,
+                                           double *logdet = nullptr)
 {
-    potf2f_body<NW>(Ab, lda, j0, dinv_b, info_b, lds, src, lsrc, src == lds, stamps);
+    potf2f_body<NW>(Ab, lda, j0, dinv_b, info_b, lds, src, lsrc, src == lds, stamps, logdet);
 }

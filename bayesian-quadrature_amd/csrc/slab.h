@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void slab_step_kernel(dou
                                                         double *__restrict__ dout, long dstride,
                                                         int factor_next, int last,
                                                         int *__restrict__ info, int col0,
-                                                        long long *stamps)
+                                                        long long *stamps, SlabOut out)
 {
 #define BQ_SSTAMP(k, dep)                                                                          \
     if (STAMP) {                                                                                   \
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void slab_step_kernel(dou
             __syncthreads();
             __syncthreads();
             potf2_body<8>(A + r0 + (long)r0 * lda, lda, col0 + r0, dout, info + b, plds, Ts, 64,
-                          (long long *)nullptr);
+                          (long long *)nullptr, out.scal ? out.scal + 4 * b + 1 : nullptr);
         }
         return;
     }
@@ -297,13 +297,37 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void slab_step_kernel(dou
         __syncthreads();
         // (col0: the global column of this sweep's first column, for the failure report)
         potf2_body<NW>(A + r0 + (long)r0 * lda, lda, col0 + r0, dout, info + b, plds, Ts, 64,
-                       (STAMP && blockIdx.z == 0) ? stamps + 5 : nullptr);
+                       (STAMP && blockIdx.z == 0) ? stamps + 5 : nullptr,
+                       out.scal ? out.scal + 4 * b + 1 : nullptr);
         return;
     }
     const bool to_s = by == 0 && bx > 0 && !last;
     double *Cout = to_s ? Sout + Rb + 16 * wave + l15 + (long)l4 * lds
                         : A + Rb + 16 * wave + l15 + (long)(Cb + l4) * lda;
     const long ldo = to_s ? lds : lda;
+    // The last step's tiles are the Schur complement S of the border: with the read-out folded
+    // in (SlabOut) the lane that holds S[c, c], S[yrow, c] or S[yrow, yrow] stores var_i, mean_i
+    // and -- log|K| is complete since the previous launch -- the log-ML (reduce.h,
+    // finalize_kernel, is the stand-alone form).  row / col: this sweep's numbering = the
+    // system's (col0 = 0 for every caller that sets `out`).
+#define BQ_SLAB_EMIT(ROW_, COL_, S_)                                                               \
+    {                                                                                              \
+        const int row_ = (ROW_), col_ = (COL_);                                                    \
+        const double s_ = (S_);                                                                    \
+        if (row_ == col_ && row_ >= out.npad && row_ < out.npad + out.M && out.var)                \
+            out.var[(long)b * out.mstride + (row_ - out.npad)] = s_;                               \
+        if (row_ == out.yrow) {                                                                    \
+            if (col_ >= out.npad && col_ < out.npad + out.M && out.mean)                           \
+                out.mean[(long)b * out.mstride + (col_ - out.npad)] = -s_;                         \
+            if (col_ == out.yrow) {                                                                \
+                const double qf_ = -s_, ld_ = out.scal[4 * b + 1];                                 \
+                out.scal[4 * b + 2] = qf_;                                                         \
+                out.scal[4 * b + 0] =                                                              \
+                    -0.5 * qf_ - 0.5 * ld_ - 0.5 * (double)out.n * 1.8378770664093453;             \
+            }                                                                                      \
+        }                                                                                          \
+    }
+    const bool emit = last && out.scal != nullptr;
     if (bx == by) {
 #pragma unroll
         for (int sb = 0; sb < 3; ++sb)
@@ -313,6 +337,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void slab_step_kernel(dou
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     Cd[(long)(4 * r) * lda] = -acc[sb][r];
+                if (emit) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        BQ_SLAB_EMIT(Rb + 16 * DIAG_RB(wave, sb) + l15,
+                                     Cb + 16 * DIAG_CB(wave, sb) + l4 + 4 * r, -acc[sb][r])
+                }
             }
     } else {
 #pragma unroll
@@ -320,7 +350,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void slab_step_kernel(dou
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 Cout[(long)(16 * cb + 4 * r) * ldo] = -acc[cb][r];
+        if (emit) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    BQ_SLAB_EMIT(Rb + 16 * wave + l15, Cb + 16 * cb + l4 + 4 * r, -acc[cb][r])
+        }
     }
+#undef BQ_SLAB_EMIT
 #undef BQ_SSTAMP
 }
 
@@ -333,7 +371,7 @@ __global__ __launch_bounds__(256) void assemble_first_kernel(
     const double *__restrict__ pts, long pstride, const double *__restrict__ y, long ystride,
     const GaussParams *__restrict__ gp, int gpstride, double *__restrict__ A, long lda,
     long astride, Layout L, double *__restrict__ S0, long lds, long sstride,
-    double *__restrict__ dinv, long dstride, int *__restrict__ info)
+    double *__restrict__ dinv, long dstride, int *__restrict__ info, double *__restrict__ scal)
 {
     __shared__ __attribute__((aligned(16))) double plds[BQ_POTF2_LDS_DOUBLES];
     const int b = blockIdx.z;
@@ -341,12 +379,16 @@ __global__ __launch_bounds__(256) void assemble_first_kernel(
     assemble_tile<D>(pts + (long)b * pstride, y + (long)b * ystride, gp[(long)b * gpstride], A,
                      lda, L, S0 + (long)b * sstride, lds);
     if (blockIdx.x == 0 && blockIdx.y == 0) {
-        if (threadIdx.x == 0)
+        if (threadIdx.x == 0) {
             info[b] = 0;
+            if (scal)
+                scal[4 * b + 1] = 0.0; // log|K|: the factors add to it (SlabOut)
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads(); // the block's 64 x 64 entries (rows 0..63 of this tile) are in memory
         __builtin_amdgcn_s_setprio(3);
-        potf2_body(A, lda, 0, dinv + (long)b * dstride, info + b, plds);
+        potf2_body(A, lda, 0, dinv + (long)b * dstride, info + b, plds, nullptr, 0, nullptr,
+                   scal ? scal + 4 * b + 1 : nullptr);
     }
 }
 

@@ -27,6 +27,15 @@ struct Layout {
     int n, npad, M, yrow, ntot; // yrow < 0: no y row
 };
 
+// Read-out of a bordered system folded into the one-launch sweep (slab.h): the diagonal factors
+// add their share of log|K| to scal[4b + 1] as they go, and the LAST step's tiles -- the Schur
+// complement of the border -- store what finalize_kernel would read from it (no launch of its own).
+struct SlabOut {
+    double *scal, *mean, *var; // scal: 4 per problem {logml, logdet, qf, -}; mean / var: mstride per problem
+    long mstride;
+    int n, npad, M, yrow;
+};
+
 // batched active-sampling systems (moments.h: assemble_esm_kernel)
 struct EsmLayout {
     int ns, nsc, npad, ntot; // points [0, nsc] (nsc+1 of them), border rows npad, npad+1

@@ -1112,6 +1112,63 @@ def test_potf2_eight_waves_is_the_same_factor(engine):
         eng4.close()
 
 
+def test_folded_readout_matches_finalize(engine, oracle):
+    """A sweep of one-launch steps carries its read-out (slab.h, SlabOut: log|K| from the diagonal
+    factors as they go, mean / variance / log-ML from the last step's tiles) instead of a
+    finalize launch; BQ_FOLD_READOUT=0 (read when a context is created) gives the stand-alone
+    form.  Plans (one and several problems, with and without prediction points) and the
+    resident fit agree between the two and with the oracle."""
+    import os
+    from bayesian_quadrature_amd import Engine
+    old = os.environ.get("BQ_FOLD_READOUT")
+    os.environ["BQ_FOLD_READOUT"] = "0"
+    try:
+        eng0 = Engine(0)
+    finally:
+        if old is None:
+            os.environ.pop("BQ_FOLD_READOUT", None)
+        else:
+            os.environ["BQ_FOLD_READOUT"] = old
+    try:
+        rs = np.random.RandomState(11)
+        for B, n, M in ((1, 1024, 256), (3, 200, 33), (5, 40, 0), (2, 64, 64), (1, 63, 1)):
+            dx = 10.0 / n
+            x = np.linspace(-5, 5, n)[None, :] + 0.2 * dx * rs.uniform(-1, 1, (B, n))
+            y = np.sin(x) + 0.1 * rs.randn(B, n)
+            xo = rs.uniform(-5, 5, (B, max(M, 1)))[:, :M]
+            wv = np.array([1.3 * dx])
+            res = []
+            for eng in (engine, eng0):
+                plan = eng.plan(B, 1, n, M)
+                plan.set_inputs(x, y, xo if M else None, 1.3, wv, 1e-3)
+                plan.run()
+                res.append(plan.results())
+                plan.close()
+            mean, var, logml, status = res[0]
+            assert (status == 0).all() and (res[1][3] == 0).all()
+            assert np.abs(logml - res[1][2]).max() <= 1e-13 * np.abs(logml).max()
+            if M:
+                assert relmax(mean, res[1][0]) < 1e-13
+                assert relmax(var, res[1][1], scale=oracle.kernel_scale(1, 1.3, wv)) < 1e-13
+            Lo, ao, lmo = oracle.gp_fit(x[0], y[0], 1.3, wv, 1e-3)
+            assert abs(logml[0] - lmo) <= RTOL * abs(lmo)
+            if M:
+                k0 = oracle.kernel_scale(1, 1.3, wv)
+                mo, vo = oracle.gp_predict(x[0], 1.3, wv, Lo, ao, xo[0])
+                assert relmax(mean[0], mo) < RTOL and relmax(var[0], vo, scale=k0) < RTOL
+        c = wl.c2()
+        lm = []
+        for eng in (engine, eng0):
+            fit = eng.gp_fit(c["x"], c["y"], c["h"], c["w"], c["s"])
+            lm.append(fit.logml)
+            fit.refit(c["h"] * 1.1, c["w"], c["s"])
+            lm.append(fit.logml)
+            fit.close()
+        assert abs(lm[0] - lm[2]) <= 1e-13 * abs(lm[0]) and abs(lm[1] - lm[3]) <= 1e-13 * abs(lm[1])
+    finally:
+        eng0.close()
+
+
 def test_ksplit_variants_agree(engine):
     """The eight-wave forms of the sweeps' step kernels (rows_step_kernel<8>,
     rows_fused_kernel<., 2>; BQ_GEMM_KSPLIT, read when a context is created) against the
