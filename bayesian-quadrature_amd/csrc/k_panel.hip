@@ -14,8 +14,13 @@ void launch_assemble_d(bq_ctx *c, const double *pts, long pstride, const double 
                        Layout L, int batch, const FirstStep &fs)
 {
     dim3 grid((L.ntot + 127) / 128, (L.ntot + 63) / 64, batch);
-    if (fs.S0)
-        hipLaunchKernelGGL(assemble_first_kernel<D>, grid, dim3(256), 0, c->cur, pts, pstride, y,
+    const long wgs = (long)grid.x * grid.y * grid.z;
+    if (fs.S0 && c->potf2_8w && wgs <= 2L * c->cus)
+        hipLaunchKernelGGL((assemble_first_kernel<D, 8>), grid, dim3(512), 0, c->cur, pts, pstride, y,
+                           ystride, gp, gpstride, A, lda, astride, L, fs.S0, fs.lds, fs.sstride,
+                           fs.dinv, (long)BQ_DINV_STRIDE, fs.info, fs.scal);
+    else if (fs.S0)
+        hipLaunchKernelGGL((assemble_first_kernel<D, 4>), grid, dim3(256), 0, c->cur, pts, pstride, y,
                            ystride, gp, gpstride, A, lda, astride, L, fs.S0, fs.lds, fs.sstride,
                            fs.dinv, (long)BQ_DINV_STRIDE, fs.info, fs.scal);
     else

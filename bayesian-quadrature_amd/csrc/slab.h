@@ -366,8 +366,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void slab_step_kernel(dou
 // tiles of column block 0 also fill the sweep's scratch column, and the workgroup of tile
 // (0, 0) clears the failure flag and factors the leading 64 x 64 block once its own stores are
 // out -- one launch, one memset and 12 us less per pass of a small problem.
-template <int D>
-__global__ __launch_bounds__(256) void assemble_first_kernel(
+// NW = 8 (one problem or a few: the grid has a CU per workgroup): 512 threads, waves 4-7 only
+// join the diagonal factor of tile (0, 0) (potf2f_body<8>).
+template <int D, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void assemble_first_kernel(
     const double *__restrict__ pts, long pstride, const double *__restrict__ y, long ystride,
     const GaussParams *__restrict__ gp, int gpstride, double *__restrict__ A, long lda,
     long astride, Layout L, double *__restrict__ S0, long lds, long sstride,
@@ -376,8 +378,9 @@ __global__ __launch_bounds__(256) void assemble_first_kernel(
     __shared__ __attribute__((aligned(16))) double plds[BQ_POTF2_LDS_DOUBLES];
     const int b = blockIdx.z;
     A += (long)b * astride;
-    assemble_tile<D>(pts + (long)b * pstride, y + (long)b * ystride, gp[(long)b * gpstride], A,
-                     lda, L, S0 + (long)b * sstride, lds);
+    if (NW == 4 || threadIdx.x < 256)
+        assemble_tile<D>(pts + (long)b * pstride, y + (long)b * ystride, gp[(long)b * gpstride],
+                         A, lda, L, S0 + (long)b * sstride, lds);
     if (blockIdx.x == 0 && blockIdx.y == 0) {
         if (threadIdx.x == 0) {
             info[b] = 0;
@@ -387,8 +390,8 @@ __global__ __launch_bounds__(256) void assemble_first_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads(); // the block's 64 x 64 entries (rows 0..63 of this tile) are in memory
         __builtin_amdgcn_s_setprio(3);
-        potf2_body(A, lda, 0, dinv + (long)b * dstride, info + b, plds, nullptr, 0, nullptr,
-                   scal ? scal + 4 * b + 1 : nullptr);
+        potf2_body<NW>(A, lda, 0, dinv + (long)b * dstride, info + b, plds, nullptr, 0, nullptr,
+                       scal ? scal + 4 * b + 1 : nullptr);
     }
 }
 
