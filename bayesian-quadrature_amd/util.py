@@ -108,6 +108,48 @@ def _slice_sample(samples, logpdf, xval, w, verbose=False):
 _PEEK_RS = np.random.RandomState(0)
 
 
+class _Draws(object):
+    """The chain's random numbers as raw uniform doubles, in the order the sequential sampler
+    draws them, from a private copy of numpy's global generator -- so that looking AHEAD costs
+    nothing (copying the generator's state for every look, 624 words each way, was a third of a
+    small system's pass).  ``uniform(lo, hi)`` is numpy's own ``lo + (hi - lo) * u`` and
+    ``rand(d)`` its next d doubles; ``close`` leaves the global generator where the sequential
+    sampler would have: at the start state advanced by exactly the doubles consumed."""
+
+    def __init__(self):
+        self._state0 = np.random.get_state()
+        self._rs = _PEEK_RS
+        self._rs.set_state(self._state0)
+        self._buf = np.empty(0)
+        self._pos = 0
+        self._used = 0
+
+    def _need(self, k):
+        if self._pos + k > self._buf.size:
+            fresh = self._rs.random_sample(max(512, k))
+            self._buf = np.concatenate([self._buf[self._pos:], fresh])
+            self._pos = 0
+
+    def take(self, k):
+        self._need(k)
+        out = self._buf[self._pos:self._pos + k]
+        self._pos += k
+        self._used += k
+        return out
+
+    def peek(self, k):
+        self._need(k)
+        return self._buf[self._pos:self._pos + k]
+
+    def uniform(self, lo, hi):
+        return lo + (hi - lo) * float(self.take(1)[0])
+
+    def close(self):
+        np.random.set_state(self._state0)
+        if self._used:
+            np.random.random_sample(self._used)
+
+
 def _slice_sample_batched(samples, logpdf_batch, xval, w, spec=4):
     """The same chain as ``_slice_sample`` -- the same random draws in the same order, the same
     comparisons -- with the log-pdf evaluated in BATCHES of ``spec + 2`` points per device pass.
@@ -136,15 +178,15 @@ def _slice_sample_batched(samples, logpdf_batch, xval, w, spec=4):
         for t, v in zip(ts, vals):
             cache[t] = float(v)
 
+    draws = _Draws()
+
     def peek(left, right, k):
         """the next k shrinkage proposals if every one of them is rejected"""
-        rs = _PEEK_RS  # (constructing a RandomState seeds it from the OS: 50 us a time)
-        rs.set_state(np.random.get_state())
         out = []
-        for _ in range(k):
+        for u in draws.peek(k):
             if (right - left) < 1e-9:
                 break
-            loc = rs.uniform(left, right)
+            loc = left + (right - left) * float(u)
             out.append(loc)
             if loc < 0:
                 left = loc
@@ -152,15 +194,23 @@ def _slice_sample_batched(samples, logpdf_batch, xval, w, spec=4):
                 right = loc
         return out
 
+    try:
+        _slice_chain(samples, logpdf_batch, w, spec, S, cache, fetch, peek, draws)
+    finally:
+        draws.close()
+
+
+def _slice_chain(samples, logpdf_batch, w, spec, S, cache, fetch, peek, draws):
+    n, d = samples.shape
     xpr = float(np.asarray(logpdf_batch(np.repeat(samples[0][None, :], S, axis=0)))[0])
     i = 0
     while i < n - 1:
         if xpr == -np.inf:
             raise RuntimeError("zero probability encountered")
         x0 = samples[i]
-        yval = np.random.uniform(0, np.exp(xpr))
+        yval = draws.uniform(0, np.exp(xpr))
         logyval = np.log(yval) if yval > 0 else -np.inf
-        direction = np.random.rand(d) - 0.5
+        direction = draws.take(d) - 0.5
         direction /= np.linalg.norm(direction)
         left, right = -w, w
         cache.clear()
@@ -194,7 +244,7 @@ def _slice_sample_batched(samples, logpdf_batch, xval, w, spec=4):
         while True:
             if (right - left) < 1e-9:
                 break  # window collapsed: redraw the slice height at the same point
-            loc = np.random.uniform(left, right)
+            loc = draws.uniform(left, right)
             samples[i + 1] = x0 + loc * direction
             nl, nr = (loc, right) if loc < 0 else (left, loc)
             v = val(loc, peek(nl, nr, spec + 1) if loc not in cache else ())
