@@ -26,6 +26,12 @@ struct bq_pair {
     // targets are the samples' own values, nothing of it depends on GP1, and both have ns
     // points -- ONE plan of 2 S systems (p1; first S: GP1, last S: GP2), one sweep instead of two
     bool merged = false;
+    // the whole device side of a bq_pair_llh pass -- parameters up from pinned staging, both
+    // plans' launches, targets, the record per set, the record down -- as ONE graph launch
+    hipGraph_t lgraph = nullptr;
+    hipGraphExec_t lgexec = nullptr;
+    int lgraph_state = 0; // 0 = not tried, 1 = ready, -1 = unavailable (eager launches)
+    int lgraph_key = 0;
     DevBuf l_s, x_sc, x_a, y2, flag;
     // stage 2 of bq_pair_esm, kept between calls (choose_next calls it once per step with the
     // same shapes; allocating and releasing its tens of GB per call costs more than the pass)
@@ -40,6 +46,10 @@ struct bq_pair {
     DevBuf dres;
     ~bq_pair()
     {
+        if (lgexec)
+            (void)hipGraphExecDestroy(lgexec);
+        if (lgraph)
+            (void)hipGraphDestroy(lgraph);
         if (hpar)
             (void)hipHostFree(hpar);
         if (hres)
@@ -203,6 +213,45 @@ extern "C" void bq_pair_destroy(bq_ctx *c, bq_pair *pr)
     delete pr;
 }
 
+// the device side of one bq_pair_llh pass (the parameter sets are in pr->hpar)
+static int pair_llh_enqueue(bq_ctx *c, bq_pair *pr)
+{
+    const int S = pr->S, nsc = pr->nsc, ns = pr->ns, nc = pr->nc;
+    if (pr->merged) {
+        // one plan of 2 S systems: [GP1 under the S sets | GP2 under the S sets]
+        HIPCHK(c, hipMemcpyAsync(pr->p1->gp.p, pr->hpar, sizeof(GaussParams) * 2 * S,
+                                 hipMemcpyHostToDevice, c->stream));
+        BQCHK(plan_enqueue(c, pr->p1));
+        HIPCHK(c, hipMemsetAsync(pr->flag.p, 0, sizeof(int) * S, c->stream));
+        hipLaunchKernelGGL(pair_collect_kernel, dim3(S), dim3(64), 0, c->stream, pr->p1->scal.d(),
+                           pr->p1->scal.d() + 4 * S, pr->p1->info.i(), pr->p1->info.i() + S,
+                           pr->flag.i(), pr->p1->y.d(), (long)pr->p1->L.npad, ns, 0,
+                           pr->dres.d());
+        HIPCHK(c, hipGetLastError());
+    } else {
+        HIPCHK(c, hipMemcpyAsync(pr->p1->gp.p, pr->hpar, sizeof(GaussParams) * S,
+                                 hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(pr->p2->gp.p, pr->hpar + S, sizeof(GaussParams) * S,
+                                 hipMemcpyHostToDevice, c->stream));
+        BQCHK(plan_enqueue(c, pr->p1));
+        HIPCHK(c, hipMemsetAsync(pr->flag.p, 0, sizeof(int) * S, c->stream));
+        const long ms = std::max(nc, 1), ys = pr->p2->L.npad;
+        hipLaunchKernelGGL(pair_targets_kernel, dim3((nsc + 255) / 256, S), dim3(256), 0,
+                           c->stream, pr->l_s.d(), ns, nc, pr->p1->mean.d(), pr->p1->var.d(), ms,
+                           max_log(), pr->p2->y.d(), ys, pr->flag.i());
+        HIPCHK(c, hipGetLastError());
+        BQCHK(plan_enqueue(c, pr->p2));
+        hipLaunchKernelGGL(pair_collect_kernel, dim3(S), dim3(64), 0, c->stream,
+                           pr->p1->scal.d(), pr->p2->scal.d(), pr->p1->info.i(),
+                           pr->p2->info.i(), pr->flag.i(), pr->p2->y.d(), ys, ns, nc,
+                           pr->dres.d());
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipMemcpyAsync(pr->hres, pr->dres.p, sizeof(double) * (size_t)S * (5 + nc),
+                             hipMemcpyDeviceToHost, c->stream));
+    return BQ_OK;
+}
+
 // llh[b] = log_lh(GP1) + log_lh(GP2) under parameter set b = (p_tl[3b..], p_l[3b..]) = (h, w, s)
 // each; -inf where a factorisation fails or the overflow guard trips (status[b] = 1 / 2 / 3:
 // GP1 not positive definite / GP mean too large / GP2 not positive definite).  l_c (S x nc,
@@ -216,49 +265,51 @@ extern "C" int bq_pair_llh(bq_ctx *c, bq_pair *pr, const double *p_tl, const dou
         return fail(c, BQ_ERR_BAD_ARG, "illegal value");
     if (pr->ma)
         return fail(c, BQ_ERR_BAD_ARG, "pair was created for the acquisition (ma > 0)");
-    const int S = pr->S, nsc = pr->nsc;
+    const int S = pr->S, nc = pr->nc;
     BQCHK(check_params(c, p_tl, S, "pair_llh (GP1)"));
     BQCHK(check_params(c, p_l, S, "pair_llh (GP2)"));
     HIPCHK(c, hipSetDevice(c->device));
-    const int ns = pr->ns, nc = pr->nc;
     // both plans' kernel parameters from pinned staging
     for (int b = 0; b < S; ++b) {
         const double w1[1] = {p_tl[3 * b + 1]}, w2[1] = {p_l[3 * b + 1]};
         pr->hpar[b] = make_params(1, p_tl[3 * b], w1, p_tl[3 * b + 2]);
         pr->hpar[S + b] = make_params(1, p_l[3 * b], w2, p_l[3 * b + 2]);
     }
-    if (pr->merged) {
-        // one plan of 2 S systems: [GP1 under the S sets | GP2 under the S sets]
-        HIPCHK(c, hipMemcpyAsync(pr->p1->gp.p, pr->hpar, sizeof(GaussParams) * 2 * S,
-                                 hipMemcpyHostToDevice, c->stream));
-        BQCHK(bq_plan_run(c, pr->p1));
-        HIPCHK(c, hipMemsetAsync(pr->flag.p, 0, sizeof(int) * S, c->stream));
-        hipLaunchKernelGGL(pair_collect_kernel, dim3(S), dim3(64), 0, c->stream, pr->p1->scal.d(),
-                           pr->p1->scal.d() + 4 * S, pr->p1->info.i(), pr->p1->info.i() + S,
-                           pr->flag.i(), pr->p1->y.d(), (long)pr->p1->L.npad, ns, 0,
-                           pr->dres.d());
-        HIPCHK(c, hipGetLastError());
-    } else {
-        HIPCHK(c, hipMemcpyAsync(pr->p1->gp.p, pr->hpar, sizeof(GaussParams) * S,
-                                 hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(pr->p2->gp.p, pr->hpar + S, sizeof(GaussParams) * S,
-                                 hipMemcpyHostToDevice, c->stream));
-        BQCHK(bq_plan_run(c, pr->p1));
-        HIPCHK(c, hipMemsetAsync(pr->flag.p, 0, sizeof(int) * S, c->stream));
-        const long ms = std::max(nc, 1), ys = pr->p2->L.npad;
-        hipLaunchKernelGGL(pair_targets_kernel, dim3((nsc + 255) / 256, S), dim3(256), 0,
-                           c->stream, pr->l_s.d(), ns, nc, pr->p1->mean.d(), pr->p1->var.d(), ms,
-                           max_log(), pr->p2->y.d(), ys, pr->flag.i());
-        HIPCHK(c, hipGetLastError());
-        BQCHK(bq_plan_run(c, pr->p2));
-        hipLaunchKernelGGL(pair_collect_kernel, dim3(S), dim3(64), 0, c->stream,
-                           pr->p1->scal.d(), pr->p2->scal.d(), pr->p1->info.i(),
-                           pr->p2->info.i(), pr->flag.i(), pr->p2->y.d(), ys, ns, nc,
-                           pr->dres.d());
-        HIPCHK(c, hipGetLastError());
+    // one graph launch per pass where graphs are in use (the pass of a small system is a dozen
+    // stream operations of a few microseconds each)
+    const int key = c->nb_override * 64 + c->lookahead * 32 + c->split_batch * 16 +
+                    c->gemm_lds64 * 8 + c->gemm_lds * 4 + c->potf2_8w * 2 + c->fold_readout;
+    if (pr->lgraph_state == 1 && pr->lgraph_key != key) {
+        (void)hipGraphExecDestroy(pr->lgexec);
+        (void)hipGraphDestroy(pr->lgraph);
+        pr->lgexec = nullptr;
+        pr->lgraph = nullptr;
+        pr->lgraph_state = 0;
     }
-    HIPCHK(c, hipMemcpyAsync(pr->hres, pr->dres.p, sizeof(double) * (size_t)S * (5 + nc),
-                             hipMemcpyDeviceToHost, c->stream));
+    if (!c->prof && c->use_graph && c->own_stream && pr->lgraph_state == 0) {
+        pr->lgraph_key = key;
+        pr->lgraph_state = -1;
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
+            const int st = pair_llh_enqueue(c, pr);
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(c->stream, &g);
+            if (st == BQ_OK && e == hipSuccess && g &&
+                hipGraphInstantiate(&pr->lgexec, g, nullptr, nullptr, 0) == hipSuccess) {
+                pr->lgraph = g;
+                pr->lgraph_state = 1;
+            } else {
+                if (g)
+                    (void)hipGraphDestroy(g);
+                (void)hipGetLastError(); // clear; fall back to eager launches
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (!c->prof && c->use_graph && c->own_stream && pr->lgraph_state == 1)
+        HIPCHK(c, hipGraphLaunch(pr->lgexec, c->stream));
+    else
+        BQCHK(pair_llh_enqueue(c, pr));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int b = 0; b < S; ++b) {
         const double *r = pr->hres + (size_t)b * (5 + nc);
