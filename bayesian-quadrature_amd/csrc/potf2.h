@@ -122,10 +122,14 @@ __device__ __forceinline__ void potf2f_update(Potf2FT<NW> &st, const double *slo
 //     before step P + 1) and applies its own panel P to its later groups;
 //   * the other two waves apply panel P to everything of theirs that lies behind it.
 // wst (profiling probe only): every wave's arrival at and release from barrier P.
-template <int P, int NW = 4>
+template <int P, int NW = 4, bool PAD = false>
 struct Potf2FSteps {
+    // PAD, nreal: the block's rows / columns from nreal on are identity padding (a system whose
+    // size is not a multiple of 64): panels that lie wholly in it are neither factored nor applied
+    // -- they are what they will be -- and the sweep over the panels ends with the last real one.
+    // (An instantiation of its own: the tests cost the full block's straight-line code 0.9 us.)
     static __device__ __forceinline__ void run(Potf2FT<NW> &st, double *slots, int w, int lane,
-                                               long long *wst)
+                                               long long *wst, int nreal)
     {
         constexpr int NG = 16 / NW;
         constexpr int QP = P / NW, WP = P % NW;
@@ -142,8 +146,10 @@ struct Potf2FSteps {
         for (int s = 0; s < 4; ++s)
             li[s] = slot[s * 64 + lane];
         if (P < 15 && w == WN) {
-            potf2f_update<(1 << QN), NW>(st, slot, li, w);
-            potf2f_factor<PN, NW>(st, slots + (PN % 3) * 256, lane);
+            if (!PAD || 4 * PN < nreal) {
+                potf2f_update<(1 << QN), NW>(st, slot, li, w);
+                potf2f_factor<PN, NW>(st, slots + (PN % 3) * 256, lane);
+            }
         } else if (w == WP) {
             if (P >= 1 && LATER != 0) {
                 const double *prev = slots + ((P + 2) % 3) * 256;
@@ -159,12 +165,15 @@ struct Potf2FSteps {
         } else {
             potf2f_update<LATER, NW>(st, slot, li, w);
         }
-        Potf2FSteps<P + 1, NW>::run(st, slots, w, lane, wst);
+        if (!PAD || 4 * (P + 1) < nreal)
+            Potf2FSteps<P + 1, NW, PAD>::run(st, slots, w, lane, wst, nreal);
     }
 };
-template <int NW>
-struct Potf2FSteps<16, NW> {
-    static __device__ __forceinline__ void run(Potf2FT<NW> &, double *, int, int, long long *) {}
+template <int NW, bool PAD>
+struct Potf2FSteps<16, NW, PAD> {
+    static __device__ __forceinline__ void run(Potf2FT<NW> &, double *, int, int, long long *, int)
+    {
+    }
 };
 
 // lds: BQ_POTF2F_LDS_DOUBLES doubles.  src (leading dimension lsrc): where the block is read
@@ -180,7 +189,7 @@ __device__ __forceinline__ void potf2f_body(double *__restrict__ Ab, long lda, i
                                             const double *src = nullptr, long lsrc = 0,
                                             bool src_in_slots = false,
                                             long long *stamps = nullptr,
-                                            double *logdet = nullptr)
+                                            double *logdet = nullptr, int nreal = 64)
 {
     constexpr int NG = 16 / NW;
     const int lane = threadIdx.x & 63;
@@ -205,8 +214,15 @@ __device__ __forceinline__ void potf2f_body(double *__restrict__ Ab, long lda, i
         potf2f_factor<0, NW>(st, slots, lane);
     // (per-wave barrier stamps: the four-wave probe only, and only when it asks for them with
     // stamps[5] != 0 -- they cost the chain 2,500 cycles)
-    Potf2FSteps<0, NW>::run(st, slots, w, lane,
-                            (stamps && NW == 4 && stamps[5] != 0) ? stamps + 8 : nullptr);
+    // (only the assembly's first factor passes nreal -- a system of fewer than 64 points has no
+    // other --: inside slab_step_kernel the second instantiation cost C2 0.4 us per step)
+    if (nreal < 64)
+        Potf2FSteps<0, NW, true>::run(st, slots, w, lane, nullptr, nreal > 0 ? nreal : 1);
+    else
+        Potf2FSteps<0, NW, false>::run(st, slots, w, lane,
+                                       (stamps && NW == 4 && stamps[5] != 0) ? stamps + 8
+                                                                              : nullptr,
+                                       64);
     BQ_STAMP(2);
     // the four 16 x 16 diagonal sub-blocks into LDS from registers:
     // blk[b][i + 16 k] = L[16 b + i][16 b + k]; my columns c = 4 (NW q + w) + sc: block c >> 4
@@ -322,7 +338,8 @@ __device__ __forceinline__ void potf2_body(double *__restrict__ Ab, long lda, in
                                            double *__restrict__ dinv_b, int *__restrict__ info_b,
                                            double *lds, const double *src = nullptr,
                                            long lsrc = 0, long long *stamps = nullptr,
-                                           double *logdet = nullptr)
+                                           double *logdet = nullptr, int nreal = 64)
 {
-    potf2f_body<NW>(Ab, lda, j0, dinv_b, info_b, lds, src, lsrc, src == lds, stamps, logdet);
+    potf2f_body<NW>(Ab, lda, j0, dinv_b, info_b, lds, src, lsrc, src == lds, stamps, logdet,
+                    nreal);
 }

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64 * NW) void assemble_first_kernel(
         __syncthreads(); // the block's 64 x 64 entries (rows 0..63 of this tile) are in memory
         __builtin_amdgcn_s_setprio(3);
         potf2_body<NW>(A, lda, 0, dinv + (long)b * dstride, info + b, plds, nullptr, 0, nullptr,
-                       scal ? scal + 4 * b + 1 : nullptr);
+                       scal ? scal + 4 * b + 1 : nullptr, L.n);
     }
 }
 
