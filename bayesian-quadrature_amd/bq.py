@@ -298,10 +298,35 @@ class BQ(object):
         """X (S x 2 len(params)) -> the S values of the closure of ``_make_llh_params``, all sets
         in ONE batched device pass (bq_pair_llh) instead of S sequential refits of both GPs.
         Unlike the closure it leaves the GPs' parameters alone."""
+        order = {"h": 0, "w": 1, "s": 2}
+        cols = [order[name] for name in params]
+        nparam = len(params)
+        base_tl = np.asarray(self.gp_log_l.params, dtype=DTYPE).copy()
+        base_l = np.asarray(self.gp_l.params, dtype=DTYPE).copy()
+        buf = {}
+
         def fb(X):
-            p_tl, p_l, ok = self._param_sets(params, X)
-            llh, _, _ = self._pair(p_tl.shape[0]).llh(p_tl, p_l)
-            return np.where(ok, llh, -np.inf)
+            # (the loops call this thousands of times on tiny systems: the S x 3 parameter arrays
+            # are kept per S and filled in place -- _param_sets, the general form, costs 14 us)
+            X = np.asarray(X, dtype=DTYPE)
+            if X.ndim != 2:
+                X = np.atleast_2d(X)
+            S = X.shape[0]
+            if S not in buf:
+                buf[S] = (np.empty((S, 3)), np.empty((S, 3)))
+            p_tl, p_l = buf[S]
+            p_tl[:] = base_tl
+            p_l[:] = base_l
+            p_tl[:, cols] = X[:, :nparam]
+            p_l[:, cols] = X[:, nparam:]
+            ok = (np.isfinite(X).all(axis=1) & (p_tl[:, :2] > 0).all(axis=1) & (p_tl[:, 2] >= 0) &
+                  (p_l[:, :2] > 0).all(axis=1) & (p_l[:, 2] >= 0))
+            if not ok.all():
+                # rejected sets still ride through the batch, with harmless parameters
+                p_tl[~ok] = base_tl
+                p_l[~ok] = base_l
+            llh, _, _ = self._pair(S).llh(p_tl, p_l)
+            return llh if ok.all() else np.where(ok, llh, -np.inf)
 
         return fb
 
