@@ -96,6 +96,12 @@ static int ctx_init(bq_ctx *c, int device)
         c->lookahead = std::atoi(e);
     if (const char *e = std::getenv("BQ_SPLIT"))
         c->split_batch = std::atoi(e);
+    if (const char *e = std::getenv("BQ_DIAG_FIRST"))
+        c->diag_first = std::atoi(e);
+    if (const char *e = std::getenv("BQ_DF_SWEEP"))
+        c->df_sweep = std::atoi(e);
+    if (const char *e = std::getenv("BQ_DF_SHARING"))
+        c->df_sharing = std::atoi(e);
     if (const char *e = std::getenv("BQ_LA_MIN"))
         c->la_min = std::atoi(e);
     if (const char *e = std::getenv("BQ_GEMM_LDS"))

@@ -634,11 +634,19 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C
 // (group g takes k-steps 2g, 2g + 1 of the four) and meet in LDS at the end: the form the tile
 // takes inside rows_fused_kernel's eight-wave workgroups (whose job tiles gain from eight waves;
 // this tile neither gains nor loses).
-template <bool QT, int KS = 1>
+// TRSM (the batched panel solve, potrf.hip: enqueue_trsm_rec): the tiles of column block 0 -- the
+// 64-column slab that is solved next -- do not store C - P Q^T but (C - P Q^T) L_ss^-T, the
+// trsm_blk_kernel scheme applied to the tile on its way out (through LDS into that kernel's
+// 16-rows-per-wave operand form): one launch and one pass over the slab less per 64 columns.
+// Lss: the slab's factored 64 x 64 diagonal block, wrec: its record of block inverses.
+template <bool QT, int KS = 1, bool TRSM = false>
 __device__ __forceinline__ void gemm_lds64_body(unsigned char *smem, double *__restrict__ C,
                                                 long ldc, const double *__restrict__ P, long ldp,
                                                 const double *__restrict__ Q, long ldq, int m,
-                                                int n, int k, int lower, int ncut, int bx, int by)
+                                                int n, int k, int lower, int ncut, int bx, int by,
+                                                const double *__restrict__ Lss = nullptr,
+                                                long ldl = 0,
+                                                const double *__restrict__ wrec = nullptr)
 {
     const int t = threadIdx.x, lane = t & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -791,9 +799,68 @@ __device__ __forceinline__ void gemm_lds64_body(unsigned char *smem, double *__r
         ct.store_neg(acc, lower);
         return;
     }
+    if (TRSM && by == 0) {
+        // (lower == 0 and whole tiles here: every wave is active)
+        double *Ts = reinterpret_cast<double *>(smem); // the updated tile, column-major 64 x 64
+        __syncthreads();                               // the staging buffers are free
+        {
+            const int blk = (lane >> 2) & 3;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        Ts[wr + 16 * tm + l15 + 64 * (wc + 16 * tn + l4 + 4 * ((blk - s) & 3))] =
+                            -acc[tm][tn][s];
+        }
+        __syncthreads();
+        // rows 16 wave .. + 15 of the tile: X_c = (T_c - sum_{b<c} X_b L_cb^T) W_cc^T (trsm.h)
+        const double *L11 = Lss + l15 + (long)l4 * ldl;
+        const double *W = wrec + 64 + l15 + 16 * l4;
+        const double *Tw = Ts + 16 * wave + l15 + 64 * l4;
+        double *Xr = C + R0 + 16 * wave + l15 + (long)(C0 + l4) * ldc;
+        double4_t x[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            double4_t a4 = {-Tw[64 * (16 * c)], -Tw[64 * (16 * c + 4)], -Tw[64 * (16 * c + 8)],
+                            -Tw[64 * (16 * c + 12)]};
+#pragma unroll
+            for (int bb = 0; bb < c; ++bb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                        L11[16 * c + (long)(16 * bb + 4 * r) * ldl], x[bb][r], a4, 0, 0, 0);
+            double4_t xc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                xc = __builtin_amdgcn_mfma_f64_16x16x4f64(-W[256 * c + 64 * r], a4[r], xc, 0, 0, 0);
+            x[c] = xc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Xr[(long)(16 * c + 4 * r) * ldc] = xc[r];
+        }
+        return;
+    }
     if (!active)
         return;
     ct.store_neg(acc, lower);
+}
+
+// the product of the batched panel solve: C (m x n) -= P Q^T with the solve of the first 64
+// columns of C fused in (gemm_lds64_body<.., TRSM>); m, n multiples of 64, k of 32
+__global__ __launch_bounds__(256, 4) void gemm_trsm64_kernel(
+    double *__restrict__ C, long ldc, long cstride, const double *__restrict__ P, long ldp,
+    long pstride, const double *__restrict__ Q, long ldq, long qstride, int m, int n, int k,
+    const double *__restrict__ Lss, long ldl, long lstride, const double *__restrict__ wrec,
+    long wstride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.z;
+    gemm_lds64_body<false, 1, true>(smem, C + (long)b * cstride, ldc, P + (long)b * pstride, ldp,
+                                    Q + (long)b * qstride, ldq, m, n, k, 0, 0x7fffffff,
+                                    blockIdx.x, blockIdx.y, Lss + (long)b * lstride, ldl,
+                                    wrec + (long)b * wstride);
 }
 
 template <bool QT, int KS = 1>

@@ -84,6 +84,11 @@ struct bq_ctx {
     hipEvent_t ev_panel = nullptr, ev_next = nullptr, ev_fork = nullptr;
     int lookahead = 1;
     int split_batch = 1; // halves of a mid-sized batch on the two streams (BQ_SPLIT=0: lock-step)
+    int diag_first = 1;  // batches: every outer block as diagonal factor, ONE panel solve, update
+                         // (enqueue_potrf_dfirst; BQ_DIAG_FIRST=0: the recursive panels)
+    int df_sweep = 1;    // the panel solve of an outer block in one launch (trsm_sweep_kernel; BQ_DF_SWEEP)
+    int df_sharing = 1;  // gemm_lds_tile's sharing mode while a diagonal factor runs beside an update
+    int cfg_epoch = 0;   // bumped by every setter that changes a launch sequence (graph keys)
     int la_min = 3072;   // look-ahead only while the bulk update has at least this many rows (BQ_LA_MIN)
     DevBuf panel_ws;     // scratch panel columns of the eager linalg entry points
     DevBuf scratch;      // per-call temporaries of the acquisition / moment entry points, kept
@@ -275,11 +280,12 @@ int launch_panel_step(bq_ctx *c, double *A, long lda, long astride, int batch, i
                       double *dinv_in, double *dinv_out, int has_next, int first, double *SL,
                       int *info, double work);
 int launch_slab_first(bq_ctx *c, double *A, long lda, long astride, int batch, double *S, long lds,
-                      long sstride, int ntot, double *dinv, int *info, int col0);
+                      long sstride, int ntot, double *dinv, int *info, int col0,
+                      long dstride = BQ_DINV_STRIDE);
 int launch_slab_step(bq_ctx *c, double *A, long lda, long astride, int batch, double *Sin,
                      double *Sout, long lds, long sstride, int ntot, int j0, double *dinv_in,
                      double *dinv_out, int fnext, int last, int *info, int col0,
-                     long long *stamps, double work);
+                     long long *stamps, double work, long dstride = BQ_DINV_STRIDE);
 
 // ---- k_gemm.hip -----------------------------------------------------------------------
 int gemm_init(bq_ctx *c); // function attributes of the LDS-staged kernels, once per context
@@ -289,6 +295,13 @@ int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const dou
                 long pstride, const double *Q, long qsj, long qsk, long qstride, int m, int n,
                 int k, int lower, int batch, int fuse_j0 = -1, double *dinv = nullptr,
                 long dstride = 0, int *info = nullptr, int ccut = 0);
+bool gemm_trsm_ok(const bq_ctx *c, int m, int n, int k);
+int launch_gemm_trsm(bq_ctx *c, double *C, long ldc, long cstride, const double *P, long ldp,
+                     long pstride, const double *Q, long ldq, long qstride, int m, int n, int k,
+                     const double *Lss, long ldl, long lstride, const double *wrec, long wstride,
+                     int batch);
+int launch_trsm_sweep(bq_ctx *c, double *X, long ldx, long xstride, int m, const double *L11,
+                      long ldl, long lstride, const double *rec, long rstride, int kb, int batch);
 int launch_gemm_rows(bq_ctx *c, int cls, double *C, long ldc, const double *P, long ldp,
                      const double *Q, long qsj, long qsk, int m, int n, int k);
 int launch_rows_step(bq_ctx *c, int mrows, const RowsJob &a, const RowsJob &b, double work);
@@ -321,12 +334,16 @@ int launch_trsv_bwd(bq_ctx *c, const double *L, long ldl, int J, int bJ, int B, 
 // ---- potrf.hip ------------------------------------------------------------------------
 int auto_nb(const bq_ctx *c, int ntot, int batch);
 size_t panel_ws_doubles(int ntot, int batch);
+size_t sweep_ws_doubles(const bq_ctx *c, int ntot, int batch);
 bool panel_ws_useful(const bq_ctx *c, int ntot, int batch);
 bool sweep_is_slab(const bq_ctx *c, int ntot, int ncols, int batch, size_t panel_ws_len);
 int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
                           int ncols, double *dinv, int *info, double *panel_ws = nullptr,
                           size_t panel_ws_len = 0, bool first_done = false,
                           bool skip_border = false);
+
+int enqueue_panel_solve(bq_ctx *c, double *A, long lda, long astride, int batch, int r0, int m2,
+                        int K0, int KB, const double *rec, long rstride);
 
 // ---- sweeps.hip -----------------------------------------------------------------------
 struct WideInv {

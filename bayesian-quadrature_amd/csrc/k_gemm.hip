@@ -1,6 +1,7 @@
 // k_gemm.hip -- the MFMA products C -= P Q^T (gemm.h) and their launchers.
 #include "host.h"
 #include "gemm.h"
+#include "trsmsweep.h"
 
 namespace bqh {
 
@@ -18,6 +19,8 @@ int gemm_init(bq_ctx *c)
     BQ_L64_ATTR((rows_fused_kernel<true, 1>), BQ_L64_BYTES);
     BQ_L64_ATTR((rows_fused_kernel<false, 2>), BQ_L64_BYTES);
     BQ_L64_ATTR((rows_fused_kernel<true, 2>), BQ_L64_BYTES);
+    BQ_L64_ATTR(gemm_trsm64_kernel, BQ_L64_BYTES);
+    BQ_L64_ATTR(trsm_sweep_kernel, BQ_L64_BYTES);
 #undef BQ_L64_ATTR
     return BQ_OK;
 }
@@ -174,6 +177,45 @@ int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const dou
             BQ_GEMM_SUB(1, 1, 32);
     }
 #undef BQ_GEMM_SUB
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+// C (m x n) -= P Q^T with the panel solve of C's first 64 columns fused in (gemm_trsm64_kernel):
+// the batched panel solve's products (potrf.hip, enqueue_trsm_rec).  Lss / wrec: the factored
+// diagonal block those 64 columns are solved against and its record of block inverses.
+bool gemm_trsm_ok(const bq_ctx *c, int m, int n, int k)
+{
+    return c->gemm_lds64 && m > 0 && (m % 64) == 0 && n >= 64 && (n % 64) == 0 && k >= 32 &&
+           (k % 32) == 0;
+}
+
+int launch_gemm_trsm(bq_ctx *c, double *C, long ldc, long cstride, const double *P, long ldp,
+                     long pstride, const double *Q, long ldq, long qstride, int m, int n, int k,
+                     const double *Lss, long ldl, long lstride, const double *wrec, long wstride,
+                     int batch)
+{
+    if (!gemm_trsm_ok(c, m, n, k))
+        return fail(c, BQ_ERR_BAD_ARG, "gemm_trsm: m, n multiples of 64 and k of 32");
+    Bracket br(c, BQ_K_GEMM, (2.0 * (double)m * n * k + 64.0 * 64 * (double)m) * batch);
+    hipLaunchKernelGGL(gemm_trsm64_kernel, dim3(m / 64, n / 64, batch), dim3(256), BQ_L64_BYTES,
+                       c->cur, C, ldc, cstride, P, ldp, pstride, Q, ldq, qstride, m, n, k, Lss, ldl,
+                       lstride, wrec, wstride);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+// X (m x kb) <- X L11^-T for every row block in one launch (trsm_sweep_kernel)
+int launch_trsm_sweep(bq_ctx *c, double *X, long ldx, long xstride, int m, const double *L11,
+                      long ldl, long lstride, const double *rec, long rstride, int kb, int batch)
+{
+    if (m <= 0)
+        return BQ_OK;
+    if ((m & 63) || (kb & 63) || kb <= 0)
+        return fail(c, BQ_ERR_BAD_ARG, "trsm_sweep: m and kb must be multiples of 64");
+    Bracket br(c, BQ_K_TRSM, (double)m * kb * kb * batch);
+    hipLaunchKernelGGL(trsm_sweep_kernel, dim3(m / 64, 1, batch), dim3(256), BQ_L64_BYTES, c->cur, X,
+                       ldx, xstride, L11, ldl, lstride, rec, rstride, kb);
     HIPCHK(c, hipGetLastError());
     return BQ_OK;
 }

@@ -100,11 +100,11 @@ int launch_panel_step(bq_ctx *c, double *A, long lda, long astride, int batch, i
 
 // the first diagonal factor of a slab sweep and the staging of panel 0 in one launch
 int launch_slab_first(bq_ctx *c, double *A, long lda, long astride, int batch, double *S, long lds,
-                      long sstride, int ntot, double *dinv, int *info, int col0)
+                      long sstride, int ntot, double *dinv, int *info, int col0, long dstride)
 {
     Bracket br(c, BQ_K_POTF2, 64.0 * 64 * 64 / 3.0 * batch);
     hipLaunchKernelGGL(slab_first_kernel, dim3(ntot / 64, 1, batch), dim3(256), 0, c->cur, A, lda,
-                       astride, S, lds, sstride, ntot, dinv, (long)BQ_DINV_STRIDE, info, col0);
+                       astride, S, lds, sstride, ntot, dinv, dstride, info, col0);
     HIPCHK(c, hipGetLastError());
     return BQ_OK;
 }
@@ -114,7 +114,7 @@ int launch_slab_first(bq_ctx *c, double *A, long lda, long astride, int batch, d
 int launch_slab_step(bq_ctx *c, double *A, long lda, long astride, int batch, double *Sin,
                      double *Sout, long lds, long sstride, int ntot, int j0, double *dinv_in,
                      double *dinv_out, int fnext, int last, int *info, int col0,
-                     long long *stamps, double work)
+                     long long *stamps, double work, long dstride)
 {
     const int T = (ntot - j0 - 64) / 64;
     Bracket br(c, BQ_K_SYRK_SMALL, work);
@@ -123,21 +123,21 @@ int launch_slab_step(bq_ctx *c, double *A, long lda, long astride, int batch, do
     if (stamps && w8)
         hipLaunchKernelGGL((slab_step_kernel<true, 8>), dim3(T * (T + 1) / 2, 1, batch), dim3(512), 0,
                            c->cur, A, lda, astride, Sin, Sout, lds, sstride, ntot, j0, dinv_in,
-                           dinv_out, (long)BQ_DINV_STRIDE, fnext, last, info, col0, stamps, c->slab_out);
+                           dinv_out, dstride, fnext, last, info, col0, stamps, c->slab_out);
     else if (stamps)
         hipLaunchKernelGGL((slab_step_kernel<true, 4>), dim3(T * (T + 1) / 2, 1, batch), dim3(256), 0,
                            c->cur, A, lda, astride, Sin, Sout, lds, sstride, ntot, j0, dinv_in,
-                           dinv_out, (long)BQ_DINV_STRIDE, fnext, last, info, col0, stamps, c->slab_out);
+                           dinv_out, dstride, fnext, last, info, col0, stamps, c->slab_out);
     else if (w8)
         // a CU per workgroup: 512 threads, the diagonal factor on eight waves
         hipLaunchKernelGGL((slab_step_kernel<false, 8>), dim3(T * (T + 1) / 2, 1, batch), dim3(512),
                            0, c->cur, A, lda, astride, Sin, Sout, lds, sstride, ntot, j0, dinv_in,
-                           dinv_out, (long)BQ_DINV_STRIDE, fnext, last, info, col0,
+                           dinv_out, dstride, fnext, last, info, col0,
                            (long long *)nullptr, c->slab_out);
     else
         hipLaunchKernelGGL((slab_step_kernel<false, 4>), dim3(T * (T + 1) / 2, 1, batch), dim3(256),
                            0, c->cur, A, lda, astride, Sin, Sout, lds, sstride, ntot, j0, dinv_in,
-                           dinv_out, (long)BQ_DINV_STRIDE, fnext, last, info, col0,
+                           dinv_out, dstride, fnext, last, info, col0,
                            (long long *)nullptr, c->slab_out);
     HIPCHK(c, hipGetLastError());
     return BQ_OK;

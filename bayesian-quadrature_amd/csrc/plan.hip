@@ -38,9 +38,7 @@ extern "C" int bq_plan_create(bq_ctx *c, int64_t nprob, int64_t d, int64_t n, in
     A(p->y, sizeof(double) * (size_t)p->L.npad * nprob);
     A(p->gp, sizeof(GaussParams) * (size_t)nprob);
     A(p->dinv, sizeof(double) * BQ_DINV_STRIDE * (size_t)nprob);
-    A(p->panel, panel_ws_useful(c, p->L.ntot, (int)nprob)
-                    ? sizeof(double) * panel_ws_doubles(p->L.ntot, (int)nprob)
-                    : 0);
+    A(p->panel, sizeof(double) * sweep_ws_doubles(c, p->L.ntot, (int)nprob));
     A(p->info, sizeof(int) * (size_t)nprob);
     A(p->scal, sizeof(double) * 4 * (size_t)nprob);
     A(p->mean, sizeof(double) * (size_t)std::max<int64_t>(M, 1) * nprob);

@@ -146,20 +146,25 @@ bool panel_ws_useful(const bq_ctx *c, int ntot, int batch)
 // diagonal factor and the staging of panel 0.
 // col0: global column of A's first column (a sweep over the trailing block of a larger
 // factorisation reports failures in the larger matrix's numbering)
+// rstride > 0: `dinv` is a row of RECORDS per problem (rstride doubles apart), one BQ_DINV_HALF
+// per 64-column step, and every step's reciprocal pivots / block inverses stay behind in the
+// record of its own diagonal block (the batched panel solve reads them: enqueue_potrf_dfirst);
+// else the two halves of a BQ_DINV_STRIDE ping-pong.
 static int enqueue_slab_sweep(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
                        int ncols, double *dinv, int *info, double *ws, int col0 = 0,
-                       bool first_done = false)
+                       bool first_done = false, long rstride = 0)
 {
+    const long dstride = rstride > 0 ? rstride : (long)BQ_DINV_STRIDE;
     if (ntot <= 64)
-        return launch_potf2(c, A - col0 - (long)col0 * lda, lda, astride, col0, dinv,
-                            BQ_DINV_STRIDE, info, batch);
+        return launch_potf2(c, A - col0 - (long)col0 * lda, lda, astride, col0, dinv, dstride,
+                            info, batch);
     const long sstride = 64L * ntot;
     double *S[2] = {ws, ws + sstride * batch};
     if (!first_done)
         // the first diagonal factor and the staging of panel 0 share a launch (or ride in the
         // assembly: assemble_first_kernel)
         BQCHK(launch_slab_first(c, A, lda, astride, batch, S[0], (long)ntot, sstride, ntot, dinv,
-                                info, col0));
+                                info, col0, dstride));
     for (int j0 = 0, par = 0; j0 < ncols; j0 += 64, par ^= 1) {
         const int r0 = j0 + 64;
         if (r0 >= ntot)
@@ -171,10 +176,12 @@ static int enqueue_slab_sweep(bq_ctx *c, double *A, long lda, long astride, int 
                                 ? c->stamp_buf + 160 * (j0 / 64)
                                 : nullptr;
         // the tile updates (lower half of 2 m^2 64) and the solve of the panel (m 64^2)
+        const long din = rstride > 0 ? (long)(j0 / 64) * BQ_DINV_HALF : (long)par * BQ_DINV_HALF;
+        const long dout =
+            rstride > 0 ? (long)(j0 / 64 + 1) * BQ_DINV_HALF : (long)(par ^ 1) * BQ_DINV_HALF;
         BQCHK(launch_slab_step(c, A, lda, astride, batch, S[par], S[par ^ 1], (long)ntot, sstride,
-                               ntot, j0, dinv + par * BQ_DINV_HALF,
-                               dinv + (par ^ 1) * BQ_DINV_HALF, fnext, !fnext, info, col0, stamps,
-                               (m * m * 64.0 + m * 64.0 * 64.0) * batch));
+                               ntot, j0, dinv + din, dinv + dout, fnext, !fnext, info, col0, stamps,
+                               (m * m * 64.0 + m * 64.0 * 64.0) * batch, dstride));
     }
     return BQ_OK;
 }
@@ -319,6 +326,141 @@ static int enqueue_potrf_group(bq_ctx *c, double *A, long lda, long astride, int
     return BQ_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batches, diagonal block first (round 4).  The recursive panels above factor an outer block's
+// m x NB panel as a chain of 64-column steps over ALL its rows: per step a one-workgroup diagonal
+// factor, a panel solve and a product, each a pass over rows that do not fit a cache (a C5
+// shard's panels: 440 MB) -- a third of a batch's sweep at a fifth of the chip's rate, and
+// a chain that two half-batches on two streams only hide by slowing each other down.  But
+// the rows below an outer block's NB x NB diagonal block take no part in factoring it:
+//     D  the diagonal block alone: a small Cholesky (one-launch steps, slab.h), a few MB per
+//        matrix, whose 64-column steps leave their block inverses behind in records;
+//     S  L21 = A21 L11^-T for all rows below in ONE sweep of throughput launches, recursively
+//        (left half, product, right half) with the solve of a product's first 64 columns fused
+//        into the product (gemm_trsm64_kernel): NB / 64 launches, none latency-bound;
+//     U  the trailing update, k = NB -- first, on the second stream, the NEXT diagonal block
+//        and its factorisation D, hidden beside the rest of the update.
+// The whole batch moves in lock-step through launches that each fill the chip.
+// ---------------------------------------------------------------------------------------------
+static size_t dfirst_rec_doubles(int nb, int batch) { return (size_t)(nb / 64) * BQ_DINV_HALF * batch; }
+static size_t dfirst_ws_doubles(int nb, int batch)
+{
+    return panel_ws_doubles(nb, batch) + dfirst_rec_doubles(nb, batch);
+}
+
+static bool dfirst_applies(const bq_ctx *c, int ntot, int ncols, int batch)
+{
+    return c->diag_first && batch >= 3 && ncols >= 128 && auto_nb(c, ntot, batch) >= 128;
+}
+
+size_t sweep_ws_doubles(const bq_ctx *c, int ntot, int batch)
+{
+    if (dfirst_applies(c, ntot, ntot, batch))
+        return dfirst_ws_doubles(std::min(auto_nb(c, ntot, batch), ntot), batch);
+    return panel_ws_useful(c, ntot, batch) ? panel_ws_doubles(ntot, batch) : 0;
+}
+
+// X = rows [rx, rx + m) of the panel that starts at column K0: columns [j0, j0 + w) (relative
+// to K0) solved against L11 = A[K0.., K0..]; rec: the records of L11's 64 x 64 diagonal blocks.
+// solved: the launch that last updated slab j0 solved it as well.
+static int enqueue_trsm_rec(bq_ctx *c, double *A, long lda, long astride, int batch, int rx, int m,
+                            int K0, int j0, int w, const double *rec, long rstride, bool solved)
+{
+    if (w <= 64) {
+        if (solved)
+            return BQ_OK;
+        const long cj = K0 + j0;
+        return launch_trsm_blk(c, A + rx + cj * lda, lda, astride, m, A + cj + cj * lda, lda,
+                               astride, rec + (long)(j0 / 64) * BQ_DINV_HALF, rstride, batch);
+    }
+    const int wl = ((w / 64 + 1) / 2) * 64, wr = w - wl;
+    BQCHK(enqueue_trsm_rec(c, A, lda, astride, batch, rx, m, K0, j0, wl, rec, rstride, solved));
+    const long cl = K0 + j0, cr = cl + wl;
+    double *C = A + rx + cr * lda;
+    const double *P = A + rx + cl * lda;
+    const double *Q = A + cr + cl * lda; // L11[j0 + wl .., j0 ..): wr x wl
+    const bool fuse = gemm_trsm_ok(c, m, wr, wl);
+    if (fuse)
+        BQCHK(launch_gemm_trsm(c, C, lda, astride, P, lda, astride, Q, lda, astride, m, wr, wl,
+                               A + cr + cr * lda, lda, astride,
+                               rec + (long)((j0 + wl) / 64) * BQ_DINV_HALF, rstride, batch));
+    else
+        BQCHK(launch_gemm(c, BQ_K_GEMM, C, lda, astride, P, lda, astride, Q, 1, lda, astride, m, wr,
+                          wl, 0, batch));
+    return enqueue_trsm_rec(c, A, lda, astride, batch, rx, m, K0, j0 + wl, wr, rec, rstride, fuse);
+}
+
+// the panel solve of one outer block as enqueue_potrf_dfirst issues it (also bq_probe_panel_solve)
+int enqueue_panel_solve(bq_ctx *c, double *A, long lda, long astride, int batch, int r0, int m2,
+                        int K0, int KB, const double *rec, long rstride)
+{
+    if (c->df_sweep && c->gemm_lds64)
+        return launch_trsm_sweep(c, A + r0 + (long)K0 * lda, lda, astride, m2,
+                                 A + K0 + (long)K0 * lda, lda, astride, rec, rstride, KB, batch);
+    return enqueue_trsm_rec(c, A, lda, astride, batch, r0, m2, K0, 0, KB, rec, rstride, false);
+}
+
+static int enqueue_potrf_dfirst(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
+                                int ncols, int *info, double *ws, bool skip_border)
+{
+    const int NB = std::min(auto_nb(c, ntot, batch), ncols);
+    double *rec = ws + panel_ws_doubles(NB, batch);
+    const long rstride = (long)(NB / 64) * BQ_DINV_HALF;
+    const bool la = c->lookahead && c->aux && c->cur == c->stream;
+    auto diag = [&](int K0, int KB) {
+        return enqueue_slab_sweep(c, A + K0 + (long)K0 * lda, lda, astride, batch, KB, KB, rec, info,
+                                  ws, K0, false, rstride);
+    };
+    BQCHK(diag(0, NB));
+    Sharing scope(c, la ? c->df_sharing : 0);
+    for (int K0 = 0; K0 < ncols; K0 += NB) {
+        const int KB = std::min(NB, ncols - K0), r0 = K0 + KB, m2 = ntot - r0;
+        if (m2 <= 0)
+            break;
+        BQCHK(enqueue_panel_solve(c, A, lda, astride, batch, r0, m2, K0, KB, rec, rstride));
+        const double *P = A + r0 + (long)K0 * lda;
+        const int nw = r0 < ncols ? std::min(NB, ncols - r0) : 0;
+        if (nw == 0) {
+            // what is left is the Schur complement of the border: nobody reads it when the
+            // results come off the border rows
+            if (!skip_border)
+                BQCHK(launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda,
+                                  astride, P, 1, lda, astride, m2, m2, KB, 1, batch));
+            break;
+        }
+        // the next diagonal block: updated and factored (on the second stream, beside the rest)
+        if (la) {
+            HIPCHK(c, hipEventRecord(c->ev_next, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_next, 0));
+            c->cur = c->aux;
+        }
+        int st = launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda, astride, P,
+                             1, lda, astride, nw, nw, KB, 1, batch);
+        if (st == BQ_OK)
+            st = diag(r0, nw);
+        if (la) {
+            c->cur = c->stream;
+            if (st == BQ_OK)
+                HIPCHK(c, hipEventRecord(c->ev_panel, c->aux));
+        }
+        BQCHK(st);
+        const int r1 = r0 + nw;
+        if (r1 < ntot) {
+            const double *P1 = A + r1 + (long)K0 * lda;
+            // the rows below it: the next panel's columns, then the square behind them
+            BQCHK(launch_gemm(c, BQ_K_SYRK, A + r1 + (long)r0 * lda, lda, astride, P1, lda, astride,
+                              P, 1, lda, astride, ntot - r1, nw, KB, 0, batch));
+            if (!(skip_border && r1 >= ncols))
+                BQCHK(launch_gemm(c, BQ_K_SYRK, A + r1 + (long)r1 * lda, lda, astride, P1, lda,
+                                  astride, P1, 1, lda, astride, ntot - r1, ntot - r1, KB, 1, batch,
+                                  -1, nullptr, 0, nullptr, skip_border ? ncols - r1 : 0));
+        }
+        if (la)
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_panel, 0));
+    }
+    return BQ_OK;
+}
+
 // Eliminate the first ncols columns of `batch` matrices.  A batch of mid-sized matrices
 // (config C5: 64 x N = 2048) sweeps in lock-step: every 64-column panel step is two short
 // dependent launches that leave most of the chip idle, and a third of the sweep's time is
@@ -333,6 +475,10 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
     if ((ntot & 63) || (ncols & 63) || ncols > ntot)
         return fail(c, BQ_ERR_BAD_ARG, "potrf: sizes must be multiples of 64");
     const int NB = auto_nb(c, ntot, batch);
+    if (dfirst_applies(c, ntot, ncols, batch) && panel_ws &&
+        panel_ws_len >= dfirst_ws_doubles(std::min(NB, ncols), batch))
+        return enqueue_potrf_dfirst(c, A, lda, astride, batch, ntot, ncols, info, panel_ws,
+                                    skip_border);
     // large systems (a look-ahead's size) in a batch that fills the chip many times over run
     // as ONE sequential group: the product is power-bound, beside it the
     // panel chain only takes clock away (C3, 100 x N = 4096: 189.8 ms with the look-ahead,

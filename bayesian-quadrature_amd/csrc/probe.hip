@@ -378,3 +378,45 @@ extern "C" int bq_probe_mfma_layout(bq_ctx *c, double *out256)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return BQ_OK;
 }
+
+// The batched panel solve alone: X (m x kb per problem) <- X L^-T against `batch` lower-triangular
+// kb x kb factors L (host, column-major, dense lower triangles), through the launches the batched
+// factorisation issues for an outer block (mode 0: as the context is configured; 1: the recursive
+// products + solves; 2: the one-launch sweep).  The factors' block-inverse records are built on
+// the device (diag_winv_kernel).
+extern "C" int bq_probe_panel_solve(bq_ctx *c, int64_t m, int64_t kb, int64_t batch, const double *L,
+                                    double *X, int mode)
+{
+    if (!c || !L || !X || m < 64 || (m & 63) || kb < 64 || (kb & 63) || batch < 1)
+        return c ? fail(c, BQ_ERR_BAD_ARG, "panel_solve: m, kb multiples of 64") : BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const long lda = (long)(kb + m), astride = lda * (long)kb;
+    const long rstride = (long)(kb / 64) * BQ_DINV_HALF;
+    DevBuf A, rec;
+    HIPCHK(c, A.alloc(sizeof(double) * (size_t)astride * batch));
+    HIPCHK(c, rec.alloc(sizeof(double) * (size_t)rstride * batch));
+    for (int64_t b = 0; b < batch; ++b) {
+        HIPCHK(c, hipMemcpy2DAsync(A.d() + b * astride, sizeof(double) * lda, L + b * kb * kb,
+                                   sizeof(double) * kb, sizeof(double) * kb, kb,
+                                   hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(A.d() + b * astride + kb, sizeof(double) * lda, X + b * m * kb,
+                                   sizeof(double) * m, sizeof(double) * m, kb,
+                                   hipMemcpyHostToDevice, c->stream));
+        BQCHK(launch_diag_winv(c, A.d() + b * astride, lda, (int)kb, rec.d() + b * rstride));
+    }
+    const int keep = c->df_sweep;
+    if (mode == 1)
+        c->df_sweep = 0;
+    if (mode == 2)
+        c->df_sweep = 1;
+    const int st = enqueue_panel_solve(c, A.d(), lda, astride, (int)batch, (int)kb, (int)m, 0,
+                                       (int)kb, rec.d(), rstride);
+    c->df_sweep = keep;
+    BQCHK(st);
+    for (int64_t b = 0; b < batch; ++b)
+        HIPCHK(c, hipMemcpy2DAsync(X + b * m * kb, sizeof(double) * m, A.d() + b * astride + kb,
+                                   sizeof(double) * lda, sizeof(double) * m, kb,
+                                   hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BQ_OK;
+}

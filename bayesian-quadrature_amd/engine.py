@@ -420,6 +420,20 @@ class Engine(object):
                                             C.cast(C.byref(v), _dp)))
         return float(v.value)
 
+    def probe_panel_solve(self, Lfac, X, mode=0):
+        """X L^-T for a batch of lower-triangular kb x kb factors L (batch, kb, kb) and row blocks
+        X (batch, m, kb) through the batched factorisation's panel-solve launches."""
+        L_ = np.asarray(Lfac, dtype=np.float64)
+        X_ = np.asarray(X, dtype=np.float64)
+        batch, kb, _ = L_.shape
+        m = X_.shape[1]
+        # column-major per problem
+        Lf = np.ascontiguousarray(np.transpose(L_, (0, 2, 1)))
+        Xf = np.ascontiguousarray(np.transpose(X_, (0, 2, 1)))
+        self._check(self._lib.bq_probe_panel_solve(self._ctx, int(m), int(kb), int(batch),
+                                                   L.dptr(Lf), L.dptr(Xf), int(mode)))
+        return np.transpose(Xf, (0, 2, 1)).copy()
+
     def probe_launch(self, n=2000):
         v = C.c_double()
         self._check(self._lib.bq_probe_launch(self._ctx, int(n), C.cast(C.byref(v), _dp)))

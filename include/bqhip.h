@@ -331,6 +331,12 @@ int bq_probe_c2_timeline(bq_ctx *ctx, bq_plan *plan, int64_t *stamps, int64_t ns
 int bq_probe_potf2(bq_ctx *ctx, const double *A, int from_lds, int64_t reps, double *L_out,
                    double *dinv_out, int32_t *info_out, double *us_per_launch,
                    int64_t *stamps136);
+/* The batched panel solve of one outer block alone (potrf.hip, enqueue_panel_solve): X (m x kb per
+ * problem, column-major, in / out) <- X L^-T against `batch` dense lower-triangular kb x kb
+ * factors L; mode 0: as the context is configured, 1: recursive products + 64-column solves,
+ * 2: the one-launch sweep (trsm_sweep_kernel).  m, kb multiples of 64. */
+int bq_probe_panel_solve(bq_ctx *ctx, int64_t m, int64_t kb, int64_t batch, const double *L,
+                         double *X, int mode);
 /* dump of the f64 MFMA D-register layout: out[64*4] receives, for lane l and
  * register r, the value row*16+col of the D element it holds */
 int bq_probe_mfma_layout(bq_ctx *ctx, double *out256);
