@@ -106,7 +106,7 @@ SIGNATURES = {
     "bq_probe_potf2": (C.c_int, [_vp, _dp, C.c_int, _i64, _dp, _dp, C.POINTER(C.c_int32), _dp,
                                  C.POINTER(C.c_int64)]),
     "bq_probe_mfma_layout": (C.c_int, [_vp, _dp]),
-    "bq_probe_panel_solve": (C.c_int, [_vp, _i64, _i64, _i64, _dp, _dp, C.c_int]),
+    "bq_probe_panel_solve": (C.c_int, [_vp, _i64, _i64, _i64, _dp, _dp, C.c_int, _i64, _dp]),
 }
 
 _lib = None

@@ -100,6 +100,10 @@ static int ctx_init(bq_ctx *c, int device)
         c->diag_first = std::atoi(e);
     if (const char *e = std::getenv("BQ_DF_SWEEP"))
         c->df_sweep = std::atoi(e);
+    if (const char *e = std::getenv("BQ_DF_WG"))
+        c->df_wg = std::atoi(e);
+    if (const char *e = std::getenv("BQ_DF_HALVES"))
+        c->df_halves = std::atoi(e);
     if (const char *e = std::getenv("BQ_DF_SHARING"))
         c->df_sharing = std::atoi(e);
     if (const char *e = std::getenv("BQ_LA_MIN"))

@@ -87,7 +87,11 @@ struct bq_ctx {
     int diag_first = 1;  // batches: every outer block as diagonal factor, ONE panel solve, update
                          // (enqueue_potrf_dfirst; BQ_DIAG_FIRST=0: the recursive panels)
     int df_sweep = 1;    // the panel solve of an outer block in one launch (trsm_sweep_kernel; BQ_DF_SWEEP)
-    int df_sharing = 1;  // gemm_lds_tile's sharing mode while a diagonal factor runs beside an update
+    int df_wg = -1;      // a batch's diagonal factor by one workgroup per matrix (potrf_wg_kernel): -1 by
+                         // batch size (potrf.hip, dfirst_wg), 0 / 1 forced (BQ_DF_WG)
+    int df_halves = 0;   // the diagonal-first sweep as two half-batches on the two streams (BQ_DF_HALVES)
+    int df_sharing = 0;  // gemm_lds_tile's sharing mode while a diagonal factor runs beside an update
+                         // (0: the rule of a product alone -- C5 shard 5.73 ms against 6.05 with 1)
     int cfg_epoch = 0;   // bumped by every setter that changes a launch sequence (graph keys)
     int la_min = 3072;   // look-ahead only while the bulk update has at least this many rows (BQ_LA_MIN)
     DevBuf panel_ws;     // scratch panel columns of the eager linalg entry points
@@ -271,6 +275,8 @@ int launch_assemble(bq_ctx *c, int d, const double *pts, long pstride, const dou
                     long astride, Layout L, int batch, const FirstStep &fs = FirstStep());
 int launch_potf2(bq_ctx *c, double *A, long lda, long astride, int j0, double *dinv, long dstride,
                  int *info, int batch);
+int launch_potrf_wg(bq_ctx *c, double *A, long lda, long astride, int kb, double *rec, long rstride,
+                    int *info, int col0, int batch);
 int launch_trsm_blk(bq_ctx *c, double *X, long ldx, long xstride, int m, const double *L11,
                     long ldl, long lstride, const double *dinv, long dstride, int batch);
 // the 16 x 16 block inverses of every 64 x 64 diagonal block of a factor (npad / 64 records)

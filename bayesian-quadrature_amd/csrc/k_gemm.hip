@@ -214,8 +214,9 @@ int launch_trsm_sweep(bq_ctx *c, double *X, long ldx, long xstride, int m, const
     if ((m & 63) || (kb & 63) || kb <= 0)
         return fail(c, BQ_ERR_BAD_ARG, "trsm_sweep: m and kb must be multiples of 64");
     Bracket br(c, BQ_K_TRSM, (double)m * kb * kb * batch);
-    hipLaunchKernelGGL(trsm_sweep_kernel, dim3(m / 64, 1, batch), dim3(256), BQ_L64_BYTES, c->cur, X,
-                       ldx, xstride, L11, ldl, lstride, rec, rstride, kb);
+    const int nrb = m / 64;
+    hipLaunchKernelGGL(trsm_sweep_kernel, dim3(8 * nrb * ((batch + 7) / 8)), dim3(256), BQ_L64_BYTES,
+                       c->cur, X, ldx, xstride, L11, ldl, lstride, rec, rstride, kb, nrb, batch);
     HIPCHK(c, hipGetLastError());
     return BQ_OK;
 }

@@ -63,6 +63,18 @@ int launch_potf2(bq_ctx *c, double *A, long lda, long astride, int j0, double *d
     return BQ_OK;
 }
 
+// the kb x kb diagonal block of every matrix of a batch, one workgroup per matrix
+// (potrf_wg_kernel); rec: kb / 64 records per matrix, rstride doubles apart
+int launch_potrf_wg(bq_ctx *c, double *A, long lda, long astride, int kb, double *rec, long rstride,
+                    int *info, int col0, int batch)
+{
+    Bracket br(c, BQ_K_POTF2, (double)kb * kb * kb / 3.0 * batch);
+    hipLaunchKernelGGL(potrf_wg_kernel, dim3(batch), dim3(512), 0, c->cur, A, lda, astride, kb, rec,
+                       rstride, info, col0);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
 // the MFMA panel solve (trsm_blk_kernel): needs the block inverses potf2f_body leaves
 // behind the 64 reciprocal pivots
 int launch_trsm_blk(bq_ctx *c, double *X, long ldx, long xstride, int m, const double *L11,

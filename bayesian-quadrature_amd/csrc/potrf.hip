@@ -5,6 +5,12 @@
 
 namespace bqh {
 
+// A batch's diagonal factors (enqueue_potrf_dfirst): one workgroup per matrix from 96 matrices on
+// -- the workgroups then cover the chip, and unlike the one-launch steps they solve nothing
+// twice --, the one-launch steps below (64 matrices would leave three quarters of the CUs without
+// a factor to work on: 366 us alone against 236).  BQ_DF_WG = 0 / 1 forces either.
+static bool dfirst_wg(const bq_ctx *c, int batch) { return c->df_wg < 0 ? batch >= 96 : c->df_wg != 0; }
+
 int auto_nb(const bq_ctx *c, int ntot, int batch)
 {
     if (c->nb_override > 0)
@@ -49,8 +55,11 @@ int auto_nb(const bq_ctx *c, int ntot, int batch)
     // 5 x 3072 2.250 / 2.272, 8 x 3072 3.069 / 2.856 with 128 / 256)
     // (re-measured at the end of round 3, 320 against 448 in one box: C3 190.4 / 187.0 ms,
     // 256 x C2 5.23 / 5.16, C5 shard 5.82 / 5.80)
+    // (round 4, diagonal block first, ms with 320 / 384 / 448 / 512 in one box: C5 shard 5.85 / 5.78 /
+    // 5.71 / 5.90 on the one-launch steps; with a workgroup per matrix 256 x C2 4.45 / 4.32 / 4.50 /
+    // 4.52, the C3 grid 188 / 178 / 190 / 180)
     if (ntot >= 1024 && mb >= 500.0)
-        return 448;
+        return (c->diag_first && dfirst_wg(c, batch)) ? 384 : 448;
     if (ntot >= 512)
         return 128;
     return 64;
@@ -408,11 +417,14 @@ static int enqueue_potrf_dfirst(bq_ctx *c, double *A, long lda, long astride, in
     const long rstride = (long)(NB / 64) * BQ_DINV_HALF;
     const bool la = c->lookahead && c->aux && c->cur == c->stream;
     auto diag = [&](int K0, int KB) {
+        if (dfirst_wg(c, batch))
+            return launch_potrf_wg(c, A + K0 + (long)K0 * lda, lda, astride, KB, rec, rstride, info,
+                                   K0, batch);
         return enqueue_slab_sweep(c, A + K0 + (long)K0 * lda, lda, astride, batch, KB, KB, rec, info,
                                   ws, K0, false, rstride);
     };
     BQCHK(diag(0, NB));
-    Sharing scope(c, la ? c->df_sharing : 0);
+    Sharing scope(c, la ? c->df_sharing : c->sharing);
     for (int K0 = 0; K0 < ncols; K0 += NB) {
         const int KB = std::min(NB, ncols - K0), r0 = K0 + KB, m2 = ntot - r0;
         if (m2 <= 0)
@@ -476,9 +488,35 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
         return fail(c, BQ_ERR_BAD_ARG, "potrf: sizes must be multiples of 64");
     const int NB = auto_nb(c, ntot, batch);
     if (dfirst_applies(c, ntot, ncols, batch) && panel_ws &&
-        panel_ws_len >= dfirst_ws_doubles(std::min(NB, ncols), batch))
+        panel_ws_len >= dfirst_ws_doubles(std::min(NB, ncols), batch)) {
+        // (df_halves: the two halves of the batch on the two streams, each in lock-step with its
+        // diagonal factors on its own stream -- one half's tails and factor chains beside the
+        // other half's launches)
+        if (c->df_halves && c->aux && c->cur == c->stream && batch >= 8) {
+            const int b0 = batch / 2, b1 = batch - b0;
+            const int nbw = std::min(NB, ncols);
+            Sharing halves(c, 2);
+            const int la_keep = c->lookahead;
+            c->lookahead = 0;
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+            c->cur = c->aux;
+            int st = enqueue_potrf_dfirst(c, A + (long)b0 * astride, lda, astride, b1, ntot, ncols,
+                                          info + b0, panel_ws + dfirst_ws_doubles(nbw, b0),
+                                          skip_border);
+            c->cur = c->stream;
+            if (st == BQ_OK)
+                st = enqueue_potrf_dfirst(c, A, lda, astride, b0, ntot, ncols, info, panel_ws,
+                                          skip_border);
+            c->lookahead = la_keep;
+            BQCHK(st);
+            HIPCHK(c, hipEventRecord(c->ev_panel, c->aux));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_panel, 0));
+            return BQ_OK;
+        }
         return enqueue_potrf_dfirst(c, A, lda, astride, batch, ntot, ncols, info, panel_ws,
                                     skip_border);
+    }
     // large systems (a look-ahead's size) in a batch that fills the chip many times over run
     // as ONE sequential group: the product is power-bound, beside it the
     // panel chain only takes clock away (C3, 100 x N = 4096: 189.8 ms with the look-ahead,

@@ -385,7 +385,7 @@ extern "C" int bq_probe_mfma_layout(bq_ctx *c, double *out256)
 // products + solves; 2: the one-launch sweep).  The factors' block-inverse records are built on
 // the device (diag_winv_kernel).
 extern "C" int bq_probe_panel_solve(bq_ctx *c, int64_t m, int64_t kb, int64_t batch, const double *L,
-                                    double *X, int mode)
+                                    double *X, int mode, int64_t reps, double *ms_per_call)
 {
     if (!c || !L || !X || m < 64 || (m & 63) || kb < 64 || (kb & 63) || batch < 1)
         return c ? fail(c, BQ_ERR_BAD_ARG, "panel_solve: m, kb multiples of 64") : BQ_ERR_BAD_ARG;
@@ -411,6 +411,18 @@ extern "C" int bq_probe_panel_solve(bq_ctx *c, int64_t m, int64_t kb, int64_t ba
         c->df_sweep = 1;
     const int st = enqueue_panel_solve(c, A.d(), lda, astride, (int)batch, (int)kb, (int)m, 0,
                                        (int)kb, rec.d(), rstride);
+    if (st == BQ_OK && reps > 0 && ms_per_call) {
+        // timing: the same call again and again on its own (now solved, still finite) output
+        float ms = 0;
+        BQCHK(bq_timer_start(c));
+        for (int64_t r = 0; r < reps; ++r)
+            (void)enqueue_panel_solve(c, A.d(), lda, astride, (int)batch, (int)kb, (int)m, 0,
+                                      (int)kb, rec.d(), rstride);
+        BQCHK(bq_timer_stop_ms(c, &ms));
+        *ms_per_call = ms / (double)reps;
+        c->df_sweep = keep;
+        return BQ_OK; // (X is not downloaded: it has been solved reps + 1 times)
+    }
     c->df_sweep = keep;
     BQCHK(st);
     for (int64_t b = 0; b < batch; ++b)

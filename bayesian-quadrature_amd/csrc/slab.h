@@ -607,3 +607,147 @@ __global__ __launch_bounds__(256) void panel_step_kernel(double *__restrict__ A,
         for (int r = 0; r < 4; ++r)
             Cout[(long)(16 * cb + 4 * r) * lds] = -acc[cb][r];
 }
+
+// ---------------------------------------------------------------------------
+// The whole kb x kb diagonal block of an outer block factored by ONE workgroup per matrix
+// (potrf.hip, enqueue_potrf_dfirst: a batch's diagonal factor D).  The one-launch steps above
+// spend a chip on it -- every tile's workgroup solves the panel rows it needs itself, 253 VGPRs,
+// hundreds of workgroups per step -- which is right for a chain that has the chip to itself and
+// wrong for one that is supposed to hide beside the previous block's trailing update: there its
+// workgroups displace the update's.  Here the factor of a matrix occupies one workgroup (eight
+// waves) from its first column to its last:
+//     per 64-column slab: the 64 x 64 factor (potf2f_body<8>, leaves its record behind);
+//     the rows below, 16 per wave-task, on the matrix cores (slab_solve16);
+//     the trailing tiles of the block, 32 x 32 per wave-task, k = 64 (all fragments requested
+//     up front), lower triangle only;
+// phases separated by workgroup barriers -- the block (1.6 MB at kb = 448) lives in L2, the same
+// CU wrote what it reads.  64 matrices = 64 workgroups; ~20 us per slab.
+// grid (batch), block 512.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wg_update32(double *__restrict__ C, long ldc,
+                                            const double *__restrict__ P,
+                                            const double *__restrict__ Q, long ldp, int row0,
+                                            int col0, int lane)
+{
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double pa[16][2], qa[16][2], cold[2][2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const double *pp = P + row0 + 16 * h + l15 + (long)l4 * ldp;
+        const double *qq = Q + col0 + 16 * h + l15 + (long)l4 * ldp;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            pa[ks][h] = pp[(long)(4 * ks) * ldp];
+            qa[ks][h] = qq[(long)(4 * ks) * ldp];
+        }
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                cold[tm][tn][rr] =
+                    C[(row0 + 16 * tm + l15) + (long)(col0 + 16 * tn + l4 + 4 * rr) * ldc];
+    __builtin_amdgcn_sched_barrier(0);
+    double4_t acc[2][2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+            acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+                acc[tm][tn] =
+                    __builtin_amdgcn_mfma_f64_16x16x4f64(qa[ks][tn], pa[ks][tm], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            if (col0 + 16 * tn >= row0 + 16 * tm + 16)
+                continue; // (wave-uniform: a 16 x 16 block above the diagonal)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                C[(row0 + 16 * tm + l15) + (long)(col0 + 16 * tn + l4 + 4 * rr) * ldc] =
+                    cold[tm][tn][rr] - acc[tm][tn][rr];
+        }
+}
+
+__global__ __launch_bounds__(512) void potrf_wg_kernel(double *__restrict__ A, long lda,
+                                                       long astride, int kb,
+                                                       double *__restrict__ rec, long rstride,
+                                                       int *__restrict__ info, int col0)
+{
+    __shared__ __attribute__((aligned(16))) double plds[BQ_POTF2_LDS_DOUBLES];
+    __builtin_amdgcn_s_setprio(3);
+    const int b = blockIdx.x;
+    A += (long)b * astride;
+    rec += (long)b * rstride;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ns = kb >> 6;
+    for (int s = 0; s < ns; ++s) {
+        double *Ass = A + 64 * s + (long)(64 * s) * lda;
+        double *rs = rec + (long)s * BQ_DINV_HALF;
+        potf2_body<8>(Ass, lda, col0 + 64 * s, rs, info + b, plds);
+        // (explicit: what this workgroup stored is in memory before its other waves read it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int nr = ns - s - 1;
+        if (nr == 0)
+            break;
+        const int r0 = 64 * (s + 1);
+        {
+            double la[4][3][4], wneg[4][4];
+            const double *L11 = Ass + l15 + (long)l4 * lda;
+            const double *W = rs + 64 + l15 + 16 * l4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    wneg[c][r] = -W[256 * c + 64 * r];
+#pragma unroll
+            for (int c = 1; c < 4; ++c)
+#pragma unroll
+                for (int bb = 0; bb < c; ++bb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        la[c][bb][r] = L11[16 * c + (long)(16 * bb + 4 * r) * lda];
+            for (int task = wave; task < 4 * nr; task += 8) {
+                double *Xr = A + r0 + 16 * task + l15 + (long)(64 * s + l4) * lda;
+                double t[4][4];
+                double4_t x[4];
+                slab_load16(Xr, lda, t);
+                slab_solve16(t, la, wneg, x);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Xr[(long)(16 * c + 4 * r) * lda] = x[c][r];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        {
+            const double *Pn = A + r0 + (long)(64 * s) * lda; // the solved panel, rows from r0
+            double *Cn = A + r0 + (long)r0 * lda;
+            const int ntask = 4 * (nr * (nr + 1) / 2);
+            for (int task = wave; task < ntask; task += 8) {
+                int ti, tj;
+                tri_decode(task >> 2, ti, tj);
+                const int q = task & 3;
+                const int row0 = 64 * ti + 32 * (q & 1), cl0 = 64 * tj + 32 * (q >> 1);
+                if (cl0 > row0)
+                    continue; // the upper 32 x 32 block of a diagonal tile
+                wg_update32(Cn, lda, Pn, Pn, lda, row0, cl0, lane);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}

@@ -16,23 +16,34 @@
 // One launch per outer block instead of a chain of ~13 products and solves, one read and one
 // write of the panel from HBM instead of ~30 slab passes.  36 KiB of LDS, <= 128 VGPRs: four
 // workgroups per CU hide each other's slab boundaries.
-// grid (m / 64, 1, batch), block 256; m a multiple of 64, kb of 64.
+// Placement: every workgroup of a matrix re-reads the same rows of L11 (Q), slab by slab and at
+// about the same time; dealt over the chip as they come (consecutive workgroup ids go round-robin
+// over the eight XCDs) each XCD fetches every matrix's L11 for itself and the launch is bound by
+// the fabric (4 TB/s measured into LDS).  The 1-D grid is therefore cut by XCD: workgroup id w runs
+// on XCD w % 8 (observed dispatch, speed only) and takes row block (w / 8) % nrb of matrix
+// w % 8 + 8 ((w / 8) / nrb) -- a matrix's row blocks share one L2.
+// grid (8 nrb ceil(batch / 8)), block 256; m a multiple of 64, kb of 64.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 4) void trsm_sweep_kernel(double *__restrict__ X, long ldx,
                                                             long xstride,
                                                             const double *__restrict__ L11, long ldl,
                                                             long lstride,
                                                             const double *__restrict__ rec,
-                                                            long rstride, int kb)
+                                                            long rstride, int kb, int nrb,
+                                                            int batch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.z;
+    const int slot = blockIdx.x >> 3;
+    const int b = (int)(blockIdx.x & 7) + 8 * (slot / nrb);
+    if (b >= batch)
+        return; // (the whole workgroup, before any barrier)
+    const int rb = slot % nrb;
     X += (long)b * xstride;
     L11 += (long)b * lstride;
     rec += (long)b * rstride;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int R0 = blockIdx.x * 64;
+    const int R0 = rb * 64;
     const int wr = (wave & 1) * 32, wc = (wave >> 1) * 32;
     const int l15 = lane & 15, l4 = lane >> 4;
 

@@ -420,7 +420,7 @@ class Engine(object):
                                             C.cast(C.byref(v), _dp)))
         return float(v.value)
 
-    def probe_panel_solve(self, Lfac, X, mode=0):
+    def probe_panel_solve(self, Lfac, X, mode=0, reps=0):
         """X L^-T for a batch of lower-triangular kb x kb factors L (batch, kb, kb) and row blocks
         X (batch, m, kb) through the batched factorisation's panel-solve launches."""
         L_ = np.asarray(Lfac, dtype=np.float64)
@@ -430,8 +430,12 @@ class Engine(object):
         # column-major per problem
         Lf = np.ascontiguousarray(np.transpose(L_, (0, 2, 1)))
         Xf = np.ascontiguousarray(np.transpose(X_, (0, 2, 1)))
+        ms = C.c_double()
         self._check(self._lib.bq_probe_panel_solve(self._ctx, int(m), int(kb), int(batch),
-                                                   L.dptr(Lf), L.dptr(Xf), int(mode)))
+                                                   L.dptr(Lf), L.dptr(Xf), int(mode), int(reps),
+                                                   C.cast(C.byref(ms), _dp)))
+        if reps > 0:
+            return float(ms.value)  # ms per call
         return np.transpose(Xf, (0, 2, 1)).copy()
 
     def probe_launch(self, n=2000):

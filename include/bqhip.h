@@ -334,9 +334,11 @@ int bq_probe_potf2(bq_ctx *ctx, const double *A, int from_lds, int64_t reps, dou
 /* The batched panel solve of one outer block alone (potrf.hip, enqueue_panel_solve): X (m x kb per
  * problem, column-major, in / out) <- X L^-T against `batch` dense lower-triangular kb x kb
  * factors L; mode 0: as the context is configured, 1: recursive products + 64-column solves,
- * 2: the one-launch sweep (trsm_sweep_kernel).  m, kb multiples of 64. */
+ * 2: the one-launch sweep (trsm_sweep_kernel).  m, kb multiples of 64.  reps > 0: the call is
+ * repeated reps times on its own output and timed (HIP events, ms per call); X is then not
+ * written back. */
 int bq_probe_panel_solve(bq_ctx *ctx, int64_t m, int64_t kb, int64_t batch, const double *L,
-                         double *X, int mode);
+                         double *X, int mode, int64_t reps, double *ms_per_call);
 /* dump of the f64 MFMA D-register layout: out[64*4] receives, for lane l and
  * register r, the value row*16+col of the D element it holds */
 int bq_probe_mfma_layout(bq_ctx *ctx, double *out256);
