@@ -56,3 +56,22 @@ def test_null_context_is_rejected():
     lib = _lib.load_library()
     assert lib.bq_ctx_sync(None) == _lib.BQ_ERR_BAD_ARG
     assert lib.bq_set_block(None, 64) == _lib.BQ_ERR_BAD_ARG
+
+
+def test_lds_dma_fills_are_waited_for_before_barriers(tmp_path):
+    """hipcc orders an LDS-DMA (global_load_lds) only against the issuing wave's own LDS reads: the
+    `s_waitcnt vmcnt(0)` the OTHER waves of the workgroup rely on before the barrier is there by
+    explicit asm or by luck.  tools/check_ldsdma_waits.py walks the control-flow graph of every
+    LDS-DMA kernel in the gfx950 ISA of k_gemm.hip and finds no barrier reachable with a fill in
+    flight (round 4: the loop header of trsm_sweep_kernel was one)."""
+    import subprocess
+    import sys
+    src = os.path.join(ROOT, "bayesian-quadrature_amd", "csrc", "k_gemm.hip")
+    out = tmp_path / "k_gemm-hip-amdgcn-amd-amdhsa-gfx950.s"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950",
+                           "-fno-fast-math", "--cuda-device-only", "-S", src, "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_ldsdma_waits.py"),
+                        str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "trsm_sweep_kernel" in r.stdout and "gemm_lds_kernel" in r.stdout

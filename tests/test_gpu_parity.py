@@ -1313,3 +1313,96 @@ def test_pair_esm_vs_per_set_route(engine, oracle, ns, nc, S, M):
             assert np.abs(r["A_a"][b] - ref[0]).max() <= tol * scale
             assert np.abs(r["A_sc_l"][b] - ref[1]).max() <= tol * scale
     pair.close()
+
+
+# ---- the batched factorisation, diagonal block first (round 4) --------------------
+@pytest.mark.parametrize("m,kb,batch", [(64, 64, 1), (128, 192, 2), (256, 448, 3), (1472, 448, 4),
+                                        (3712, 448, 2), (320, 256, 9)])
+def test_panel_solve_vs_lapack(engine, m, kb, batch):
+    """The batched panel solve X <- X L^-T of one outer block (potrf.hip, enqueue_panel_solve) on
+    DENSE random factors against LAPACK's dtrtrs, slab by slab: the recursive products + solves
+    (gemm_trsm64_kernel) and the one-launch sweep (trsm_sweep_kernel).  The 1-D sorted inputs of
+    C2 / C5 give banded matrices whose panels are zeros below the band -- a product over them
+    tests nothing, which is how a missing LDS-DMA wait passed every config test but C3's."""
+    import scipy.linalg as sla
+    rs = np.random.RandomState(m + kb)
+    Ls, Xs, refs = [], [], []
+    for _ in range(batch):
+        G = rs.standard_normal((kb, kb))
+        Lf = np.linalg.cholesky(G @ G.T + kb * np.eye(kb))
+        X = rs.standard_normal((m, kb))
+        Ls.append(Lf)
+        Xs.append(X)
+        refs.append(sla.solve_triangular(Lf, X.T, lower=True).T)
+    Ls, Xs, refs = np.array(Ls), np.array(Xs), np.array(refs)
+    for mode in (1, 2):
+        out = engine.probe_panel_solve(Ls, Xs, mode)
+        for s in range(kb // 64):
+            err = relmax(out[:, :, 64 * s:64 * s + 64], refs[:, :, 64 * s:64 * s + 64],
+                         scale=np.max(np.abs(refs)))
+            assert err < 1e-13, (mode, s, err)
+        # and twice the same bits
+        assert np.array_equal(out, engine.probe_panel_solve(Ls, Xs, mode))
+
+
+def _dense_batch(batch, n, m, d=2, seed=11):
+    rs = np.random.RandomState(seed)
+    x = rs.uniform(-3, 3, (batch, d, n))
+    xo = rs.uniform(-3, 3, (batch, d, m))
+    y = wl.norm_logpdf(x[:, 0]) + wl.norm_logpdf(x[:, 1])
+    return x, y, xo, 1.3, np.full(d, 6.0 / np.sqrt(n) * 1.5), 0.05
+
+
+@pytest.mark.parametrize("batch,n,m", [(12, 1100, 70), (100, 700, 40)])
+def test_batch_dense_vs_oracle_and_variants(engine, oracle, batch, n, m):
+    """A batch of DENSE 2-D problems (outer block 128: diagonal block first -- a workgroup per
+    matrix from 96 matrices on, the one-launch steps below) against the oracle, and every switch of
+    the batched sweep against the default on the same inputs: the recursive panels of rounds 1-3
+    (BQ_DIAG_FIRST=0), either form of the diagonal factor, the recursive panel solve, two
+    half-batches."""
+    import os
+    from bayesian_quadrature_amd import Engine
+    x, y, xo, h, w, s = _dense_batch(batch, n, m)
+    mean, var, logml, status = engine.batch_fit_predict(x, y, h, w, s, xo)
+    assert (status == 0).all()
+    for i in (0, batch // 2, batch - 1):
+        Lo, ao, lmo = oracle.gp_fit(x[i], y[i], h, w, s)
+        mo, vo = oracle.gp_predict(x[i], h, w, Lo, ao, xo[i])
+        assert relmax(mean[i], mo) < RTOL
+        assert relmax(var[i], vo, scale=oracle.kernel_scale(2, h, w)) < RTOL
+        assert abs(logml[i] - lmo) <= RTOL * abs(lmo)
+    for env in ({"BQ_DIAG_FIRST": "0"}, {"BQ_DF_WG": "0"}, {"BQ_DF_WG": "1"}, {"BQ_DF_SWEEP": "0"},
+                {"BQ_DF_HALVES": "1"}, {"BQ_LOOKAHEAD": "0"}):
+        os.environ.update(env)
+        try:
+            e2 = Engine(0)
+        finally:
+            for k in env:
+                del os.environ[k]
+        try:
+            m2, v2, l2, st2 = e2.batch_fit_predict(x, y, h, w, s, xo)
+        finally:
+            e2.close()
+        assert (st2 == 0).all(), env
+        assert relmax(m2, mean) < 1e-12 and relmax(l2, logml) < 1e-12, env
+        assert relmax(v2, var, scale=oracle.kernel_scale(2, h, w)) < 1e-12, env
+
+
+def test_batch_diag_first_reports_not_pd(engine):
+    """A hopeless matrix in the batch (length scale far beyond the spacing, no noise: not positive
+    definite in fp64) is reported with a non-zero status, its neighbours are untouched."""
+    x, y, xo, h, w, s = _dense_batch(10, 900, 16)
+    plan = engine.plan(10, 2, 900, 16)
+    ww = np.tile(w[None], (10, 1))
+    ww[4] = 5.0
+    ss = np.full(10, s)
+    ss[4] = 0.0
+    plan.set_inputs(x, y, xo, h, ww, ss)
+    plan.run()
+    mean, var, logml, status = plan.results()
+    plan.close()
+    assert status[4] != 0 and (np.delete(status, 4) == 0).all()
+    assert np.isfinite(np.delete(logml, 4)).all()
+    m1, v1, l1, st1 = engine.batch_fit_predict(np.delete(x, 4, 0), np.delete(y, 4, 0), h, w, s,
+                                               np.delete(xo, 4, 0))
+    assert relmax(np.delete(mean, 4, 0), m1) < 1e-12 and relmax(np.delete(logml, 4), l1) < 1e-12
