@@ -10,6 +10,11 @@ int prof_collect(bq_ctx *c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->aux)
         HIPCHK(c, hipStreamSynchronize(c->aux));
+    // the timeline's origin: the start of the first launch bracketed since the recording was
+    // armed -- kept across drains (profile_read / _reset / _enable in between), so every row
+    // is measured against the same instant
+    if (c->prof_keep_timeline && !c->prof_origin)
+        c->prof_origin = c->prof_events.front().a;
     for (auto &e : c->prof_events) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
@@ -18,15 +23,16 @@ int prof_collect(bq_ctx *c)
             c->prof_work[e.cls] += e.work;
             if (c->prof_keep_timeline) {
                 float t0 = 0.f;
-                (void)hipEventElapsedTime(&t0, c->prof_events.front().a, e.a);
+                (void)hipEventElapsedTime(&t0, c->prof_origin, e.a);
                 c->prof_timeline.insert(c->prof_timeline.end(),
                                         {(double)e.cls, (double)e.on_aux, (double)t0,
                                          (double)t0 + ms, e.work});
             }
         }
     }
-    for (auto &e : c->prof_events) { // (the first launch's start is the timeline's origin)
-        (void)hipEventDestroy(e.a);
+    for (auto &e : c->prof_events) {
+        if (e.a != c->prof_origin)
+            (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
     c->prof_events.clear();
@@ -102,6 +108,8 @@ static int ctx_init(bq_ctx *c, int device)
         c->df_sweep = std::atoi(e);
     if (const char *e = std::getenv("BQ_DF_WG"))
         c->df_wg = std::atoi(e);
+    if (const char *e = std::getenv("BQ_PAIR_BORDER"))
+        c->pair_border = std::atoi(e);
     if (const char *e = std::getenv("BQ_DF_HALVES"))
         c->df_halves = std::atoi(e);
     if (const char *e = std::getenv("BQ_DF_SHARING"))
@@ -185,9 +193,12 @@ extern "C" void bq_ctx_destroy(bq_ctx *c)
         c->plan_cache = nullptr;
     }
     for (auto &e : c->prof_events) {
-        (void)hipEventDestroy(e.a);
+        if (e.a != c->prof_origin)
+            (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
+    if (c->prof_origin)
+        (void)hipEventDestroy(c->prof_origin);
     if (c->t0)
         (void)hipEventDestroy(c->t0);
     if (c->t1)
@@ -222,7 +233,8 @@ extern "C" int bq_device_info(bq_ctx *c, char *name, int *cus, size_t *hbm_bytes
     hipDeviceProp_t prop;
     HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
     if (name) {
-        std::snprintf(name, 64, "%s (%s)", prop.name, prop.gcnArchName);
+        // (on the GPU box the marketing name comes back empty: say what is known)
+        std::snprintf(name, 64, "%s (%s)", prop.name[0] ? prop.name : "AMD GPU", prop.gcnArchName);
     }
     if (cus)
         *cus = prop.multiProcessorCount;
@@ -246,6 +258,19 @@ extern "C" int bq_set_lookahead(bq_ctx *c, int on)
     if (!c)
         return BQ_ERR_BAD_ARG;
     c->lookahead = on ? 1 : 0;
+    return BQ_OK;
+}
+
+extern "C" int bq_get_config(bq_ctx *c, int *nb, int *lookahead, int *min_rows)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    if (nb)
+        *nb = c->nb_override;
+    if (lookahead)
+        *lookahead = c->lookahead;
+    if (min_rows)
+        *min_rows = c->la_min;
     return BQ_OK;
 }
 
@@ -362,6 +387,12 @@ extern "C" int bq_profile_timeline(bq_ctx *c, int keep, double *out, int64_t max
     if (!c)
         return BQ_ERR_BAD_ARG;
     BQCHK(prof_collect(c));
+    if ((keep && !out) || !keep) {
+        // (re)armed or stopped: the next recording starts from its own first launch
+        if (c->prof_origin)
+            (void)hipEventDestroy(c->prof_origin);
+        c->prof_origin = nullptr;
+    }
     if (keep && !out)
         c->prof_timeline.clear();
     const int64_t n = (int64_t)c->prof_timeline.size() / 5;

@@ -89,10 +89,11 @@ struct bq_ctx {
     int df_sweep = 1;    // the panel solve of an outer block in one launch (trsm_sweep_kernel; BQ_DF_SWEEP)
     int df_wg = -1;      // a batch's diagonal factor by one workgroup per matrix (potrf_wg_kernel): -1 by
                          // batch size (potrf.hip, dfirst_wg), 0 / 1 forced (BQ_DF_WG)
+    int pair_border = 1; // bq_pair_esm as S factorisations + border rows (BQ_PAIR_BORDER=0: the S Ma
+                         // full bordered systems)
     int df_halves = 0;   // the diagonal-first sweep as two half-batches on the two streams (BQ_DF_HALVES)
     int df_sharing = 0;  // gemm_lds_tile's sharing mode while a diagonal factor runs beside an update
                          // (0: the rule of a product alone -- C5 shard 5.73 ms against 6.05 with 1)
-    int cfg_epoch = 0;   // bumped by every setter that changes a launch sequence (graph keys)
     int la_min = 3072;   // look-ahead only while the bulk update has at least this many rows (BQ_LA_MIN)
     DevBuf panel_ws;     // scratch panel columns of the eager linalg entry points
     DevBuf scratch;      // per-call temporaries of the acquisition / moment entry points, kept
@@ -163,6 +164,21 @@ inline int fail(bq_ctx *c, int code, const char *fmt, ...)
     } while (0)
 
 inline long roundup(long v, long q) { return (v + q - 1) / q * q; }
+
+// Every context field that decides which launches a sweep is made of, hashed: a captured
+// hipGraph (plans, the pair's objective) is replayed only while this is what it was captured
+// under -- whichever setter, environment switch or probe changed a field.
+inline unsigned long long launch_config_key(const bq_ctx *c)
+{
+    const int f[] = {c->nb_override, c->lookahead, c->split_batch, c->la_min, c->gemm_lds,
+                     c->gemm_lds64, c->slab_nb_max, c->slab_max, c->fold_readout, c->potf2_8w,
+                     c->gemm_ksplit, c->gemm_tile, c->diag_first, c->df_sweep, c->df_wg,
+                     c->df_halves, c->df_sharing};
+    unsigned long long h = 1469598103934665603ull;
+    for (int v : f)
+        h = (h ^ (unsigned long long)(unsigned)v) * 1099511628211ull;
+    return h;
+}
 
 // leading dimension for an ntot x ntot column-major matrix: even, and nudged
 // off large powers of two so that the 4 columns of an MFMA fragment do not
@@ -401,7 +417,7 @@ struct bq_plan {
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     int graph_state = 0; // 0 = not tried, 1 = ready, -1 = unavailable (eager launches)
-    int graph_nb = 0, graph_la = 0, graph_pw = 0;
+    unsigned long long graph_key = 0; // launch_config_key the graph was captured under
     double *hres = nullptr; // pinned staging of bq_plan_results: [scal 4 nb | info nb | mean | var]
     ~bq_plan()
     {

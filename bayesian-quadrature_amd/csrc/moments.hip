@@ -534,9 +534,7 @@ extern "C" int bq_esm_batch(bq_ctx *c, const double *x_sc, const double *l_sc, i
     HIPCHK(c, dj2.alloc(sizeof(double) * M));
     HIPCHK(c, Ad.alloc(sizeof(double) * (size_t)lda * L.ntot * (size_t)chunk));
     HIPCHK(c, dinv.alloc(sizeof(double) * BQ_DINV_STRIDE * (size_t)chunk));
-    HIPCHK(c, panel.alloc(panel_ws_useful(c, L.ntot, (int)chunk)
-                              ? sizeof(double) * panel_ws_doubles(L.ntot, (int)chunk)
-                              : 0));
+    HIPCHK(c, panel.alloc(sizeof(double) * sweep_ws_doubles(c, L.ntot, (int)chunk)));
     HIPCHK(c, info.alloc(sizeof(int) * (size_t)chunk));
     HIPCHK(c, outd.alloc(sizeof(double) * 2 * (size_t)chunk));
     HIPCHK(c, hipMemcpyAsync(xs.p, x_sc, sizeof(double) * nsc, hipMemcpyHostToDevice, c->stream));

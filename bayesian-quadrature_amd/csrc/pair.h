@@ -149,3 +149,130 @@ __global__ void esm_multi_finalize_kernel(const double *__restrict__ A, long lda
     out[2 * b] = z_last / l_last;
     out[2 * b + 1] = -Ab[(L.npad + 1) + (long)L.npad * lda];
 }
+
+
+// ---------------------------------------------------------------------------
+// The acquisition under S parameter sets as S factorisations + border rows (round 4).  The
+// S x Ma bordered systems above differ, within a set, only in their LAST rows: the candidate
+// x_a, the jitter on the candidate points near it and the two border rows.  With the cut at
+// p = 64 floor(ns / 64) <= ns (no jitter above it) the first p columns of all Ma systems of a set
+// are eliminated ONCE, with every candidate's row k_a carried along as a border row:
+//   index   [0, nsc)          the points x_sc (the first p of them are eliminated)
+//           [nsc, nsc + Ma)   the candidates x_a (rows only)
+//           nsc + Ma          the row of int K p (over x_sc, then over the candidates)
+//           nsc + Ma + 1      the row of l_sc
+//           ...               identity padding up to ntot = p + 64 ceil((nsc - p + Ma + 2) / 64)
+// (assemble_esmb_kernel; the sweep keeps the whole trailing block up to date).  The trailing block
+// is then the Schur complement every candidate's small system starts from: esmb_gather_kernel
+// cuts the (nsc - p + 1)-point system of element (set, candidate) out of it -- its points, ITS
+// candidate row, the two border rows -- and adds the reference's jitter; a batch of S Ma systems
+// of 128 or 192 rows finishes the elimination (the one-launch steps).  1/Ma of the flops.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void assemble_esmb_kernel(
+    const double *__restrict__ x_sc, const double *__restrict__ x_a, int Ma, long s0,
+    const double *__restrict__ intk_sc, const double *__restrict__ intk_a,
+    const double *__restrict__ l_sc, long lstride, const GaussParams *__restrict__ gp,
+    double *__restrict__ A, long lda, long astride, int nsc, int ntot)
+{
+    const int b = blockIdx.z;
+    const long s = s0 + b;
+    const int t = threadIdx.x;
+    const int ib = blockIdx.x * 128, jb = blockIdx.y * 64;
+    if (jb > ib + 127)
+        return;
+    A += (long)b * astride;
+    const GaussParams g = gp[s];
+    const double *ik = intk_sc + s * nsc;
+    const double *ika = intk_a + s * Ma;
+    const double *lv = l_sc + s * lstride;
+    const int npts = nsc + Ma, rb = npts, rl = npts + 1;
+    const int i = ib + (t & 63) * 2;
+    const int jbase = jb + (t >> 6) * 16;
+    if (i >= ntot)
+        return;
+    double xi[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int ii = i + r;
+        xi[r] = ii < nsc ? x_sc[ii] : (ii < npts ? x_a[ii - nsc] : 0.0);
+    }
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = jbase + jj;
+        if (j >= ntot)
+            break;
+        const double xj = j < nsc ? x_sc[j] : (j < npts ? x_a[j - nsc] : 0.0);
+        double v[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int ii = i + r;
+            double val;
+            if (ii < npts && j < npts) {
+                const double tdiff = xi[r] - xj;
+                val = g.c * exp_gauss((tdiff * tdiff) * g.nh[0]);
+            } else if (ii == rb) {
+                val = j < nsc ? ik[j] : (j < npts ? ika[j - nsc] : 0.0);
+            } else if (ii == rl) {
+                val = j < nsc ? lv[j] : 0.0;
+            } else {
+                val = (ii == j) ? 1.0 : 0.0;
+            }
+            v[r] = val;
+        }
+        double2_t vv = {v[0], v[1]};
+        *reinterpret_cast<double2_t *>(A + i + (long)j * lda) = vv;
+    }
+}
+
+// element e = e0 + blockIdx.z = (set s - s0, candidate a): its small system from the trailing
+// block T = A[p.., p..] of set s.  Small layout (EsmLayout Ls): points [0, nt0) = x_sc[p ..),
+// nt0 = the candidate; rows Ls.npad / Ls.npad + 1 = the int K p / l_sc rows; identity padding.
+// grid (ceil(ntot_s / 64), ntot_s / 64, elements), block 256: thread t -> row (t & 63), 16 columns.
+__global__ __launch_bounds__(256) void esmb_gather_kernel(
+    const double *__restrict__ A, long lda, long astride, int p, int nsc, int Ma, int ns,
+    const double *__restrict__ x_sc, const double *__restrict__ x_a,
+    const double *__restrict__ jit1, const double *__restrict__ jit2, double thresh, long s0,
+    long e0, double *__restrict__ As, long ldas, long asstride, EsmLayout Ls)
+{
+    const long e = e0 + blockIdx.z;
+    const int sl = (int)(e / Ma - s0), a = (int)(e % Ma);
+    const double *T = A + (long)sl * astride;
+    double *O = As + (long)blockIdx.z * asstride;
+    const int nt0 = Ls.nsc; // trailing points of the big system = points of the small one - 1
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j0 = blockIdx.y * 64 + (threadIdx.x >> 6) * 16;
+    if (i >= Ls.ntot)
+        return;
+    // the big system's index of small row i (-1: padding)
+    auto big = [&](int q) {
+        if (q < nt0)
+            return p + q;
+        if (q == nt0)
+            return nsc + a;
+        if (q == Ls.npad)
+            return nsc + Ma;
+        if (q == Ls.npad + 1)
+            return nsc + Ma + 1;
+        return -1;
+    };
+    const int bi = big(i);
+    const double xa = x_a[a];
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = j0 + jj;
+        if (j >= Ls.ntot)
+            break;
+        const int bj = big(j);
+        double val;
+        if (j > i) {
+            val = 0.0; // (the upper triangle is never read)
+        } else if (bi >= 0 && bj >= 0) {
+            val = T[bi + (long)bj * lda]; // (big() is increasing: bi >= bj, the lower triangle)
+            if (i == j && i == nt0)
+                val += jit2[e];
+            else if (i == j && i < nt0 && p + i >= ns && fabs(x_sc[p + i] - xa) < thresh)
+                val += jit1[e];
+        } else {
+            val = (i == j) ? 1.0 : 0.0;
+        }
+        O[i + (long)j * ldas] = val;
+    }
+}

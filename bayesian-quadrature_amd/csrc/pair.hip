@@ -31,12 +31,16 @@ struct bq_pair {
     hipGraph_t lgraph = nullptr;
     hipGraphExec_t lgexec = nullptr;
     int lgraph_state = 0; // 0 = not tried, 1 = ready, -1 = unavailable (eager launches)
-    int lgraph_key = 0;
+    unsigned long long lgraph_key = 0;
     DevBuf l_s, x_sc, x_a, y2, flag;
     // stage 2 of bq_pair_esm, kept between calls (choose_next calls it once per step with the
     // same shapes; allocating and releasing its tens of GB per call costs more than the pass)
     DevBuf gpd, pard, ik, ika, dj1, dj2, Ad, dinv, info, outd, panel;
     int64_t chunk = 0;
+    bool esm_small = false; // gpd .. dj2 are allocated
+    // the border route (S factorisations + border rows): the sets' systems, the S Ma small ones
+    DevBuf bA, bdinv, binfo, bws, sA, sdinv, sinfo, sws, sout;
+    int64_t bchunk = 0; // parameter sets per pass
     std::vector<double> hx_s, hx_c, hx_a;
     // bq_pair_llh runs hundreds of times per optimisation / chain on tiny systems, where the
     // host's share of a pass matters: parameters go up from PINNED staging (asynchronous for
@@ -277,8 +281,7 @@ extern "C" int bq_pair_llh(bq_ctx *c, bq_pair *pr, const double *p_tl, const dou
     }
     // one graph launch per pass where graphs are in use (the pass of a small system is a dozen
     // stream operations of a few microseconds each)
-    const int key = c->nb_override * 64 + c->lookahead * 32 + c->split_batch * 16 +
-                    c->gemm_lds64 * 8 + c->gemm_lds * 4 + c->potf2_8w * 2 + c->fold_readout;
+    const unsigned long long key = launch_config_key(c);
     if (pr->lgraph_state == 1 && pr->lgraph_key != key) {
         (void)hipGraphExecDestroy(pr->lgexec);
         (void)hipGraphDestroy(pr->lgraph);
@@ -320,6 +323,105 @@ extern "C" int bq_pair_llh(bq_ctx *c, bq_pair *pr, const double *p_tl, const dou
         if (l_c)
             for (int i = 0; i < nc; ++i)
                 l_c[(size_t)b * nc + i] = r[5 + i];
+    }
+    return BQ_OK;
+}
+
+// bq_pair_esm's stage 2 as S factorisations + border rows (pair.h has the picture): the sets'
+// parameters, int K p, jitters and GP2's targets are on the device (pr->gpd, ik, ika, dj1, dj2, y2)
+static int pair_esm_border(bq_ctx *c, bq_pair *pr, int p, double thresh, double *A_a,
+                           double *A_sc_l, int32_t *status)
+{
+    const int S = pr->S, ns = pr->ns, nsc = pr->nsc, ma = pr->ma;
+    const int nt0 = nsc - p;
+    const int ntot = p + (int)roundup(nt0 + ma + 2, 64);
+    const long lda = pick_ld(ntot), astride = lda * (long)ntot;
+    EsmLayout Ls;
+    Ls.ns = 0;
+    Ls.nsc = nt0;
+    Ls.npad = (int)roundup(nt0 + 1, 64);
+    Ls.ntot = Ls.npad + 64;
+    const long ldas = Ls.ntot, asstride = ldas * (long)Ls.ntot;
+    if (pr->bchunk == 0) {
+        size_t freeb = 0, totalb = 0;
+        HIPCHK(c, hipMemGetInfo(&freeb, &totalb));
+        const size_t per = sizeof(double) * ((size_t)astride + (size_t)ma * asstride) * 2;
+        // (the small systems are a batch in blockIdx.z: at most 65535 of them per pass)
+        const int64_t sch = std::min<int64_t>(
+            std::min<int64_t>(S, std::max<int64_t>(1, 65535 / ma)),
+            std::max<int64_t>(1, (int64_t)(std::min<size_t>(freeb / 2, (size_t)8 << 30) / per)));
+        const int64_t ech = sch * ma;
+        hipError_t e = pr->bA.alloc(sizeof(double) * (size_t)astride * sch);
+        auto A = [&](DevBuf &b, size_t bytes) {
+            if (e == hipSuccess)
+                e = b.alloc(bytes);
+        };
+        A(pr->bdinv, sizeof(double) * BQ_DINV_STRIDE * (size_t)sch);
+        A(pr->binfo, sizeof(int) * (size_t)sch);
+        A(pr->bws, sizeof(double) * sweep_ws_doubles(c, ntot, (int)sch));
+        A(pr->sA, sizeof(double) * (size_t)asstride * ech);
+        A(pr->sdinv, sizeof(double) * BQ_DINV_STRIDE * (size_t)ech);
+        A(pr->sinfo, sizeof(int) * (size_t)ech);
+        A(pr->sws, sizeof(double) * sweep_ws_doubles(c, Ls.ntot, (int)ech));
+        A(pr->sout, sizeof(double) * 2 * (size_t)ech);
+        if (e != hipSuccess) {
+            for (DevBuf *b : {&pr->bA, &pr->bdinv, &pr->binfo, &pr->bws, &pr->sA, &pr->sdinv,
+                              &pr->sinfo, &pr->sws, &pr->sout})
+                b->release();
+            return fail(c, e == hipErrorOutOfMemory ? BQ_ERR_NOMEM : BQ_ERR_HIP,
+                        "pair_esm: workspace allocation failed: %s", hipGetErrorString(e));
+        }
+        pr->bchunk = sch;
+    }
+    const int64_t sch = pr->bchunk;
+    std::vector<double> hout((size_t)sch * ma * 2);
+    std::vector<int> hsi((size_t)sch * ma), hbi((size_t)sch);
+    for (int64_t s0 = 0; s0 < S; s0 += sch) {
+        const int nb = (int)std::min<int64_t>(sch, S - s0), ne = nb * ma;
+        HIPCHK(c, hipMemsetAsync(pr->binfo.p, 0, sizeof(int) * nb, c->stream));
+        HIPCHK(c, hipMemsetAsync(pr->sinfo.p, 0, sizeof(int) * ne, c->stream));
+        {
+            Bracket br(c, BQ_K_GRAM, 8.0 * ntot * (ntot + 1.0) / 2.0 * nb);
+            hipLaunchKernelGGL(assemble_esmb_kernel, dim3((ntot + 127) / 128, (ntot + 63) / 64, nb),
+                               dim3(256), 0, c->stream, pr->x_sc.d(), pr->x_a.d(), ma, (long)s0,
+                               pr->ik.d(), pr->ika.d(), pr->y2.d(), (long)nsc,
+                               static_cast<const GaussParams *>(pr->gpd.p), pr->bA.d(), lda, astride,
+                               nsc, ntot);
+            HIPCHK(c, hipGetLastError());
+        }
+        // the first p columns of every set, the whole trailing block kept up to date
+        BQCHK(enqueue_potrf_partial(c, pr->bA.d(), lda, astride, nb, ntot, p, pr->bdinv.d(),
+                                    pr->binfo.i(), pr->bws.d(), pr->bws.bytes / sizeof(double)));
+        {
+            Bracket br(c, BQ_K_GRAM, 8.0 * Ls.ntot * Ls.ntot * ne);
+            hipLaunchKernelGGL(esmb_gather_kernel, dim3((Ls.ntot + 63) / 64, Ls.ntot / 64, ne),
+                               dim3(256), 0, c->stream, pr->bA.d(), lda, astride, p, nsc, ma, ns,
+                               pr->x_sc.d(), pr->x_a.d(), pr->dj1.d(), pr->dj2.d(), thresh,
+                               (long)s0, (long)s0 * ma, pr->sA.d(), ldas, asstride, Ls);
+            HIPCHK(c, hipGetLastError());
+        }
+        BQCHK(enqueue_potrf_partial(c, pr->sA.d(), ldas, asstride, ne, Ls.ntot, Ls.npad,
+                                    pr->sdinv.d(), pr->sinfo.i(), pr->sws.d(),
+                                    pr->sws.bytes / sizeof(double)));
+        hipLaunchKernelGGL(esm_multi_finalize_kernel, dim3((ne + 255) / 256), dim3(256), 0,
+                           c->stream, pr->sA.d(), ldas, asstride, Ls, ne, pr->sout.d());
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(hout.data(), pr->sout.p, sizeof(double) * 2 * ne,
+                                 hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hsi.data(), pr->sinfo.p, sizeof(int) * ne, hipMemcpyDeviceToHost,
+                                 c->stream));
+        HIPCHK(c, hipMemcpyAsync(hbi.data(), pr->binfo.p, sizeof(int) * nb, hipMemcpyDeviceToHost,
+                                 c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int k = 0; k < ne; ++k) {
+            const int64_t e = s0 * ma + k;
+            A_a[e] = hout[(size_t)2 * k];
+            A_sc_l[e] = hout[(size_t)2 * k + 1];
+            // (a failure in the common leading block is every candidate's; the small system's
+            // column counts on from the cut)
+            const int lead = hbi[(size_t)(k / ma)];
+            status[e] = lead ? lead : (hsi[(size_t)k] ? p + hsi[(size_t)k] : 0);
+        }
     }
     return BQ_OK;
 }
@@ -376,27 +478,46 @@ extern "C" int bq_pair_esm(bq_ctx *c, bq_pair *pr, const double *p_tl, const dou
     const int64_t E = (int64_t)S * ma;
     const size_t per = sizeof(double) * ((size_t)lda * L.ntot + panel_ws_doubles(L.ntot, 1) +
                                          BQ_DINV_STRIDE + 2) + sizeof(int);
-    if (pr->chunk == 0) {
-        size_t freeb = 0, totalb = 0;
-        HIPCHK(c, hipMemGetInfo(&freeb, &totalb));
-        int64_t ch = std::max<int64_t>(1, (int64_t)((freeb / 2) / per));
-        ch = std::min<int64_t>(std::min<int64_t>(ch, E), 32768);
+    if (!pr->esm_small) {
         HIPCHK(c, pr->gpd.alloc(sizeof(GaussParams) * S));
         HIPCHK(c, pr->pard.alloc(sizeof(double) * 3 * S));
         HIPCHK(c, pr->ik.alloc(sizeof(double) * (size_t)S * nsc));
         HIPCHK(c, pr->ika.alloc(sizeof(double) * (size_t)E));
         HIPCHK(c, pr->dj1.alloc(sizeof(double) * (size_t)E));
         HIPCHK(c, pr->dj2.alloc(sizeof(double) * (size_t)E));
-        HIPCHK(c, pr->Ad.alloc(sizeof(double) * (size_t)lda * L.ntot * (size_t)ch));
-        HIPCHK(c, pr->dinv.alloc(sizeof(double) * BQ_DINV_STRIDE * (size_t)ch));
-        HIPCHK(c, pr->panel.alloc(panel_ws_useful(c, L.ntot, (int)ch)
-                                      ? sizeof(double) * panel_ws_doubles(L.ntot, (int)ch)
-                                      : 0));
-        HIPCHK(c, pr->info.alloc(sizeof(int) * (size_t)ch));
-        HIPCHK(c, pr->outd.alloc(sizeof(double) * 2 * (size_t)ch));
+        pr->esm_small = true;
+    }
+    // the cut of the border route: the jitter sits on candidate points, rows >= ns >= pcut
+    const int pcut = (ns / 64) * 64;
+    const bool border = c->pair_border && pcut >= 64;
+    if (!border && pr->chunk == 0) {
+        // the S Ma full systems: a workspace of at most 8 GB (it stays with the pair between
+        // calls -- choose_next calls once per step with the same shapes -- and a BQ object keeps
+        // up to four pairs: an unbounded half of the free HBM starved later fits and plans)
+        size_t freeb = 0, totalb = 0;
+        HIPCHK(c, hipMemGetInfo(&freeb, &totalb));
+        const size_t budget = std::min<size_t>(freeb / 2, (size_t)8 << 30);
+        int64_t ch = std::max<int64_t>(1, (int64_t)(budget / per));
+        ch = std::min<int64_t>(std::min<int64_t>(ch, E), 32768);
+        hipError_t e = pr->Ad.alloc(sizeof(double) * (size_t)lda * L.ntot * (size_t)ch);
+        if (e == hipSuccess)
+            e = pr->dinv.alloc(sizeof(double) * BQ_DINV_STRIDE * (size_t)ch);
+        if (e == hipSuccess)
+            e = pr->panel.alloc(sizeof(double) * sweep_ws_doubles(c, L.ntot, (int)ch));
+        if (e == hipSuccess)
+            e = pr->info.alloc(sizeof(int) * (size_t)ch);
+        if (e == hipSuccess)
+            e = pr->outd.alloc(sizeof(double) * 2 * (size_t)ch);
+        if (e != hipSuccess) {
+            // nothing half-allocated stays behind
+            pr->Ad.release(), pr->dinv.release(), pr->panel.release(), pr->info.release(),
+                pr->outd.release();
+            return fail(c, e == hipErrorOutOfMemory ? BQ_ERR_NOMEM : BQ_ERR_HIP,
+                        "pair_esm: workspace allocation failed: %s", hipGetErrorString(e));
+        }
         pr->chunk = ch;
     }
-    const int64_t chunk = pr->chunk;
+    const int64_t chunk = std::max<int64_t>(pr->chunk, 1);
     DevBuf &gpd = pr->gpd, &pard = pr->pard, &ik = pr->ik, &ika = pr->ika, &dj1 = pr->dj1,
            &dj2 = pr->dj2, &Ad = pr->Ad, &dinv = pr->dinv, &info = pr->info, &outd = pr->outd,
            &panel = pr->panel;
@@ -434,9 +555,11 @@ extern "C" int bq_pair_esm(bq_ctx *c, bq_pair *pr, const double *p_tl, const dou
     hipLaunchKernelGGL(pair_int_K_kernel, dim3((ma + 255) / 256, S), dim3(256), 0, c->stream,
                        pr->x_a.d(), ma, pard.d(), mu[0], ika.d());
     HIPCHK(c, hipGetLastError());
+    if (border)
+        BQCHK(pair_esm_border(c, pr, pcut, thresh, A_a, A_sc_l, status));
     std::vector<double> hout((size_t)chunk * 2);
     std::vector<int> hinfo((size_t)chunk);
-    for (int64_t e0 = 0; e0 < E; e0 += chunk) {
+    for (int64_t e0 = 0; e0 < E && !border; e0 += chunk) {
         const int nb = (int)std::min(chunk, E - e0);
         HIPCHK(c, hipMemsetAsync(info.p, 0, sizeof(int) * nb, c->stream));
         {

@@ -245,15 +245,12 @@ extern "C" int bq_plan_run(bq_ctx *c, bq_plan *p)
     if (c->prof || !c->use_graph || !c->own_stream)
         return plan_enqueue(c, p);
     // settings that change the launch sequence invalidate the captured graph
-    if (p->graph_state == 1 && (p->graph_nb != c->nb_override || p->graph_la != c->lookahead ||
-                                p->graph_pw != c->la_min * 8 + c->split_batch * 4 + c->gemm_lds64 * 2 + c->gemm_lds)) {
+    if (p->graph_state == 1 && p->graph_key != launch_config_key(c)) {
         plan_drop_graph(p);
         p->graph_state = 0;
     }
     if (p->graph_state == 0) {
-        p->graph_nb = c->nb_override;
-        p->graph_la = c->lookahead;
-        p->graph_pw = c->la_min * 8 + c->split_batch * 4 + c->gemm_lds64 * 2 + c->gemm_lds;
+        p->graph_key = launch_config_key(c);
         p->graph_state = -1;
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
             const int st = plan_enqueue(c, p);

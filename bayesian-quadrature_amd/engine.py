@@ -105,6 +105,12 @@ class Engine(object):
         if min_rows is not None:
             self._check(self._lib.bq_set_lookahead_rows(self._ctx, int(min_rows)))
 
+    def config(self):
+        """(outer block override, look-ahead on, look-ahead min_rows) as they stand."""
+        nb, la, mr = C.c_int(), C.c_int(), C.c_int()
+        self._check(self._lib.bq_get_config(self._ctx, C.byref(nb), C.byref(la), C.byref(mr)))
+        return nb.value, bool(la.value), mr.value
+
     def trim(self):
         """Release the workspace the batched calls keep between calls."""
         self._check(self._lib.bq_ctx_trim(self._ctx))

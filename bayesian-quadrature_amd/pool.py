@@ -79,7 +79,13 @@ class EnginePool(object):
                                    "(there is no CPU fallback)")
             devices = list(range(n.value))
         self.devices = [int(d) for d in devices]
-        self._workers = [_Worker(d) for d in self.devices]
+        self._workers = []
+        try:
+            for d in self.devices:
+                self._workers.append(_Worker(d))
+        except BaseException:
+            self.close()  # the threads and contexts already started
+            raise
 
     def __len__(self):
         return len(self._workers)
@@ -107,9 +113,12 @@ class EnginePool(object):
         for box, done in pend:
             done.wait()
             out.append(box[0])
-        for ok, val in out:
-            if not ok:
-                raise val
+        # the first REAL failure in worker order: a worker that only saw a barrier broken by
+        # another one's failure (bench.py --inproc) is reported only if nothing else failed
+        bad = [val for ok, val in out if not ok]
+        if bad:
+            real = [e for e in bad if not isinstance(e, threading.BrokenBarrierError)]
+            raise (real or bad)[0]
         return [val for _, val in out]
 
     def map_blocks(self, nitems, fn):

@@ -36,6 +36,12 @@ def fd_points(x0, step):
     return X, np.array([X[i + 1, i] - x0[i] for i in range(x0.size)])
 
 
+# what the last find_good_parameters did: wall times of fit_hypers are trajectory-dependent
+# (L-BFGS-B on 1e-8 finite differences of a rounding-noisy objective), so timing tools print the
+# iterations, evaluations and the final value beside them
+LAST_OPT = {}
+
+
 def find_good_parameters(logpdf, x0, method, ntry=10, logpdf_batch=None):
     """Up to ``ntry`` restarts of scipy.optimize.minimize on -logpdf; returns the
     first optimum whose log-pdf exceeds MIN, else None.
@@ -61,6 +67,9 @@ def find_good_parameters(logpdf, x0, method, ntry=10, logpdf_batch=None):
         else:
             res = optim.minimize(fun=lambda x: -logpdf(x), x0=x0, method=method)
         p = logpdf(res["x"])
+        LAST_OPT.clear()
+        LAST_OPT.update({"attempts": i + 1, "nit": int(res.get("nit", -1)),
+                         "nfev": int(res.get("nfev", -1)), "logpdf": float(p)})
         if p > MIN:
             return res["x"]
         if logpdf(x0) < p:

@@ -47,6 +47,17 @@ def c4(n=16384):
     return {"x": x, "h": 1.0, "w": np.array([dx]), "s": 1e-3, "d": 1}
 
 
+def c4_dense(n=16384):
+    """C4's matrix size with DENSE operands: the same points, a length scale of 200 spacings and
+    unit noise (well conditioned through the noise floor).  C4 itself (w = dx) gives a banded Gram
+    -- exp underflows to exactly 0 beyond ~38 neighbours -- so the panels fed to its trailing
+    updates are > 97 % zeros, which draw less power and clock higher: the kernel's roofline figure
+    is quoted on this variant."""
+    x = np.linspace(-5.0, 5.0, n)
+    dx = 10.0 / (n - 1)
+    return {"x": x, "h": 1.0, "w": np.array([200.0 * dx]), "s": 1.0, "d": 1}
+
+
 def c5_problem(p, n=2048, m=256):
     """Problem p of C5: x = sort(U(-5,5,n)) seed 1000+p, y = log N(x|mu_p,1)."""
     rs = np.random.RandomState(1000 + p)

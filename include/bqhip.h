@@ -67,6 +67,9 @@ int bq_set_lookahead(bq_ctx *ctx, int on);
  * below that the sweep continues with sequential launches (default 3072, the measured
  * cross-over on MI355X; 0 = look-ahead to the end; also BQ_LA_MIN) */
 int bq_set_lookahead_rows(bq_ctx *ctx, int min_rows);
+/* the three settings above as they stand (a caller that changes them for a while reads them
+ * first and puts them back; any pointer may be NULL) */
+int bq_get_config(bq_ctx *ctx, int *nb, int *lookahead, int *min_rows);
 /* bq_batch_fit_predict and bq_gp_logml_grid keep their device workspace (up to half of
  * the free HBM) in the context between calls, so that a hyper-parameter loop
  * (bq.py:536-550) does not allocate and release it on every evaluation; this releases it */

@@ -1271,12 +1271,15 @@ def test_pair_llh_vs_oracle(engine, oracle, ns, nc, S):
     pair.close()
 
 
-@pytest.mark.parametrize("ns,nc,S,M", [(9, 3, 4, 10), (60, 8, 5, 16), (300, 10, 3, 12)])
+@pytest.mark.parametrize("ns,nc,S,M", [(9, 3, 4, 10), (60, 8, 5, 16), (70, 8, 5, 16),
+                                       (300, 10, 3, 12), (1030, 12, 4, 20)])
 def test_pair_esm_vs_per_set_route(engine, oracle, ns, nc, S, M):
     """bq_pair_esm: GP1's posterior at the candidates and acquisition points, GP2's targets and
     the S x M bordered systems of the acquisition in one batched pass, against the per-set route
     (a resident fit per set + bq_esm_border / bq_gp_predict) and, for the small sizes, the
-    oracle's recipe."""
+    oracle's recipe.  From ns = 64 on the pass is S factorisations + border rows (round 4: the
+    first 64 floor(ns / 64) columns of a set's M systems eliminated once, then S M small systems);
+    below, and with BQ_PAIR_BORDER=0, the S M full systems -- test_pair_esm_routes_agree."""
     from engine_double import EngineDouble
     xs, ls, xc, dx, rs = _pair_problem(ns, nc, 3 * ns + M)
     nc = xc.shape[0]
@@ -1313,6 +1316,42 @@ def test_pair_esm_vs_per_set_route(engine, oracle, ns, nc, S, M):
             assert np.abs(r["A_a"][b] - ref[0]).max() <= tol * scale
             assert np.abs(r["A_sc_l"][b] - ref[1]).max() <= tol * scale
     pair.close()
+
+
+def test_pair_esm_routes_agree(engine):
+    """The two routes of bq_pair_esm on the same inputs: S factorisations + border rows (default)
+    against the S M full bordered systems (BQ_PAIR_BORDER=0), incl. a candidate on top of a
+    candidate point (both jitters) and a set whose GP2 is numerically singular (its elements'
+    status non-zero on both routes)."""
+    import os
+    from bayesian_quadrature_amd import Engine
+    ns, S, M = 200, 6, 14
+    xs, ls, xc, dx, rs = _pair_problem(ns, 9, 3 * ns + M)
+    x_a = np.sort(np.concatenate([rs.uniform(-7, 7, M - 2), xc[:1] + 0.05, xc[-1:]]))
+    p_tl = np.column_stack([rs.uniform(8, 20, S), rs.uniform(1.0, 1.3, S) * dx, np.full(S, 1e-4)])
+    p_l = np.column_stack([rs.uniform(0.1, 0.4, S), rs.uniform(0.9, 1.1, S) * dx, np.zeros(S)])
+    p_l[3, 1] = 300 * dx
+    pair = engine.pair(xs, np.log(ls), ls, xc, x_a, S)
+    r = pair.esm(p_tl, p_l, 0.5, MU1, COV1)
+    pair.close()
+    os.environ["BQ_PAIR_BORDER"] = "0"
+    try:
+        e2 = Engine(0)
+    finally:
+        del os.environ["BQ_PAIR_BORDER"]
+    try:
+        pair2 = e2.pair(xs, np.log(ls), ls, xc, x_a, S)
+        r2 = pair2.esm(p_tl, p_l, 0.5, MU1, COV1)
+        pair2.close()
+    finally:
+        e2.close()
+    assert ((r["status"] != 0) == (r2["status"] != 0)).all() and (r["status"][3] != 0).all()
+    ok = r["status"] == 0
+    assert ok.sum() >= (S - 1) * M - 2
+    for k in ("A_a", "A_sc_l"):
+        assert np.abs(r[k][ok] - r2[k][ok]).max() <= 1e-9 * np.abs(r2[k][ok]).max(), k
+    for k in ("tm_a", "tC_a", "l_c"):
+        assert np.array_equal(r[k], r2[k]), k
 
 
 # ---- the batched factorisation, diagonal block first (round 4) --------------------

@@ -30,6 +30,7 @@ def _case(rs, n, M, d):
 @pytest.mark.parametrize("seed", range(6))
 def test_random_shapes(engine, oracle, seed):
     rs = np.random.RandomState(100 + seed)
+    nb0, la0, rows0 = engine.config()  # the session engine goes back to what it shipped with
     try:
         for _ in range(6):
             d = int(rs.choice([1, 1, 2]))
@@ -47,8 +48,8 @@ def test_random_shapes(engine, oracle, seed):
             assert np.max(np.abs(var - vo)) <= RTOL * k0, (d, n, M)
             assert abs(logml - lmo) <= RTOL * abs(lmo), (d, n, M)
     finally:
-        engine.set_block(0)
-        engine.set_lookahead(True, min_rows=4096)
+        engine.set_block(nb0)
+        engine.set_lookahead(la0, min_rows=rows0)
 
 
 @pytest.mark.parametrize("nb,la", [(0, True), (128, True), (256, False), (64, True)])
@@ -58,14 +59,15 @@ def test_batch_through_lookahead_path(engine, oracle, nb, la):
     P, n, M = 12, 1100, 100
     c = wl.c5(list(range(P)), n=n, m=M)
     w = c["w"] * 1.2
+    nb0, la0, rows0 = engine.config()
     try:
         engine.set_block(nb)
         engine.set_lookahead(la, min_rows=0)
         mean, var, logml, status = engine.batch_fit_predict(c["x"], c["y"], c["h"], w, c["s"],
                                                             c["xo"])
     finally:
-        engine.set_block(0)
-        engine.set_lookahead(True, min_rows=4096)
+        engine.set_block(nb0)
+        engine.set_lookahead(la0, min_rows=rows0)
     assert (status == 0).all()
     k0 = oracle.kernel_scale(1, c["h"], w)
     for p in (0, 5, 11):

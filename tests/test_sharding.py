@@ -210,6 +210,42 @@ def test_engine_pool_partitions_and_propagates_errors(oracle):
             with pytest.raises(ZeroDivisionError):
                 pool.run([lambda e: 1, lambda e: 1 // 0, lambda e: 3])
             assert pool.run([lambda e: e.device] * 3) == [0, 0, 0]   # still alive afterwards
+            # a rank that fails before a barrier breaks it for the others instead of leaving them
+            # waiting (bench.py --inproc): everybody returns, the REAL failure is
+            # the one that is re-raised
+            import threading
+            bar = threading.Barrier(3)
+
+            def rank(i):
+                def run(e):
+                    try:
+                        if i == 1:
+                            raise MemoryError("plan allocation failed on this device")
+                        bar.wait(timeout=30)
+                        return i
+                    except BaseException:
+                        bar.abort()
+                        raise
+                return run
+            with pytest.raises(MemoryError):
+                pool.run([rank(0), rank(1), rank(2)])
+            assert pool.run([lambda e: e.device] * 3) == [0, 0, 0]
+        # a constructor that fails half way closes the workers it has started
+        started = []
+
+        class HalfEngine(FakeEngine):
+            def __init__(self, device):
+                if device == 7:
+                    raise RuntimeError("no such device")
+                super().__init__(device)
+                started.append(self)
+
+            def close(self):
+                started.remove(self)
+        pool_mod.Engine = HalfEngine
+        with pytest.raises(RuntimeError):
+            pool_mod.EnginePool([0, 0, 7])
+        assert started == []
     finally:
         pool_mod.Engine = real
 

@@ -45,9 +45,15 @@ for n in (9, 64, 1024):
         t0 = time.perf_counter()
         p = util.find_good_parameters(f, b._current_params(params), "L-BFGS-B",
                                       logpdf_batch=b._make_llh_batch(params) if mode == "batched" else None)
-        res[mode] = (time.perf_counter() - t0, f(p))
+        res[mode] = (time.perf_counter() - t0, f(p), dict(util.LAST_OPT))
     print("n=%d (nc=%d): objective %.3f ms, value + gradient (5 points) in one pass %.3f ms; "
-          "fit_hypers sequential %.1f ms (llh %.6f), batched gradient %.1f ms (llh %.6f): %.2fx"
+          "fit_hypers sequential %.1f ms (llh %.9f, %d iterations, %d evaluations), batched "
+          "gradient %.1f ms (llh %.9f, %d iterations, %d passes): %.2fx wall, %.3f / %.3f ms per "
+          "iteration"
           % (n, b.nc, t_eval, t_grad, res["sequential"][0] * 1e3, res["sequential"][1],
-             res["batched"][0] * 1e3, res["batched"][1], res["sequential"][0] / res["batched"][0]),
+             res["sequential"][2]["nit"], res["sequential"][2]["nfev"],
+             res["batched"][0] * 1e3, res["batched"][1], res["batched"][2]["nit"],
+             res["batched"][2]["nfev"], res["sequential"][0] / res["batched"][0],
+             res["sequential"][0] * 1e3 / max(1, res["sequential"][2]["nit"]),
+             res["batched"][0] * 1e3 / max(1, res["batched"][2]["nit"])),
           flush=True)
