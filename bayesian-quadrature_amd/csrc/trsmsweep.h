@@ -162,10 +162,13 @@ __global__ __launch_bounds__(256, 4) void trsm_sweep_kernel(double *__restrict__
             for (int r = 0; r < 4; ++r)
                 Xr[(long)(16 * c + 4 * r) * ldx] = xc[r];
         }
-        // the solved slab is the next slabs' P operand: in memory (and out of this CU's way)
-        // before anyone of this workgroup stages it; Ts is free again
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // The solved slab is the next slabs' P operand.  Slab sl + 1 stages columns 16 ch .. of my
+        // rows in chunk ch: columns of slab 0 from its first fill on, columns of THIS slab not
+        // before chunk 4 sl >= 4 -- and every chunk's barrier drains vmcnt first.  So only slab
+        // 0's stores have to be in memory here; the later slabs' land under the next fills.
+        if (sl == 0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // Ts is free again
     }
 #undef BQ_TS_FILL
 #undef BQ_TS_OFF

@@ -265,6 +265,20 @@ def run_main(eng, wk, steps, warmup, dist):
                          "ms_per_step": (t1 - t0) / steps * 1e3,
                          "ms_per_step_hip_events": ev_ms / steps, "pid": os.getpid()})
     mean, var, logml, status = plan.results()
+    # host issue time of a step: how long the calls take to RETURN (nothing waited for), against
+    # the device time of the same steps -- with N contexts driven from one node's cores the
+    # launch rate must stay below the device's pace
+    ki = max(2, min(steps, 10))
+    eng.sync()
+    ti0 = time.perf_counter()
+    for _ in range(ki):
+        plan.run()
+    ti1 = time.perf_counter()
+    eng.sync()
+    ti2 = time.perf_counter()
+    issue = {"host_issue_ms_per_step": (ti1 - ti0) / ki * 1e3,
+             "device_ms_per_step": (ti2 - ti0) / ki * 1e3}
+    ranks_issue = dist.gather(dict(issue, rank=dist.rank))
     # the same K steps with the result read-back (sync + D2H) inside every step
     t2 = time.perf_counter()
     for _ in range(max(1, steps // 4)):
@@ -287,7 +301,8 @@ def run_main(eng, wk, steps, warmup, dist):
     nbytes = plan.nbytes()
     plan.close()
     return dict(wall=wall, ev_ms=ev_ms, rb_ms=rb_ms, prof=prof, mean=mean, var=var, logml=logml,
-                status=status, plan_bytes=nbytes, ranks=ranks, solo_ms=solo_ms)
+                status=status, plan_bytes=nbytes, ranks=ranks, solo_ms=solo_ms,
+                ranks_issue=ranks_issue)
 
 
 def parity_spotcheck(wk, res):
@@ -800,9 +815,20 @@ def inproc_main(a):
             t1 = time.perf_counter()
             barrier.wait(timeout=600)
             mean, var, logml, status = plan.results()
+            # host issue time of a step beside its device time, all ranks' threads at once
+            ki = max(2, min(a.steps, 10))
+            barrier.wait(timeout=600)
+            ti0 = time.perf_counter()
+            for _ in range(ki):
+                plan.run()
+            ti1 = time.perf_counter()
+            eng.sync()
+            ti2 = time.perf_counter()
             plan.close()
             return dict(rank=rank, device=eng.device, t0=t0, t1=t1, wk=wk, mean=mean, var=var,
-                        logml=logml, status=status, info=eng.info() if rank == 0 else None)
+                        logml=logml, status=status, info=eng.info() if rank == 0 else None,
+                        host_issue_ms_per_step=(ti1 - ti0) / ki * 1e3,
+                        device_ms_per_step=(ti2 - ti0) / ki * 1e3)
 
         def run(eng):
             # a rank that fails before a barrier (allocation, inputs, a HIP error on its device)
@@ -837,6 +863,8 @@ def inproc_main(a):
                    "launch_mode": "inproc: one process, an engine and a host thread per device",
                    "ranks": [{"rank": r["rank"], "device": r["device"],
                               "ms_per_step": (r["t1"] - r["t0"]) / a.steps * 1e3} for r in res]},
+        "host_issue": [{"rank": r["rank"], "host_issue_ms_per_step": r["host_issue_ms_per_step"],
+                        "device_ms_per_step": r["device_ms_per_step"]} for r in res],
         "failed_problems": nfail, "device": res[0]["info"],
         "parity": parity_spotcheck(wk, res[0]),
     }
@@ -953,6 +981,7 @@ def main():
                        "bordered_system": ntot, "sharding": "independent problems per rank, "
                        "no data-path collective",
                        "ranks": res["ranks"]},
+            "host_issue": res["ranks_issue"],
             "ms_per_problem": res["wall"] / a.steps / wk["B"] * 1e3,
             "ms_per_step_hip_events": res["ev_ms"] / a.steps,
             "ms_per_step_with_readback": res["rb_ms"],

@@ -302,3 +302,25 @@ def test_bench_inproc_mode(engine):
     assert line["config"]["launch_mode"].startswith("inproc")
     assert sorted(r_["rank"] for r_ in line["config"]["ranks"]) == [0, 1]
     assert line["parity"]["logml_rel"] < 1e-10
+
+
+@pytest.mark.gpu
+def test_eight_rank_host_side_rehearsal(engine):
+    """The host side of an eight-GPU node on the one-GPU box (no curve can be measured here):
+    ``bench.py --gpus 8 --inproc`` -- ONE process, eight contexts, eight host threads, 8 problems per
+    rank -- and five ranks as five processes (the box admits six processes on its card, this test
+    session is one of them), all on device 0 under BQ_BENCH_SHARE_DEVICE=1.  Every rank's host issue time per step stays below
+    the device time of the same steps: with the plan's launches replayed from a hipGraph a step
+    costs the host one call, so the launch rate is not what limits eight contexts."""
+    import json
+    for args in (["--gpus", "8", "--inproc"], ["--gpus", "5", "--no-extras", "--no-cpu-baseline"]):
+        r = _run_bench(args + ["--steps", "4", "--warmup", "2", "--batch", "8"],
+                       {"BQ_BENCH_SHARE_DEVICE": "1"})
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert line["n_gpus"] == int(args[1]) and line["value"] is not None
+        assert line["failed_problems"] == 0
+        hi = line["host_issue"]
+        assert len(hi) == int(args[1])
+        for rk in hi:
+            assert rk["host_issue_ms_per_step"] < rk["device_ms_per_step"], (args, rk)
