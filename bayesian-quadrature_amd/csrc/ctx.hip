@@ -98,6 +98,18 @@ static int ctx_init(bq_ctx *c, int device)
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIPCHK(c, hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, hi));
     BQCHK(gemm_init(c));
+    // the one-launch single-vector sweeps: the abort word lives in mapped
+    // host memory (the host reads it after a synchronisation without a copy)
+    {
+        void *h = nullptr;
+        HIPCHK(c, hipHostMalloc(&h, 64, hipHostMallocMapped));
+        c->flow_abort = static_cast<int *>(h);
+        *c->flow_abort = 0;
+    }
+    if (const char *e = std::getenv("BQ_TRSV_FLOW"))
+        c->trsv_flow = std::atoi(e);
+    if (const char *e = std::getenv("BQ_TRSV_FLOW_MIN"))
+        c->trsv_flow_min = std::atoi(e);
     if (const char *e = std::getenv("BQ_LOOKAHEAD"))
         c->lookahead = std::atoi(e);
     if (const char *e = std::getenv("BQ_SPLIT"))
@@ -206,6 +218,8 @@ extern "C" void bq_ctx_destroy(bq_ctx *c)
     for (hipEvent_t e : {c->ev_panel, c->ev_next, c->ev_fork})
         if (e)
             (void)hipEventDestroy(e);
+    if (c->flow_abort)
+        (void)hipHostFree(c->flow_abort);
     if (c->aux) {
         (void)hipStreamSynchronize(c->aux);
         (void)hipStreamDestroy(c->aux);
@@ -221,7 +235,7 @@ extern "C" int bq_ctx_sync(bq_ctx *c)
         return BQ_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return BQ_OK;
+    return flow_check(c);
 }
 
 extern "C" const char *bq_last_error(const bq_ctx *c) { return c ? c->err : "null context"; }

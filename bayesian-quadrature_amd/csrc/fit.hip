@@ -119,8 +119,10 @@ int fit_wide(bq_ctx *c, bq_fit *f, WideInv &w)
 // the single-vector workspace of a fit (x at vec, y at vec + npad)
 int fit_vec(bq_ctx *c, bq_fit *f)
 {
-    if (f->vec.bytes < sizeof(double) * 2 * (size_t)f->npad)
-        HIPCHK(c, f->vec.alloc(sizeof(double) * 2 * (size_t)f->npad));
+    // x | y | the one-launch sweeps' workspace (ticket + x versions)
+    const size_t need = 2 * (size_t)f->npad + trsv_flow_ws_doubles(f->npad, wide_block(f->npad));
+    if (f->vec.bytes < sizeof(double) * need)
+        HIPCHK(c, f->vec.alloc(sizeof(double) * need));
     if (!f->hvec)
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&f->hvec),
                                 sizeof(double) * (size_t)f->npad));
@@ -141,9 +143,11 @@ int fit_alpha(bq_ctx *c, bq_fit *f)
                                sizeof(double) * f->ldl, sizeof(double), f->npad,
                                hipMemcpyDeviceToDevice, c->stream));
     BQCHK(fit_replay(c, f, 1, [&]() -> int {
-        return enqueue_backward_vec(c, f->vec.d(), f->alpha.d(), f->A.d(), f->ldl, f->npad, w);
+        return enqueue_backward_vec(c, f->vec.d(), f->alpha.d(), f->A.d(), f->ldl, f->npad, w,
+                                    f->vec.d() + 2 * (size_t)f->npad);
     }));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    BQCHK(flow_check(c));
     f->have_alpha = true;
     return BQ_OK;
 }

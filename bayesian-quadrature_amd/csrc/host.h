@@ -89,6 +89,10 @@ struct bq_ctx {
     int df_sweep = 1;    // the panel solve of an outer block in one launch (trsm_sweep_kernel; BQ_DF_SWEEP)
     int df_wg = -1;      // a batch's diagonal factor by one workgroup per matrix (potrf_wg_kernel): -1 by
                          // batch size (potrf.hip, dfirst_wg), 0 / 1 forced (BQ_DF_WG)
+    int trsv_flow = 1;   // single-vector sweeps as one launch each, hand-offs through memory
+                         // (trsvflow.h; BQ_TRSV_FLOW=0: one launch per block column)
+    int trsv_flow_min = 2048; // ... from this many rows on (BQ_TRSV_FLOW_MIN)
+    int *flow_abort = nullptr; // mapped host word a timed-out hand-off raises
     int pair_border = 1; // bq_pair_esm as S factorisations + border rows (BQ_PAIR_BORDER=0: the S Ma
                          // full bordered systems)
     int df_halves = 0;   // the diagonal-first sweep as two half-batches on the two streams (BQ_DF_HALVES)
@@ -352,6 +356,13 @@ int launch_trsv_fwd(bq_ctx *c, const double *L, long ldl, int J, int bJ, int B, 
                     const double *nr, const double *tt, double *x, double *y, double work);
 int launch_trsv_bwd(bq_ctx *c, const double *L, long ldl, int J, int bJ, int B, int bn, int nupd,
                     const double *nt, const double *uu, double *x, double *y, double work);
+// a whole sweep in one launch (trsvflow.h); flow_check: BQ_ERR_HIP if a hand-off of a sweep that
+// has completed on the stream timed out (call after synchronising)
+bool trsv_flow_ok(const bq_ctx *c, int npad, int B);
+size_t trsv_flow_ws_doubles(int npad, int B);
+int launch_trsv_flow(bq_ctx *c, bool forward, const double *L, long ldl, int npad, int B,
+                     const double *m1, const double *m2, const double *x0, double *y, double *ws);
+int flow_check(bq_ctx *c);
 
 // ---- potrf.hip ------------------------------------------------------------------------
 int auto_nb(const bq_ctx *c, int ntot, int batch);
@@ -377,7 +388,14 @@ struct WideInv {
     const double *t = nullptr;  // T_J itself (rows of T contiguous: the fused row-sweep step)
     int B = 0;
 };
-inline int wide_block(int npad) { return npad < 2048 ? std::min(npad, 256) : 512; }
+inline int wide_block(int npad)
+{
+    // (BQ_WIDE_B: measurements)
+    static const int forced = std::getenv("BQ_WIDE_B") ? std::atoi(std::getenv("BQ_WIDE_B")) : 0;
+    if (forced > 0)
+        return std::min(npad, forced);
+    return npad < 2048 ? std::min(npad, 256) : 512;
+}
 inline size_t wide_doubles(int npad) { return (size_t)npad * wide_block(npad); }
 // NR, NT, TT, UU and the scratch of T before its transposition (a full B x B per block)
 inline size_t wide_alloc_doubles(int npad)
@@ -388,10 +406,11 @@ inline size_t wide_alloc_doubles(int npad)
 WideInv wide_views(const double *base, int npad);
 int compute_wide_inverses(bq_ctx *c, const double *L, long ldl, int npad, const double *dw,
                           double *nr);
+// ws: trsv_flow_ws_doubles(npad, w.B) doubles for the one-launch form (nullptr: a launch per block)
 int enqueue_forward_vec(bq_ctx *c, double *x, double *y, const double *L, long ldl, int npad,
-                        WideInv w);
+                        WideInv w, double *ws = nullptr);
 int enqueue_backward_vec(bq_ctx *c, double *x, double *y, const double *L, long ldl, int npad,
-                         WideInv w);
+                         WideInv w, double *ws = nullptr);
 int enqueue_forward_rows_blk(bq_ctx *c, double *X, long ldx, int mrows, const double *L, long ldl,
                              int npad, const double *dw);
 int enqueue_forward_rows(bq_ctx *c, double *Xin, double *Xout, long ldx, int mrows,
@@ -497,7 +516,11 @@ int fit_alpha(bq_ctx *c, bq_fit *f);
 template <class F>
 int fit_replay(bq_ctx *c, bq_fit *f, int slot, F &&enqueue)
 {
-    if (!c->use_graph || c->prof || !c->own_stream || c->cur != c->stream)
+    // (a one-launch sweep is two memsets and a kernel: enqueued directly it costs the host less
+    // than a graph launch does -- BQ_FLOW_GRAPH=1 replays it from a graph all the same)
+    static const bool flow_graph = std::getenv("BQ_FLOW_GRAPH") && std::atoi(std::getenv("BQ_FLOW_GRAPH"));
+    if (!c->use_graph || c->prof || !c->own_stream || c->cur != c->stream ||
+        (!flow_graph && trsv_flow_ok(c, f->npad, wide_block(f->npad))))
         return enqueue();
     if (!f->vgexec[slot] && !f->vg_failed[slot]) {
         f->vg_failed[slot] = true;

@@ -3,6 +3,7 @@
 #include "host.h"
 #include "reduce.h"
 #include "trsv.h"
+#include "trsvflow.h"
 
 namespace bqh {
 
@@ -139,6 +140,69 @@ int launch_trsv_bwd(bq_ctx *c, const double *L, long ldl, int J, int bJ, int B, 
     hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(bJ / 16 + nupd), dim3(1024), 0, c->cur, L, ldl, J,
                        bJ, B, bn, nt, uu, x, y);
     HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+// doubles of workspace a one-launch sweep needs behind its vectors: the ticket (one 64-byte
+// line) and the x versions 1 .. ns - 1
+size_t trsv_flow_ws_doubles(int npad, int B)
+{
+    const int ns = (npad + B - 1) / B;
+    return 8 + (size_t)(ns > 1 ? ns - 1 : 0) * npad;
+}
+
+bool trsv_flow_ok(const bq_ctx *c, int npad, int B)
+{
+    // (below 2048 rows the sweep is two to four steps: the memsets cost what the launches did)
+    return c->trsv_flow && c->flow_abort && B <= 512 && (B & 63) == 0 && (npad & 63) == 0 &&
+           npad >= c->trsv_flow_min && (npad + B - 1) / B >= 2;
+}
+
+// ws: trsv_flow_ws_doubles(npad, B) doubles; x0 is read, y written (npad each)
+int launch_trsv_flow(bq_ctx *c, bool forward, const double *L, long ldl, int npad, int B,
+                     const double *m1, const double *m2, const double *x0, double *y, double *ws)
+{
+    const int ns = (npad + B - 1) / B, last = (npad - 1) / B * B;
+    long blocks = 0;
+    double work = 0.0;
+    for (int s = 0; s < ns; ++s) {
+        const int J = forward ? s * B : last - s * B;
+        const int bJ = std::min(B, npad - J);
+        const int nupd = forward ? (s > 0 ? (npad - J - bJ) / 64 : 0) : (s > 0 ? J / 64 : 0);
+        blocks += bJ / 16 + nupd;
+        work += (double)bJ * bJ + 2.0 * B * (bJ + 64.0 * nupd);
+    }
+    // every slot starts as the sentinel (all bits set); the ticket counter starts at -1 with it
+    HIPCHK(c, hipMemsetAsync(ws, 0xFF, sizeof(double) * trsv_flow_ws_doubles(npad, B), c->cur));
+    HIPCHK(c, hipMemsetAsync(y, 0xFF, sizeof(double) * (size_t)npad, c->cur));
+    // (BQ_FLOW_FAULT=1, read per launch: the forward sweep loses a hand-off -- tests of the time-out)
+    const int fault = std::getenv("BQ_FLOW_FAULT") ? std::atoi(std::getenv("BQ_FLOW_FAULT")) : 0;
+    Bracket br(c, BQ_K_GEMM, work);
+    int *ticket = reinterpret_cast<int *>(ws);
+    double *xv = ws + 8;
+    if (!forward)
+        hipLaunchKernelGGL(trsv_bwd_flow_kernel, dim3((unsigned)blocks), dim3(1024), 0, c->cur, L, ldl,
+                           npad, B, m1, m2, x0, xv, y, ticket, c->flow_abort, fault);
+    else if (B == 512)
+        hipLaunchKernelGGL(trsv_fwd_flow_kernel<8>, dim3((unsigned)blocks), dim3(1024), 0, c->cur, L,
+                           ldl, npad, B, m1, m2, x0, xv, y, ticket, c->flow_abort, fault);
+    else if (B == 256)
+        hipLaunchKernelGGL(trsv_fwd_flow_kernel<4>, dim3((unsigned)blocks), dim3(1024), 0, c->cur, L,
+                           ldl, npad, B, m1, m2, x0, xv, y, ticket, c->flow_abort, fault);
+    else
+        hipLaunchKernelGGL(trsv_fwd_flow_kernel<0>, dim3((unsigned)blocks), dim3(1024), 0, c->cur, L,
+                           ldl, npad, B, m1, m2, x0, xv, y, ticket, c->flow_abort, fault);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+int flow_check(bq_ctx *c)
+{
+    if (c->flow_abort && *static_cast<volatile int *>(c->flow_abort) != 0) {
+        *c->flow_abort = 0;
+        return fail(c, BQ_ERR_HIP, "single-vector sweep: a hand-off between workgroups timed out "
+                                   "(BQ_TRSV_FLOW=0 selects the one-launch-per-block sweeps)");
+    }
     return BQ_OK;
 }
 

@@ -96,15 +96,15 @@ extern "C" int bq_cho_solve(bq_ctx *c, const double *L, const double *B, double 
     const WideInv w = wide_views(wide.d(), npad);
     if (nrhs == 1) {
         // one right-hand side: the GEMV sweeps (trsv.h)
-        HIPCHK(c, Xd.alloc(sizeof(double) * 2 * (size_t)npad));
-        HIPCHK(c, hipMemsetAsync(Xd.p, 0, Xd.bytes, c->stream));
+        HIPCHK(c, Xd.alloc(sizeof(double) * (2 * (size_t)npad + trsv_flow_ws_doubles(npad, w.B))));
+        HIPCHK(c, hipMemsetAsync(Xd.p, 0, sizeof(double) * 2 * (size_t)npad, c->stream));
         HIPCHK(c, hipMemcpyAsync(Xd.p, B, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-        double *x = Xd.d(), *y = Xd.d() + npad;
-        BQCHK(enqueue_forward_vec(c, x, y, A.d(), ldl, npad, w));
-        BQCHK(enqueue_backward_vec(c, y, x, A.d(), ldl, npad, w));
+        double *x = Xd.d(), *y = Xd.d() + npad, *fw = Xd.d() + 2 * (size_t)npad;
+        BQCHK(enqueue_forward_vec(c, x, y, A.d(), ldl, npad, w, fw));
+        BQCHK(enqueue_backward_vec(c, y, x, A.d(), ldl, npad, w, fw));
         HIPCHK(c, hipMemcpyAsync(X, x, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        return BQ_OK;
+        return flow_check(c);
     }
     return solve_rows_host(c, A.d(), ldl, (int)n, npad, w, B, nrhs, X);
 }

@@ -395,11 +395,13 @@ extern "C" int bq_gp_solve(bq_ctx *c, bq_fit *f, const double *B, int64_t nrhs, 
         HIPCHK(c, hipMemcpyAsync(x, f->hvec, sizeof(double) * npad, hipMemcpyHostToDevice,
                                  c->stream));
         BQCHK(fit_replay(c, f, 0, [&]() -> int {
-            BQCHK(enqueue_forward_vec(c, x, y, f->A.d(), f->ldl, npad, wv));
-            return enqueue_backward_vec(c, y, x, f->A.d(), f->ldl, npad, wv);
+            double *ws = f->vec.d() + 2 * (size_t)npad;
+            BQCHK(enqueue_forward_vec(c, x, y, f->A.d(), f->ldl, npad, wv, ws));
+            return enqueue_backward_vec(c, y, x, f->A.d(), f->ldl, npad, wv, ws);
         }));
         HIPCHK(c, hipMemcpyAsync(f->hvec, x, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        BQCHK(flow_check(c));
         std::memcpy(X, f->hvec, sizeof(double) * n);
         return BQ_OK;
     }
@@ -467,12 +469,14 @@ extern "C" int bq_bq_Z_var(bq_ctx *c, bq_fit *gp_tl, bq_fit *gp_l, const double 
     // (the reference solves with both sweeps and takes the dot product, bq_c.pyx:348-351; the
     // symmetric form errs with cond(L) instead of cond(K))
     BQCHK(fit_replay(c, gp_tl, 2, [&]() -> int {
-        return enqueue_forward_vec(c, sol, X, gp_tl->A.d(), gp_tl->ldl, npad, wi);
+        return enqueue_forward_vec(c, sol, X, gp_tl->A.d(), gp_tl->ldl, npad, wi,
+                                   gp_tl->vec.d() + 2 * (size_t)npad);
     }));
     BQCHK(launch_neg_sumsq(c, X, npad, scal + 1));
     double hs[2];
     HIPCHK(c, hipMemcpyAsync(hs, scal, sizeof hs, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    BQCHK(flow_check(c));
     *out = hs[0] + hs[1]; // hs[1] holds -|L^-1 beta|^2
     return BQ_OK;
 }

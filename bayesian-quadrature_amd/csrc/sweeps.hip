@@ -110,8 +110,10 @@ int compute_wide_inverses(bq_ctx *c, const double *L, long ldl, int npad, const 
 
 // One right-hand side: x (npad, consumed) -> y = L^-1 x, one launch per B columns (trsv.h)
 int enqueue_forward_vec(bq_ctx *c, double *x, double *y, const double *L, long ldl, int npad,
-                        WideInv w)
+                        WideInv w, double *ws)
 {
+    if (ws && trsv_flow_ok(c, npad, w.B))
+        return launch_trsv_flow(c, true, L, ldl, npad, w.B, w.nr, w.tt, x, y, ws);
     for (int J = 0; J < npad; J += w.B) {
         const int bJ = std::min(w.B, npad - J);
         const int nupd = J > 0 ? (npad - J - bJ) / 64 : 0;
@@ -124,8 +126,10 @@ int enqueue_forward_vec(bq_ctx *c, double *x, double *y, const double *L, long l
 
 // x (npad, consumed) -> y = L^-T x
 int enqueue_backward_vec(bq_ctx *c, double *x, double *y, const double *L, long ldl, int npad,
-                         WideInv w)
+                         WideInv w, double *ws)
 {
+    if (ws && trsv_flow_ok(c, npad, w.B))
+        return launch_trsv_flow(c, false, L, ldl, npad, w.B, w.nt, w.uu, x, y, ws);
     const int last = (npad - 1) / w.B * w.B;
     for (int J = last; J >= 0; J -= w.B) {
         const int bJ = std::min(w.B, npad - J);

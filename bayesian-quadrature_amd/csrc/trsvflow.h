@@ -1,0 +1,363 @@
+// trsvflow.h -- the single-vector sweeps over a resident factor as ONE launch each
+// Part of the libbqhip.so kernel set; compiled into k_reduce.hip (host.h lists the units).
+#pragma once
+#include "trsv.h"
+
+// ---------------------------------------------------------------------------
+// trsv.h runs a sweep as one launch per B columns; nothing in a launch waits on anything in it,
+// and every step pays a dependent kernel boundary: N = 4096 is sixteen launches of 5-9 us for
+// 21 us worth of bytes.  Here the workgroups of ALL steps are one grid and the boundaries become
+// hand-offs through memory:
+//   * a workgroup takes its logical id from a ticket counter as it starts, so ids follow the
+//     actual start order whatever the dispatcher does; ids are laid out step after step -- the
+//     diagonal pieces of a step first, then its update blocks by increasing row -- and a
+//     workgroup only ever waits for work of EARLIER steps: lower tickets, already resident or
+//     done.  No residency assumption, no deadlock, however few workgroups the chip admits;
+//   * the payload is its own flag.  A first version signalled through counters (stores, every
+//     wave's vmcnt drain, a workgroup barrier, an atomic add, the consumer's poll): 4-5 us per
+//     hop, what a kernel boundary costs -- N = 4096 took 0.140 ms either way.  Now every value is
+//     written ONCE into a slot that was filled with a sentinel (all bits set: a NaN no arithmetic
+//     here produces -- results that are NaN are stored as the canonical one) before the launch,
+//     and the consumer polls the very words it needs: y has one slot per entry, x one per entry
+//     and VERSION (x after s updates is row s of an ns x npad array; version 0 is the caller's
+//     vector).  Eight-byte agent-scope relaxed atomic loads / stores (sc1: L2-coherent, past the
+//     CU's L1), no drain, no barrier, no counter on the producer's side;
+//   * the factor's columns -- the only traffic that counts -- are requested BEFORE the wait.
+// The arithmetic is trsv.h's, operation for operation: the same results bit for bit.
+// Spins are bounded: after ~1 s without progress a wave raises the abort word (mapped host
+// memory), every spinner sees it and leaves; the host reports BQ_ERR_HIP (flow_check).
+// ---------------------------------------------------------------------------
+#define BQ_FLOW_SPINS (1 << 21)
+#define BQ_FLOW_SENT 0xFFFFFFFFFFFFFFFFull
+
+__device__ __forceinline__ unsigned long long flow_ldu(const double *p)
+{
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void flow_st(double *p, double v)
+{
+    if (v != v) // (never the sentinel: a NaN result goes out as the canonical quiet NaN)
+        v = __longlong_as_double(0x7FF8000000000000ll);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p),
+                       (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the pause between two polls of a wave, and the time-out: returns false to stop spinning
+__device__ __forceinline__ bool flow_again(int &it, int *abort_w)
+{
+    if (++it >= BQ_FLOW_SPINS) {
+        __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return false;
+    }
+    if ((it & 63) == 0 &&
+        __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)
+        return false;
+    __builtin_amdgcn_s_sleep(8);
+    return true;
+}
+
+// The gate in front of a workgroup's polls: ONE lane of the workgroup watches one word of each
+// vector it is going to read (nullptr: none) until neither is the sentinel, the others wait at
+// the barrier.  Without it every wave polls all its words all the time -- 4096 resident waves
+// times 8-16 loads per microsecond on a few dozen cache lines -- and the producers' stores queue
+// behind the polls: merged 16-load polls made N = 4096 ten times slower, not faster.  The words
+// behind the gate are written at about the same time as the watched one; the full polls that
+// follow catch the stragglers.
+__device__ __forceinline__ void flow_gate(const double *w0, const double *w1, int *abort_w)
+{
+    if (threadIdx.x == 0) {
+        int it = 0;
+        for (;;) {
+            const unsigned long long a = w0 ? flow_ldu(w0) : 0ull, b = w1 ? flow_ldu(w1) : 0ull;
+            if ((a != BQ_FLOW_SENT && b != BQ_FLOW_SENT) || !flow_again(it, abort_w))
+                break;
+        }
+    }
+    __syncthreads();
+}
+
+// Hand-off words are read with raw buffer loads (buffer_load_dwordx2 ... sc1): hipcc follows every
+// relaxed atomic load with s_waitcnt vmcnt(0) -- sixteen dependent round trips per poll, which made
+// the polled sweep ten times slower than the launches it replaces -- and schedules these like any
+// load: sixteen in flight, one wait.  The descriptor carries the vector's range: a word beyond it
+// reads as zero (not the sentinel, and the value the arithmetic wants there), so no lane needs a
+// mask and no vector needs slack behind it.
+typedef unsigned int flow_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t flow_rsrc(const double *p, int n)
+{
+    // raw buffer over n doubles from p (stride 0, range checked against num_records)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p), 0, n > 0 ? n * 8 : 0, 0x00020000);
+}
+__device__ __forceinline__ unsigned long long flow_bld(__amdgpu_buffer_rsrc_t r, int byte_off)
+{
+    const flow_u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 16 /* sc1 */);
+    return ((unsigned long long)v.y << 32) | v.x;
+}
+
+// v[q] = p[lo + lane + 64 q] for lo + lane + 64 q < hi (else 0) and the same for (p2, lo2, hi2),
+// polled -- one round trip per poll for both -- until none of the wave's values is the sentinel.
+__device__ __forceinline__ void flow_poll8x2(const double *p, int lo, int hi, double (&v)[8],
+                                             const double *p2, int lo2, int hi2, double (&v2)[8],
+                                             int lane, int *abort_w)
+{
+    const __amdgpu_buffer_rsrc_t r1 = flow_rsrc(p, hi), r2 = flow_rsrc(p2, hi2);
+    const int o1 = (lo + lane) * 8, o2 = (lo2 + lane) * 8;
+    int it = 0;
+    for (;;) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            v[q] = __longlong_as_double((long long)flow_bld(r1, o1 + 512 * q));
+            v2[q] = __longlong_as_double((long long)flow_bld(r2, o2 + 512 * q));
+        }
+        // (the sentinel has every bit set: AND the words, compare once)
+        unsigned long long all1 = 0ull, any = 0ull;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const unsigned long long a = (unsigned long long)__double_as_longlong(v[q]),
+                                     b = (unsigned long long)__double_as_longlong(v2[q]);
+            any |= (a == BQ_FLOW_SENT) | (b == BQ_FLOW_SENT);
+        }
+        (void)all1;
+        if (__all(any == 0ull) || !flow_again(it, abort_w))
+            return;
+    }
+}
+
+__device__ __forceinline__ double flow_poll1(const double *p, bool mine, int *abort_w)
+{
+    int it = 0;
+    for (;;) {
+        const unsigned long long u = mine ? flow_ldu(p) : 0ull;
+        if (__all(u != BQ_FLOW_SENT) || !flow_again(it, abort_w))
+            return __longlong_as_double((long long)u);
+    }
+}
+
+// Forward sweep L y = x, all steps in one grid.  Logical block (s, lb): J = s B;
+// lb < bJ / 16: y[J + 16 lb + wave]; else rows J + bJ + 64 (lb - bJ / 16) .. + 63 take y of block
+// s - 1.  x0: the right-hand side (version 0, not modified); xv: versions 1 .. (row s - 1 of an
+// ns x npad array); y and xv filled with the sentinel.  nr / tt: the whole arrays (block s at
+// + J B).  grid: the total over the steps, block 1024.
+template <int NB> // B / 64 (4 or 8), or 0: any B <= 512
+__global__ __launch_bounds__(1024) void trsv_fwd_flow_kernel(const double *__restrict__ L, long ldl,
+                                                             int npad, int B,
+                                                             const double *__restrict__ nr,
+                                                             const double *__restrict__ tt,
+                                                             const double *x0, double *xv, double *y,
+                                                             int *ticket, int *abort_w, int fault)
+{
+    __shared__ double ys[512];
+    __shared__ double part[16][64];
+    __shared__ int sh[1];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ns = (npad + B - 1) / B;
+    if (t == 0)
+        sh[0] = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    __syncthreads();
+    int id = sh[0], s = 0, J = 0, bJ = 0, ndiag = 0;
+    for (; s < ns; ++s) {
+        J = s * B;
+        bJ = min(B, npad - J);
+        ndiag = bJ >> 4;
+        const int cnt = ndiag + (s > 0 ? (npad - J - bJ) / 64 : 0);
+        if (id < cnt)
+            break;
+        id -= cnt;
+    }
+    if (s >= ns)
+        return;
+    // x after v updates: version v
+    auto xver = [&](int v) { return v == 0 ? x0 : xv + (long)(v - 1) * npad; };
+    if (id < ndiag) {
+        // ---- diagonal piece (a wave per entry, no workgroup barrier): the matrix columns
+        // first, then x of block s (version s - 1: every update but y_{s-1}'s, which T carries)
+        // and y of block s - 1 as they appear
+        const int k = id * 16 + wave;
+        const double *c1 = nr + (long)J * B + (long)k * B, *c2 = tt + (long)J * B + (long)k * B;
+        const int hi1 = (k | 63) + 1, hi2 = J > 0 ? B : 0;
+        double m1[8], m2[8], xb[8], yb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = lane + 64 * q;
+            m1[q] = i < hi1 ? c1[i] : 0.0;
+            m2[q] = i < hi2 ? c2[i] : 0.0;
+        }
+        // (the same piece of the block before, and the first of my rows' x)
+        flow_gate(s > 0 ? y + J - B + id * 16 : nullptr, s > 1 ? xver(s - 1) + J + id * 16 : nullptr,
+                  abort_w);
+        flow_poll8x2(xver(s > 0 ? s - 1 : 0) + J, 0, hi1, xb, y + J - B, 0, hi2, yb, lane, abort_w);
+        double s0 = 0.0, s1 = 0.0, u0 = 0.0, u1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+            s0 = fma(m1[q], xb[q], s0);
+            s1 = fma(m1[q + 1], xb[q + 1], s1);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+            u0 = fma(m2[q], yb[q], u0);
+            u1 = fma(m2[q + 1], yb[q + 1], u1);
+        }
+        const double sum = wave_sum((s0 + s1) + (u0 + u1));
+        // (fault: a test's lost hand-off -- step 1 never publishes, its consumers time out)
+        if (lane == 0 && !(fault && s == 1))
+            flow_st(y + J + k, -sum);
+        return;
+    }
+    // ---- update block: rows r take y of block s - 1 (columns J - B .. J - 1): version s - 1 -> s
+    const int rb = (J + bJ) / 64 + (id - ndiag);
+    const long r = 64L * rb + lane;
+    const double *p = L + r + (long)(J - B + wave) * ldl;
+    double v[NB > 0 ? NB : 1][4];
+    if (NB > 0) {
+#pragma unroll
+        for (int it = 0; it < NB; ++it)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                v[it][u] = p[(long)(64 * it + 16 * u) * ldl];
+    }
+    flow_gate(y + J - B + (rb * 16) % B, s > 1 ? xver(s - 1) + r - lane : nullptr, abort_w);
+    double xin = 0.0;
+    {
+        // every wave polls its 64 entries of y (B <= 512: waves 0 .. B / 64 - 1), wave 0 its
+        // rows of x as well, in the same round trip
+        int it = 0;
+        const __amdgpu_buffer_rsrc_t ry = flow_rsrc(y + J - B, B), rx = flow_rsrc(xver(s - 1) + 64L * rb, 64);
+        const int ox = wave == 0 ? lane * 8 : (1 << 20); // (other waves: out of range, zero)
+        for (;;) {
+            const unsigned long long uy = flow_bld(ry, t * 8), ux = flow_bld(rx, ox);
+            if (__all(uy != BQ_FLOW_SENT && ux != BQ_FLOW_SENT) || !flow_again(it, abort_w)) {
+                if (t < B)
+                    ys[t] = __longlong_as_double((long long)uy);
+                xin = __longlong_as_double((long long)ux);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (NB > 0) {
+#pragma unroll
+        for (int it = 0; it < NB; ++it)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                sacc[u] = fma(v[it][u], ys[wave + 64 * it + 16 * u], sacc[u]);
+    } else {
+        for (int k = wave; k < B; k += 64) {
+            double vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                vv[u] = p[(long)(16 * u) * ldl];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                sacc[u] = fma(vv[u], ys[k + 16 * u], sacc[u]);
+            p += 64 * ldl;
+        }
+    }
+    part[wave][lane] = (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
+    __syncthreads();
+    if (wave == 0) {
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w)
+            a += part[w][lane];
+        flow_st(xv + (long)(s - 1) * npad + r, xin - a);
+    }
+}
+
+// Backward sweep L^T y = x, all steps in one grid.  Step t: J = last - t B (last = the last
+// block's first column); lb < bJ / 16: y[J + 16 lb + wave]; else columns 64 (lb - bJ / 16) .. + 63
+// (< J) take y of block J + B (step t - 1): version t - 1 -> t.  nt / uu: the whole arrays.
+__global__ __launch_bounds__(1024) void trsv_bwd_flow_kernel(const double *__restrict__ L, long ldl,
+                                                             int npad, int B,
+                                                             const double *__restrict__ nt,
+                                                             const double *__restrict__ uu,
+                                                             const double *x0, double *xv, double *y,
+                                                             int *ticket, int *abort_w, int fault)
+{
+    __shared__ int sh[1];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ns = (npad + B - 1) / B, last = (npad - 1) / B * B;
+    if (t == 0)
+        sh[0] = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    __syncthreads();
+    int id = sh[0], st = 0, J = 0, bJ = 0, bn = 0, ndiag = 0;
+    for (; st < ns; ++st) {
+        J = last - st * B;
+        bJ = min(B, npad - J);
+        bn = st > 0 ? min(B, npad - J - B) : 0;
+        ndiag = bJ >> 4;
+        const int cnt = ndiag + (bn > 0 ? J / 64 : 0);
+        if (id < cnt)
+            break;
+        id -= cnt;
+    }
+    if (st >= ns)
+        return;
+    auto xver = [&](int v) { return v == 0 ? x0 : xv + (long)(v - 1) * npad; };
+    if (id < ndiag) {
+        const int k = id * 16 + wave;
+        const double *c1 = nt + (long)J * B + (long)k * B, *c2 = uu + (long)J * B + (long)k * B;
+        const int lo1 = k & ~63;
+        double m1[8], m2[8], xb[8], yb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i1 = lo1 + lane + 64 * q, i2 = lane + 64 * q;
+            m1[q] = i1 < bJ ? c1[i1] : 0.0;
+            m2[q] = i2 < bn ? c2[i2] : 0.0;
+        }
+        flow_gate(st > 0 ? y + J + B + (id * 16) % bn : nullptr,
+                  st > 1 ? xver(st - 1) + J + id * 16 : nullptr, abort_w);
+        flow_poll8x2(xver(st > 0 ? st - 1 : 0) + J, lo1, bJ, xb, y + J + B, 0, bn, yb, lane, abort_w);
+        double s0 = 0.0, s1 = 0.0, u0 = 0.0, u1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+            s0 = fma(m1[q], xb[q], s0);
+            s1 = fma(m1[q + 1], xb[q + 1], s1);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+            u0 = fma(m2[q], yb[q], u0);
+            u1 = fma(m2[q + 1], yb[q + 1], u1);
+        }
+        const double sum = wave_sum((s0 + s1) + (u0 + u1));
+        if (lane == 0)
+            flow_st(y + J + k, -sum);
+        return;
+    }
+    // ---- update block: 64 columns i < J take y of block J + B (a wave per four columns)
+    const int cb = id - ndiag;
+    const int nk = bn >> 6;
+    const int i0 = cb * 64 + wave * 4;
+    const double *p = L + J + B + lane + (long)i0 * ldl;
+    double v[4][8], yr[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+            v[cc][q] = q < nk ? p[64 * q + (long)cc * ldl] : 0.0;
+    flow_gate(y + J + B + (cb * 16) % bn, st > 1 ? xver(st - 1) + cb * 64 : nullptr, abort_w);
+    double xin;
+    {
+        // y of block J + B (eight per lane) and my four columns' x in one round trip
+        double xq[8];
+        flow_poll8x2(y + J + B, 0, bn, yr, xver(st - 1) + i0, 0, 4, xq, lane, abort_w);
+        xin = xq[0];
+    }
+    double mine = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+            s0 = fma(v[cc][q], yr[q], s0);
+            s1 = fma(v[cc][q + 1], yr[q + 1], s1);
+        }
+        const double sm = wave_sum(s0 + s1);
+        if (lane == cc)
+            mine = sm;
+    }
+    if (lane < 4)
+        flow_st(xv + (long)(st - 1) * npad + i0 + lane, xin - mine);
+}

@@ -1445,3 +1445,60 @@ def test_batch_diag_first_reports_not_pd(engine):
     m1, v1, l1, st1 = engine.batch_fit_predict(np.delete(x, 4, 0), np.delete(y, 4, 0), h, w, s,
                                                np.delete(xo, 4, 0))
     assert relmax(np.delete(mean, 4, 0), m1) < 1e-12 and relmax(np.delete(logml, 4), l1) < 1e-12
+
+
+# ---- the single-vector sweeps as one launch each (round 4) --------------------------
+@pytest.mark.parametrize("n", [2048, 2500, 4096, 5000])
+def test_flow_sweeps_same_bits_as_per_block_launches(engine, n):
+    """fit.solve(b) and alpha through the one-launch sweeps (trsvflow.h: every step's workgroups in
+    one grid, values handed over through sentinel-filled slots) against the one-launch-per-block
+    sweeps (BQ_TRSV_FLOW=0): the same arithmetic in the same order, so the same bits; and the
+    residual K x - b."""
+    import os
+    from bayesian_quadrature_amd import Engine
+    c = wl.c4(n)
+    y = wl.norm_logpdf(c["x"])
+    b = np.random.RandomState(n).randn(n)
+    fit = engine.gp_fit(c["x"], y, c["h"], c["w"] * 3.0, c["s"])
+    x1, a1 = fit.solve(b), fit.alpha()
+    K = fit.K()
+    fit.close()
+    os.environ["BQ_TRSV_FLOW"] = "0"
+    try:
+        e2 = Engine(0)
+    finally:
+        del os.environ["BQ_TRSV_FLOW"]
+    try:
+        f2 = e2.gp_fit(c["x"], y, c["h"], c["w"] * 3.0, c["s"])
+        x0, a0 = f2.solve(b), f2.alpha()
+        f2.close()
+    finally:
+        e2.close()
+    assert np.array_equal(x1, x0) and np.array_equal(a1, a0)
+    # (w = 3 dx: a wider band than C4's, cond(K) ~ 1e8 -- the bar is the residual with the device's
+    # own Gram matrix, as in test_fit_solve_at_benched_sizes)
+    assert np.abs(K.dot(x1) - b).max() < 1e-11 * np.abs(K).max() * np.abs(x1).max() * np.sqrt(n)
+    assert np.abs(K.dot(a1) - y).max() < 1e-11 * np.abs(K).max() * np.abs(a1).max() * np.sqrt(n)
+
+
+def test_flow_sweep_times_out_instead_of_hanging(engine):
+    """A lost hand-off (BQ_FLOW_FAULT=1: step 1 of the forward sweep never publishes its block)
+    ends in a time-out: every spinning workgroup leaves, the call reports a HIP failure, and the
+    same fit solves correctly right afterwards."""
+    import os
+    import time
+    n = 4096
+    c = wl.c4(n)
+    fit = engine.gp_fit(c["x"], wl.norm_logpdf(c["x"]), c["h"], c["w"] * 3.0, c["s"])
+    b = np.random.RandomState(1).randn(n)
+    good = fit.solve(b)
+    os.environ["BQ_FLOW_FAULT"] = "1"
+    t0 = time.time()
+    try:
+        with pytest.raises(RuntimeError):
+            fit.solve(b)
+    finally:
+        del os.environ["BQ_FLOW_FAULT"]
+    assert time.time() - t0 < 60.0
+    assert np.array_equal(fit.solve(b), good)
+    fit.close()
