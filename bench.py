@@ -92,7 +92,13 @@ def _trsv_traffic():
         doc = json.load(f)
     ks = doc["kernels"]
     raw, est, solves = 0.0, 0.0, None
-    for name in ("trsv_fwd_step_kernel<8>", "trsv_bwd_step_kernel"):
+    # (round 4: one launch per sweep; the summaries of rounds 2-3 hold the per-block kernels, 32
+    # launches per sweep at N = 16384)
+    names = ("trsv_fwd_flow_kernel<8>", "trsv_bwd_flow_kernel")
+    per_solve = 1.0
+    if not all(n in ks for n in names):
+        names, per_solve = ("trsv_fwd_step_kernel<8>", "trsv_bwd_step_kernel"), 32.0
+    for name in names:
         k = ks.get(name)
         if not k:
             return None
@@ -100,7 +106,7 @@ def _trsv_traffic():
         est += (k.get("FETCH_SIZE_estimate_bytes_total",
                       k.get("FETCH_SIZE_corrected_bytes_total", k.get("FETCH_SIZE_bytes_total", 0.0)))
                 + k.get("WRITE_SIZE_bytes_total", 0.0))
-        solves = k["launches"] / 32.0
+        solves = k["launches"] / per_solve
     cal = doc.get("read8_calibration")
     return {"bytes_per_solve_raw": raw / solves, "bytes_per_solve_estimate": est / solves,
             "calibration": cal,
@@ -573,10 +579,10 @@ def solve_predict_rooflines(eng):
             "algorithmic_bytes": byt,
             "traffic": _trsv_traffic() if n == 16384 else None,
             "note": "bq_gp_solve on a resident factor, one right-hand side: the GEMV sweeps "
-                    "of trsv.h, one launch per 512 columns (forward + backward), replayed "
-                    "from a hipGraph; ms = unprofiled wall time of the whole call (median of five "
-                    "groups); ms_event_brackets = eager launches under the launch profiler, "
-                    "informational"}
+                    "of trsv.h as ONE launch per sweep (trsvflow.h: all steps' workgroups in one "
+                    "grid, hand-offs through sentinel-filled slots); ms = unprofiled wall time of "
+                    "the whole call (median of five groups), host vector in and out; "
+                    "ms_event_brackets = the two launches under the launch profiler"}
         B = np.asfortranarray(rs.randn(n, 256))
         dev, cls, wall = _prof_call(eng, lambda: fit.solve(B), reps=2)
         fl = 2.0 * n * n * 256
@@ -931,7 +937,7 @@ def main():
             ach = prof[dom]["work"] / (dom_ms * 1e-3) / 1e12
             roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / PEAK_FP64_TFLOPS, "traffic": None}
-        dom_kernel = {"syrk_trailing_small": "slab_step_kernel<false>",
+        dom_kernel = {"syrk_trailing_small": "slab_step_kernel<false, 8>",
                       "syrk_trailing": TRAILING_KERNEL}.get(dom)
         if dom_kernel:
             roof["traffic"], roof["traffic_source"] = pmc_traffic(dom_kernel)

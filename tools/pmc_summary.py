@@ -1,7 +1,7 @@
-"""Condenses the rocprofv3 runs of tools/r03_profiles.sh into the small tables that are
+"""Condenses the rocprofv3 runs of tools/r04_profiles.sh into the small tables that are
 committed under profiles/ (run on the GPU box; results come back through gpurun_out/):
 
-    python3 tools/pmc_summary.py gpurun_out/r03p r03 [outdir]
+    python3 tools/pmc_summary.py gpurun_out/r04p r04 [outdir]
 
 Per pass P of tools/roofline_run.py (one rocprofv3 run each, never blended):
     <tag>_<P>_kernel_stats.csv     copy of the --stats summary of `t_<P>`
@@ -20,7 +20,8 @@ is exact for 16-B-per-lane streaming stores; FETCH_SIZE tallies 16-B-per-lane co
 at half and is UNCALIBRATED for other widths.  The raw counter is always reported.  Two
 estimates are added and labelled as such: (a) gemm_lds_kernel: C-tile share (8 B per lane,
 = WRITE_SIZE) kept, LDS-DMA share (16 B per lane) doubled -- the guide's rule; (b) the trsv step
-kernels (8 B per lane, 512 contiguous bytes per wave): raw x the factor MEASURED in the `calib`
+kernels (8 B per lane, 512 contiguous bytes per wave; since round 4 one launch per sweep,
+trsv_*_flow_kernel): raw x the factor MEASURED in the `calib`
 pass on probe_read8_kernel, which reads a known 1 GiB per launch with exactly that pattern."""
 import csv
 import glob
@@ -30,8 +31,8 @@ import re
 import shutil
 import sys
 
-PASSES = ("c2", "gram", "potrf256", "potrf_engine", "trsv", "solve256", "predict", "c5", "c3",
-          "calib")
+PASSES = ("c2", "gram", "potrf256", "potrf256_dense", "potrf_engine", "trsv", "solve256", "predict",
+          "c5", "c2x256", "c3", "calib")
 PEAK = 78.6e12
 
 
@@ -69,49 +70,54 @@ def main():
         if f:
             shutil.copy(f, os.path.join(outdir, "%s_%s_kernel_stats.csv" % (tag, p)))
     # ---- the trailing update, dispatch by dispatch -----------------------------------
-    tr = find(os.path.join(O, "t_potrf256"), "*_kernel_trace.csv")
-    summary = {}
-    if tr:
-        rows = [r for r in csv.DictReader(open(tr)) if "gemm_lds_kernel" in r["Kernel_Name"]]
-        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-        nb = 256
-        table, tot = [], {"bulk": [0, 0.0, 0], "small": [0, 0.0, 0]}
-        for r in rows:
-            wgs = int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])
-            T = int(((8 * wgs + 1) ** 0.5 - 1) / 2 + 0.5)
-            assert T * (T + 1) // 2 == wgs, (wgs, T)
-            m = 128 * T
-            ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-            fl = float(m) * m * nb
-            cls = "bulk" if wgs >= 256 else "small"     # launch_gemm's SYRK / SYRK_SMALL split
-            tot[cls][0] += 1
-            tot[cls][1] += fl
-            tot[cls][2] += ns
-            table.append((r["Dispatch_Id"], wgs, m, nb, ns, fl, cls))
-        with open(os.path.join(outdir, "%s_trailing_dispatches.csv" % tag), "w") as f:
-            f.write("# gemm_lds_kernel launches of ONE sequential N=16384 potrf, outer block 256 "
-                    "(python3 tools/roofline_run.py potrf256 under rocprofv3 --kernel-trace); "
-                    "flop = m^2 nb (the lower half of 2 m^2 nb)\n")
-            f.write("dispatch_id,workgroups,m,nb,duration_ns,algorithmic_flop,class\n")
-            for t in table:
-                f.write("%s,%d,%d,%d,%d,%.0f,%s\n" % t)
-            for cls in ("bulk", "small"):
-                n, fl, ns = tot[cls]
-                if n:
-                    f.write("# %s: %d launches, %.4e flop, %.3f ms -> %.2f TFLOP/s = %.3f of 78.6\n"
-                            % (cls, n, fl, ns / 1e6, fl / ns / 1e3, fl / ns * 1e9 / PEAK))
-        for cls in ("bulk", "small"):
-            n, fl, ns = tot[cls]
-            if n:
-                summary[cls] = {"launches": n, "flop": fl, "ms": ns / 1e6,
-                                "tflops": fl / ns / 1e3, "frac": fl / ns * 1e9 / PEAK,
-                                "avg_launch_us": ns / n / 1e3}
+    summary, summaries = {}, {}
+    for tpass in ("potrf256", "potrf256_dense"):
+      tr = find(os.path.join(O, "t_" + tpass), "*_kernel_trace.csv")
+      summary = {}
+      if tr:
+          rows = [r for r in csv.DictReader(open(tr)) if "gemm_lds_kernel" in r["Kernel_Name"]]
+          rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+          nb = 256
+          table, tot = [], {"bulk": [0, 0.0, 0], "small": [0, 0.0, 0]}
+          for r in rows:
+              wgs = int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])
+              T = int(((8 * wgs + 1) ** 0.5 - 1) / 2 + 0.5)
+              assert T * (T + 1) // 2 == wgs, (wgs, T)
+              m = 128 * T
+              ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+              fl = float(m) * m * nb
+              cls = "bulk" if wgs >= 256 else "small"     # launch_gemm's SYRK / SYRK_SMALL split
+              tot[cls][0] += 1
+              tot[cls][1] += fl
+              tot[cls][2] += ns
+              table.append((r["Dispatch_Id"], wgs, m, nb, ns, fl, cls))
+          with open(os.path.join(outdir, "%s_trailing_dispatches%s.csv" % (tag, "" if tpass == "potrf256" else "_dense")), "w") as f:
+              f.write("# gemm_lds_kernel launches of ONE sequential N=16384 potrf, outer block 256 "
+                      "(python3 tools/roofline_run.py %s under rocprofv3 --kernel-trace); " % tpass +
+                      "flop = m^2 nb (the lower half of 2 m^2 nb)\n")
+              f.write("dispatch_id,workgroups,m,nb,duration_ns,algorithmic_flop,class\n")
+              for t in table:
+                  f.write("%s,%d,%d,%d,%d,%.0f,%s\n" % t)
+              for cls in ("bulk", "small"):
+                  n, fl, ns = tot[cls]
+                  if n:
+                      f.write("# %s: %d launches, %.4e flop, %.3f ms -> %.2f TFLOP/s = %.3f of 78.6\n"
+                              % (cls, n, fl, ns / 1e6, fl / ns / 1e3, fl / ns * 1e9 / PEAK))
+          for cls in ("bulk", "small"):
+              n, fl, ns = tot[cls]
+              if n:
+                  summary[cls] = {"launches": n, "flop": fl, "ms": ns / 1e6,
+                                  "tflops": fl / ns / 1e3, "frac": fl / ns * 1e9 / PEAK,
+                                  "avg_launch_us": ns / n / 1e3}
+      summaries[tpass] = summary
+    summary = summaries.get("potrf256", {})
     # ---- traffic ----------------------------------------------------------------------
-    out = {"_source": "tools/r03_profiles.sh: rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE, "
+    out = {"_source": "tools/r04_profiles.sh: rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE, "
                       "separate runs, one per pass of tools/roofline_run.py; bytes = KiB x 1024; "
                       "*_bytes_* are RAW counters, *_estimate_* are labelled corrections "
                       "(tools/pmc_summary.py docstring)",
-           "passes": {}, "kernels": {}, "trailing_update_from_trace": summary}
+           "passes": {}, "kernels": {}, "trailing_update_from_trace": summary,
+           "trailing_update_dense_from_trace": summaries.get("potrf256_dense", {})}
     calib = None
     for p in PASSES:
         w, f = counters(os.path.join(O, "w_" + p)), counters(os.path.join(O, "f_" + p))
@@ -137,8 +143,8 @@ def main():
                     "of a 1 GiB buffer once per launch"}
     # flat view for bench.py: the pass that owns each roofline kernel
     own = {"gemm_lds_kernel": "potrf256", "gram_tri_kernel<2>": "gram", "gram_tri_kernel<1>": "gram",
-           "trsv_fwd_step_kernel<8>": "trsv", "trsv_bwd_step_kernel": "trsv",
-           "slab_step_kernel<false>": "c2"}
+           "trsv_fwd_flow_kernel<8>": "trsv", "trsv_bwd_flow_kernel": "trsv",
+           "slab_step_kernel<false, 8>": "c2"}
     for k, p in own.items():
         e = out["passes"].get(p, {}).get(k)
         if not e:
@@ -158,30 +164,31 @@ def main():
     with open(os.path.join(outdir, "%s_pmc_traffic.json" % tag), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     # ---- MFMA utilisation ----------------------------------------------------------------
-    mu = {"_source": "tools/r03_profiles.sh: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES "
+    mu = {"_source": "tools/r04_profiles.sh: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES "
                      "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE (own runs, "
                      "counters only); mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 "
                      "XCDs x 256 CUs x 4 SIMDs)", "passes": {}}
-    for p in ("potrf256", "c5"):
+    for p in ("potrf256", "potrf256_dense", "c5"):
         cs = counters(os.path.join(O, "m_" + p))
         # the kernel that carries the pass's trailing updates: the 128-tile LDS kernel for the
         # N = 16384 factorisation, the 64-tile one for the half-batches of a C5 shard
-        kname = "gemm_lds_kernel" if p == "potrf256" else next(
+        kname = "gemm_lds_kernel" if p.startswith("potrf256") else next(
             (k for k in cs if k.startswith("gemm_lds64_kernel<false")), "gemm_lds_kernel")
         m = cs.get(kname)
         if not m:
             continue
         n = len(m["GRBM_GUI_ACTIVE"])
         sel = range(n)
-        if p == "potrf256":   # the bulk launches only (>= 256 workgroups = the first ones)
-            nbulk = summary.get("bulk", {}).get("launches", n)
+        if p.startswith("potrf256"):   # the bulk launches only (>= 256 workgroups = the first ones)
+            nbulk = summaries.get(p, {}).get("bulk", {}).get("launches", n)
             sel = range(min(n, nbulk))
         s = {c: sum(v[i] for i in sel) for c, v in m.items()}
         mu["passes"][p] = {
             "kernel": kname, "launches": len(sel), "sums": s,
             "mfma_util": s["SQ_VALU_MFMA_BUSY_CYCLES"] / (s["GRBM_GUI_ACTIVE"] / 8 * 256 * 4),
             "flop_from_MOPS": s["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0,
-            "algorithmic_flop": summary.get("bulk", {}).get("flop") if p == "potrf256" else None}
+            "algorithmic_flop": (summaries.get(p, {}).get("bulk", {}).get("flop")
+                                 if p.startswith("potrf256") else None)}
     with open(os.path.join(outdir, "%s_mfma_util.json" % tag), "w") as f:
         json.dump(mu, f, indent=1, sort_keys=True)
     print(json.dumps({"trailing": summary, "read8": out.get("read8_calibration"),

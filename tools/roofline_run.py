@@ -7,16 +7,19 @@ must be reproducible from the tracked profiles alone, so passes are never blende
   gram          gram_tri_kernel<2> at N=4096 d=2 (10 launches), gram_tri_kernel<1> at N=16384 (3)
   potrf256      ONE sequential (no look-ahead) potrf at N=16384 with the config's tile 256:
                 the trailing updates on gemm_lds_kernel in isolation
+  potrf256_dense  the same on DENSE operands (workloads.c4_dense: w = 200 dx, s = 1) -- C4's own
+                Gram is banded and feeds the update > 97 % zeros
   potrf_engine  ONE potrf at N=16384 as shipped (engine block 512, two-stream look-ahead)
-  trsv          resident N=16384 fit, 4 single-vector solves (32 + 32 trsv step launches each)
+  trsv          resident N=16384 fit, 4 single-vector solves (one launch per sweep: trsv_fwd_flow_kernel, trsv_bwd_flow_kernel)
   solve256      resident N=4096 and N=16384 fits, 2 solves with 256 right-hand sides each
   predict       resident C2 fit, 5 predictions at M=256 and 5 at M=1000
   c5            one C5 shard (64 x N=2048, M=256), 4 plan runs
+  c2x256        256 copies of the C2 problem as one plan, 4 runs
   c3            one C3 chunk (100 grid points at N=4096 d=2), 2 runs
   calib         4 read-only passes over 1 GiB with 8-byte-per-lane loads (FETCH_SIZE calibration)
 
 Used under `rocprofv3 --kernel-trace --stats` and, in separate runs, `rocprofv3 --pmc ...`
-(tools/r03_profiles.sh); tools/pmc_summary.py turns the outputs into profiles/r03_*."""
+(tools/r04_profiles.sh); tools/pmc_summary.py turns the outputs into profiles/r04_*."""
 import os
 import sys
 
@@ -27,10 +30,10 @@ from bayesian_quadrature_amd import Engine, _lib as L_  # noqa: E402
 from bayesian_quadrature_amd import workloads as wl  # noqa: E402
 
 
-def potrf_16384(e, nb, lookahead):
+def potrf_16384(e, nb, lookahead, dense=False):
     lib, ctx = e._lib, e._ctx
     n = 16384
-    c4 = wl.c4(n)
+    c4 = wl.c4_dense(n) if dense else wl.c4(n)
     w4 = np.ascontiguousarray(c4["w"])
     xd, Kd, info = e.alloc(8 * n), e.alloc(8 * n * n), e.alloc(64)
     e.upload(xd, np.ascontiguousarray(c4["x"]))
@@ -79,6 +82,8 @@ def main():
         e.free(xd), e.free(Kd)
     elif what == "potrf256":
         potrf_16384(e, 256, False)
+    elif what == "potrf256_dense":
+        potrf_16384(e, 256, False, dense=True)
     elif what == "potrf_engine":
         potrf_16384(e, 0, True)
     elif what in ("trsv", "solve256"):
@@ -113,6 +118,18 @@ def main():
             e.timer_start()
             plan.run()
             print("c5 rep", rep, "%.3f ms" % e.timer_stop_ms(), flush=True)
+        plan.close()
+    elif what == "c2x256":
+        c2 = wl.c2()
+        B = 256
+        plan = e.plan(B, 1, 1024, 256)
+        plan.set_inputs(np.repeat(c2["x"][None], B, 0), np.repeat(c2["y"][None], B, 0),
+                        np.repeat(c2["xo"][None], B, 0), c2["h"], c2["w"], c2["s"])
+        for rep in range(4):
+            e.sync()
+            e.timer_start()
+            plan.run()
+            print("c2x256 rep", rep, "%.3f ms" % e.timer_stop_ms(), flush=True)
         plan.close()
     elif what == "c3":
         import time
