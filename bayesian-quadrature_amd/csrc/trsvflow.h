@@ -58,26 +58,6 @@ __device__ __forceinline__ bool flow_again(int &it, int *abort_w)
     return true;
 }
 
-// The gate in front of a workgroup's polls: ONE lane of the workgroup watches one word of each
-// vector it is going to read (nullptr: none) until neither is the sentinel, the others wait at
-// the barrier.  Without it every wave polls all its words all the time -- 4096 resident waves
-// times 8-16 loads per microsecond on a few dozen cache lines -- and the producers' stores queue
-// behind the polls: merged 16-load polls made N = 4096 ten times slower, not faster.  The words
-// behind the gate are written at about the same time as the watched one; the full polls that
-// follow catch the stragglers.
-__device__ __forceinline__ void flow_gate(const double *w0, const double *w1, int *abort_w)
-{
-    if (threadIdx.x == 0) {
-        int it = 0;
-        for (;;) {
-            const unsigned long long a = w0 ? flow_ldu(w0) : 0ull, b = w1 ? flow_ldu(w1) : 0ull;
-            if ((a != BQ_FLOW_SENT && b != BQ_FLOW_SENT) || !flow_again(it, abort_w))
-                break;
-        }
-    }
-    __syncthreads();
-}
-
 // Hand-off words are read with raw buffer loads (buffer_load_dwordx2 ... sc1): hipcc follows every
 // relaxed atomic load with s_waitcnt vmcnt(0) -- sixteen dependent round trips per poll, which made
 // the polled sweep ten times slower than the launches it replaces -- and schedules these like any
@@ -94,6 +74,28 @@ __device__ __forceinline__ unsigned long long flow_bld(__amdgpu_buffer_rsrc_t r,
 {
     const flow_u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 16 /* sc1 */);
     return ((unsigned long long)v.y << 32) | v.x;
+}
+
+// The gate in front of a workgroup's polls: ONE lane of the workgroup watches one word of each
+// vector it is going to read (nullptr: none) until neither is the sentinel, the others wait at
+// the barrier.  Without it every wave polls all its words all the time -- 4096 resident waves
+// times 8-16 loads per microsecond on a few dozen cache lines -- and the producers' stores queue
+// behind the polls (N = 4096, both sweeps: 74 us with the gates, 97 with them on the update
+// blocks only, 126 without).  The words behind the gate are written at about the same time as
+// the watched one; the full polls that follow catch the stragglers.
+__device__ __forceinline__ void flow_gate(const double *w0, const double *w1, int *abort_w)
+{
+    if (threadIdx.x == 0) {
+        // (both words in one round trip: buffer loads; a missing word reads as zero)
+        const __amdgpu_buffer_rsrc_t r0 = flow_rsrc(w0, w0 ? 1 : 0), r1 = flow_rsrc(w1, w1 ? 1 : 0);
+        int it = 0;
+        for (;;) {
+            const unsigned long long a = flow_bld(r0, 0), b = flow_bld(r1, 0);
+            if ((a != BQ_FLOW_SENT && b != BQ_FLOW_SENT) || !flow_again(it, abort_w))
+                break;
+        }
+    }
+    __syncthreads();
 }
 
 // v[q] = p[lo + lane + 64 q] for lo + lane + 64 q < hi (else 0) and the same for (p2, lo2, hi2),
