@@ -32,7 +32,7 @@ import shutil
 import sys
 
 PASSES = ("c2", "gram", "potrf256", "potrf256_dense", "potrf_engine", "trsv", "solve256", "predict",
-          "c5", "c2x256", "c3", "calib")
+          "c5", "c5_nola", "c2x256", "c3", "calib")
 PEAK = 78.6e12
 
 

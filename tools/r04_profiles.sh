@@ -14,6 +14,11 @@ for p in c2 gram potrf256 potrf256_dense potrf_engine trsv solve256 predict c5 c
   $T -d $O/t_$p -o t -- python3 tools/roofline_run.py $p > $O/t_$p.txt 2>&1 || echo trace-$p-failed
   echo trace-$p-done
 done
+# the C5 shard once more with the diagonal factors on the main stream (BQ_LOOKAHEAD=0): every
+# kernel alone on the chip, its duration what it costs -- in the shipped pass the factors' launches
+# sit beside the update and rocprofv3 times their whole residency
+BQ_LOOKAHEAD=0 $T -d $O/t_c5_nola -o t -- python3 tools/roofline_run.py c5 > $O/t_c5_nola.txt 2>&1 || echo trace-c5-nola-failed
+echo trace-c5-nola-done
 for p in gram potrf256 trsv calib c2 solve256; do
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/w_$p -o w -- python3 tools/roofline_run.py $p > $O/w_$p.txt 2>&1 || echo w-$p-failed
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f_$p -o f -- python3 tools/roofline_run.py $p > $O/f_$p.txt 2>&1 || echo f-$p-failed
