@@ -32,6 +32,9 @@ using Potf2F = Potf2FT<4>;
 // registers before the first panel is published --, then the four 16 x 16 diagonal
 // sub-blocks (1024 doubles)
 #define BQ_POTF2F_SLOTS (16 * 256)
+#ifndef BQ_POTF2F_EARLY
+#define BQ_POTF2F_EARLY 1
+#endif
 #define BQ_POTF2F_LDS_DOUBLES (BQ_POTF2F_SLOTS + 1024)
 
 // Factor panel P (columns 4P .. 4P+3, group QP = P >> 2) held by this wave and publish it.
@@ -114,6 +117,128 @@ __device__ __forceinline__ void potf2f_update(Potf2FT<NW> &st, const double *slo
 // groups after Q of NG: bits Q+1 .. NG-1
 #define BQ_LATER(Q, NG) (((1 << (NG)) - 1) & ~((1 << ((Q) + 1)) - 1))
 
+// ---------------------------------------------------------------------------
+// The epilogue of the eight-wave factor (BQ_POTF2F_EARLY; tools/potf2_probe.py, potf2_waves.py).
+// After the last pivot the factor used to copy the four 16 x 16 diagonal sub-blocks to LDS, pass a
+// barrier, and run the reciprocal pivots and the four block inverses beside the write-back: 6,000
+// cycles behind a chain of 13,000, most of them the inverses -- sixteen dependent steps, each lane
+// of a 16-lane group running the same 120 FMAs as the other three groups' lanes.  Now:
+//   * every panel keeps a slot of its own in LDS (16 x 256 doubles -- the region is there; the ring
+//     of three was all the chain needs), so nothing is copied and no barrier follows the chain;
+//   * wave b < 4 inverts sub-block b in four slices of four steps: group g = lane / 16 keeps the rows
+//     4 g .. 4 g + 3 of unit column lane % 16, the group that holds a slice's pivot rows solves
+//     their 4 x 4 triangle, the four multipliers cross to the other groups by ds_bpermute in one
+//     go, and the groups behind apply them -- 6 + 16 FMAs per lane and slice, the same operations
+//     on the same operands in the same order as the sixteen-step form;
+//   * wave 4 takes the reciprocal pivots and the failure report, wave 5 log|K|.
+// Measured and dropped: the same slices INSIDE the chain, on the waves that have run out of columns
+// (wave w from step 8 + w on; they reach every later barrier ~500 cycles before the panel's owner).
+// Whatever those waves did -- slices of 2, 3 or 4 steps, SIMD-aware placement, lower priority, no
+// global stores before the last barrier -- stretched the owners' steps by 150-300 cycles each: the
+// chain grew from 13,700 to 15,500-16,500 cycles and the slab step gained 0.14 us where the factor
+// alone gained 1.0.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double potf2f_rcp(double dg)
+{
+    // 1 / L_cc: v_rcp_f64 + two Newton steps (the IEEE division sequence is three times as long)
+    double rc = __builtin_amdgcn_rcp(dg);
+    rc = __builtin_fma(__builtin_fma(-dg, rc, 1.0), rc, rc);
+    rc = __builtin_fma(__builtin_fma(-dg, rc, 1.0), rc, rc);
+    return rc;
+}
+
+// steps 4 S .. 4 S + 3 of sub-block b's inversion.  Column 4 S + s of the sub-block is column s of
+// panel 4 b + S, rows 16 b .. 16 b + 15, in that panel's slot.  rc: 1 / L_tt of the sub-block's
+// column t in lane t.
+template <int S>
+__device__ __forceinline__ void potf2f_inv_slice(double (&sv4)[4], double (&wc)[12], double (&wl)[4],
+                                                 const double *slots, int b, double rc, int lane)
+{
+    const int g = lane >> 4, j = lane & 15;
+    const double *base = slots + (256 * (4 * b + S) + 16 * b);
+    double d[4][4], mb[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r > s)
+                d[s][r] = base[64 * s + 4 * S + r];
+            if (S < 3)
+                mb[s][r] = base[64 * s + 4 * g + r];
+        }
+    double t[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        t[r] = sv4[r];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        wl[s] = t[s] * readlane_f64(rc, 4 * S + s);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r > s)
+                t[r] = __builtin_fma(-d[s][r], wl[s], t[r]);
+    }
+    if (S == 3)
+        return; // the last four rows of W stay in group 3: nobody is left to apply them
+    double wk[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        wk[s] = __shfl(wl[s], 16 * S + j, 64);
+        wc[4 * S + s] = wk[s];
+    }
+    // (every group applies them: the rows of the groups up to S are never read again, and
+    // without the branch the compiler is free to issue the next slice's LDS reads early)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            sv4[r] = __builtin_fma(-mb[s][r], wk[s], sv4[r]);
+}
+
+// W_b = inverse of sub-block b by one wave, out of the panels' slots
+__device__ __forceinline__ void potf2f_inverse(const double *slots, int b, double *__restrict__ Wb,
+                                               int lane)
+{
+    const int g = lane >> 4, j = lane & 15;
+    const double rc = potf2f_rcp(slots[256 * (4 * b + (j >> 2)) + 64 * (j & 3) + 16 * b + j]);
+    double sv4[4], wc[12], wl[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        sv4[r] = (4 * g + r == j) ? 1.0 : 0.0;
+    potf2f_inv_slice<0>(sv4, wc, wl, slots, b, rc, lane);
+    potf2f_inv_slice<1>(sv4, wc, wl, slots, b, rc, lane);
+    potf2f_inv_slice<2>(sv4, wc, wl, slots, b, rc, lane);
+    potf2f_inv_slice<3>(sv4, wc, wl, slots, b, rc, lane);
+    if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            Wb[16 * lane + i] = wc[i];
+    }
+    if (lane >= 48) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            Wb[16 * j + 12 + s] = wl[s];
+    }
+}
+
+// sum over the wave, the same value in every lane: DPP row_shr within the rows of 16, the four row
+// sums by v_readlane (a __shfl_down tree is six LDS round trips for a double)
+__device__ __forceinline__ double potf2f_wave_sum(double v)
+{
+#define BQ_DPP_ADD(CTRL)                                                                           \
+    {                                                                                              \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);    \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);    \
+        v += __hiloint2double(hi, lo);                                                             \
+    }
+    BQ_DPP_ADD(0x111) // row_shr:1
+    BQ_DPP_ADD(0x112)
+    BQ_DPP_ADD(0x114)
+    BQ_DPP_ADD(0x118)
+#undef BQ_DPP_ADD
+    return (readlane_f64(v, 15) + readlane_f64(v, 31)) + (readlane_f64(v, 47) + readlane_f64(v, 63));
+}
+
 // Step P, entered with panel P factored by its owner (wave P & 3) and on its way to slot
 // P % 3 of the ring; ONE workgroup barrier per panel:
 //   * the owner of panel P + 1 brings only that panel up to date, runs its pivot chain and
@@ -122,7 +247,7 @@ __device__ __forceinline__ void potf2f_update(Potf2FT<NW> &st, const double *slo
 //     before step P + 1) and applies its own panel P to its later groups;
 //   * the other two waves apply panel P to everything of theirs that lies behind it.
 // wst (profiling probe only): every wave's arrival at and release from barrier P.
-template <int P, int NW = 4, bool PAD = false>
+template <int P, int NW = 4, bool PAD = false, bool EARLY = false>
 struct Potf2FSteps {
     // PAD, nreal: the block's rows / columns from nreal on are identity padding (a system whose
     // size is not a multiple of 64): panels that lie wholly in it are neither factored nor applied
@@ -135,11 +260,13 @@ struct Potf2FSteps {
         constexpr int QP = P / NW, WP = P % NW;
         constexpr int PN = P < 15 ? P + 1 : 15, QN = PN / NW, WN = PN % NW;
         constexpr int LATER = BQ_LATER(QP, NG);
-        const double *slot = slots + (P % 3) * 256;
+        // (EARLY: every panel keeps a slot of its own)
+        const double *slot = slots + (EARLY ? P : P % 3) * 256;
+        // (eight waves: arrivals only, wst[8 P + w])
         if (wst && lane == 0)
-            wst[(NW * P + w) * 2] = (long long)__builtin_amdgcn_s_memtime();
+            wst[NW == 8 ? 8 * P + w : (NW * P + w) * 2] = (long long)__builtin_amdgcn_s_memtime();
         __syncthreads(); // panel P is published
-        if (wst && lane == 0)
+        if (NW == 4 && wst && lane == 0)
             wst[(NW * P + w) * 2 + 1] = (long long)__builtin_amdgcn_s_memtime();
         double li[4];
 #pragma unroll
@@ -148,11 +275,11 @@ struct Potf2FSteps {
         if (P < 15 && w == WN) {
             if (!PAD || 4 * PN < nreal) {
                 potf2f_update<(1 << QN), NW>(st, slot, li, w);
-                potf2f_factor<PN, NW>(st, slots + (PN % 3) * 256, lane);
+                potf2f_factor<PN, NW>(st, slots + (EARLY ? PN : PN % 3) * 256, lane);
             }
         } else if (w == WP) {
             if (P >= 1 && LATER != 0) {
-                const double *prev = slots + ((P + 2) % 3) * 256;
+                const double *prev = slots + (EARLY ? P - 1 : (P + 2) % 3) * 256;
                 double lp[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
@@ -166,11 +293,11 @@ struct Potf2FSteps {
             potf2f_update<LATER, NW>(st, slot, li, w);
         }
         if (!PAD || 4 * (P + 1) < nreal)
-            Potf2FSteps<P + 1, NW, PAD>::run(st, slots, w, lane, wst, nreal);
+            Potf2FSteps<P + 1, NW, PAD, EARLY>::run(st, slots, w, lane, wst, nreal);
     }
 };
-template <int NW, bool PAD>
-struct Potf2FSteps<16, NW, PAD> {
+template <int NW, bool PAD, bool EARLY>
+struct Potf2FSteps<16, NW, PAD, EARLY> {
     static __device__ __forceinline__ void run(Potf2FT<NW> &, double *, int, int, long long *, int)
     {
     }
@@ -216,6 +343,43 @@ __device__ __forceinline__ void potf2f_body(double *__restrict__ Ab, long lda, i
     // stamps[5] != 0 -- they cost the chain 2,500 cycles)
     // (only the assembly's first factor passes nreal -- a system of fewer than 64 points has no
     // other --: inside slab_step_kernel the second instantiation cost C2 0.4 us per step)
+    if (NW == 8 && BQ_POTF2F_EARLY && nreal >= 64) {
+        // (eight waves, full block: the epilogue straight out of the panels' slots)
+        const double ld0 = logdet ? *logdet : 0.0; // one writer per launch, launches in order
+        Potf2FSteps<0, NW, false, NW == 8>::run(st, slots, w, lane,
+                                                (stamps && stamps[5] != 0) ? stamps + 8 : nullptr,
+                                                64);
+        BQ_STAMP(2);
+        BQ_STAMP(3);
+        // write back the lower triangle of my columns (the stores drain under what follows)
+        {
+            double *pw = Ab + lane + (long)(4 * w) * lda;
+            asm volatile("" : "+v"(pw));
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (lane >= 4 * (NW * q + w) + s)
+                        pw[(long)s * lda] = st.a[q][s];
+                pw += 4 * NW * lda;
+            }
+        }
+        if (w < 4) {
+            potf2f_inverse(slots, w, dinv_b + 64 + 256 * w, lane);
+        } else if (w == 4) {
+            const double dg = slots[256 * (lane >> 2) + 64 * (lane & 3) + lane];
+            dinv_b[lane] = potf2f_rcp(dg);
+            const unsigned long long badm = __ballot(!(dg > 0.0) || !(dg < 1.7e308));
+            if (lane == 0 && badm != 0ull && info_b[0] == 0)
+                info_b[0] = j0 + __builtin_ctzll(badm) + 1;
+        } else if (w == 5 && logdet) {
+            const double lg = potf2f_wave_sum(log(slots[256 * (lane >> 2) + 64 * (lane & 3) + lane]));
+            if (lane == 0)
+                *logdet = ld0 + 2.0 * lg;
+        }
+        BQ_STAMP(4);
+        return;
+    }
     if (nreal < 64)
         Potf2FSteps<0, NW, true>::run(st, slots, w, lane, nullptr, nreal > 0 ? nreal : 1);
     else
