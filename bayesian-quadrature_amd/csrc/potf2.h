@@ -118,7 +118,7 @@ __device__ __forceinline__ void potf2f_update(Potf2FT<NW> &st, const double *slo
 #define BQ_LATER(Q, NG) (((1 << (NG)) - 1) & ~((1 << ((Q) + 1)) - 1))
 
 // ---------------------------------------------------------------------------
-// The epilogue of the eight-wave factor (BQ_POTF2F_EARLY; tools/potf2_probe.py, potf2_waves.py).
+// The epilogue of a full block's factor (BQ_POTF2F_EARLY; tools/potf2_probe.py, potf2_waves.py).
 // After the last pivot the factor used to copy the four 16 x 16 diagonal sub-blocks to LDS, pass a
 // barrier, and run the reciprocal pivots and the four block inverses beside the write-back: 6,000
 // cycles behind a chain of 13,000, most of them the inverses -- sixteen dependent steps, each lane
@@ -130,7 +130,8 @@ __device__ __forceinline__ void potf2f_update(Potf2FT<NW> &st, const double *slo
 //     their 4 x 4 triangle, the four multipliers cross to the other groups by ds_bpermute in one
 //     go, and the groups behind apply them -- 6 + 16 FMAs per lane and slice, the same operations
 //     on the same operands in the same order as the sixteen-step form;
-//   * wave 4 takes the reciprocal pivots and the failure report, wave 5 log|K|.
+//   * waves 4-7 write the factor home out of the slots; wave 4 also takes the reciprocal pivots and
+//     the failure report, wave 5 log|K|.
 // Measured and dropped: the same slices INSIDE the chain, on the waves that have run out of columns
 // (wave w from step 8 + w on; they reach every later barrier ~500 cycles before the panel's owner).
 // Whatever those waves did -- slices of 2, 3 or 4 steps, SIMD-aware placement, lower priority, no
@@ -148,35 +149,35 @@ __device__ __forceinline__ double potf2f_rcp(double dg)
 }
 
 // steps 4 S .. 4 S + 3 of sub-block b's inversion.  Column 4 S + s of the sub-block is column s of
-// panel 4 b + S, rows 16 b .. 16 b + 15, in that panel's slot.  rc: 1 / L_tt of the sub-block's
-// column t in lane t.
+// panel 4 b + S, rows 16 b .. 16 b + 15, in that panel's slot.  rcv[r]: 1 / L_ii of this lane's row
+// i = 4 g + r.  Every lane runs the pivot rows' 4 x 4 substitution on a copy of ITS rows with ITS
+// rows' entries (mb) -- in group S those are the pivot rows and the pivot triangle, and it is group
+// S's result that crosses to the others.
 template <int S>
 __device__ __forceinline__ void potf2f_inv_slice(double (&sv4)[4], double (&wc)[12], double (&wl)[4],
-                                                 const double *slots, int b, double rc, int lane)
+                                                 const double *slots, int b,
+                                                 const double (&rcv)[4], int lane)
 {
     const int g = lane >> 4, j = lane & 15;
     const double *base = slots + (256 * (4 * b + S) + 16 * b);
-    double d[4][4], mb[4][4];
+    double mb[4][4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (r > s)
-                d[s][r] = base[64 * s + 4 * S + r];
-            if (S < 3)
+        for (int r = 0; r < 4; ++r)
+            if (S < 3 || r > s)
                 mb[s][r] = base[64 * s + 4 * g + r];
-        }
     double t[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         t[r] = sv4[r];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        wl[s] = t[s] * readlane_f64(rc, 4 * S + s);
+        wl[s] = t[s] * rcv[s];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (r > s)
-                t[r] = __builtin_fma(-d[s][r], wl[s], t[r]);
+                t[r] = __builtin_fma(-mb[s][r], wl[s], t[r]);
     }
     if (S == 3)
         return; // the last four rows of W stay in group 3: nobody is left to apply them
@@ -200,15 +201,20 @@ __device__ __forceinline__ void potf2f_inverse(const double *slots, int b, doubl
                                                int lane)
 {
     const int g = lane >> 4, j = lane & 15;
+    // 1 / L_tt of the sub-block's column t in lane t, then this lane's rows' four
     const double rc = potf2f_rcp(slots[256 * (4 * b + (j >> 2)) + 64 * (j & 3) + 16 * b + j]);
+    double rcv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        rcv[r] = __shfl(rc, 4 * g + r, 64);
     double sv4[4], wc[12], wl[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         sv4[r] = (4 * g + r == j) ? 1.0 : 0.0;
-    potf2f_inv_slice<0>(sv4, wc, wl, slots, b, rc, lane);
-    potf2f_inv_slice<1>(sv4, wc, wl, slots, b, rc, lane);
-    potf2f_inv_slice<2>(sv4, wc, wl, slots, b, rc, lane);
-    potf2f_inv_slice<3>(sv4, wc, wl, slots, b, rc, lane);
+    potf2f_inv_slice<0>(sv4, wc, wl, slots, b, rcv, lane);
+    potf2f_inv_slice<1>(sv4, wc, wl, slots, b, rcv, lane);
+    potf2f_inv_slice<2>(sv4, wc, wl, slots, b, rcv, lane);
+    potf2f_inv_slice<3>(sv4, wc, wl, slots, b, rcv, lane);
     if (lane < 16) {
 #pragma unroll
         for (int i = 0; i < 12; ++i)
@@ -343,16 +349,32 @@ __device__ __forceinline__ void potf2f_body(double *__restrict__ Ab, long lda, i
     // stamps[5] != 0 -- they cost the chain 2,500 cycles)
     // (only the assembly's first factor passes nreal -- a system of fewer than 64 points has no
     // other --: inside slab_step_kernel the second instantiation cost C2 0.4 us per step)
-    if (NW == 8 && BQ_POTF2F_EARLY && nreal >= 64) {
-        // (eight waves, full block: the epilogue straight out of the panels' slots)
+    if (BQ_POTF2F_EARLY && nreal >= 64) {
+        // (a full block: the epilogue straight out of the panels' slots)
         const double ld0 = logdet ? *logdet : 0.0; // one writer per launch, launches in order
-        Potf2FSteps<0, NW, false, NW == 8>::run(st, slots, w, lane,
-                                                (stamps && stamps[5] != 0) ? stamps + 8 : nullptr,
-                                                64);
+        Potf2FSteps<0, NW, false, true>::run(
+            st, slots, w, lane,
+            (stamps && stamps[5] != 0) ? stamps + 8 : nullptr, 64);
         BQ_STAMP(2);
         BQ_STAMP(3);
-        // write back the lower triangle of my columns (the stores drain under what follows)
-        {
+        // The factor goes home (the stores drain under the inverses).  Eight waves: waves 0-3 go
+        // straight to the inverses and waves 4-7 write sixteen columns each out of the panels'
+        // slots; four waves: every wave its own columns out of its registers.
+        if (NW == 8 && w >= 4) {
+            const int c0 = 16 * (w - 4);
+            double *pw = Ab + lane + (long)c0 * lda;
+            const double *ps = slots + 64 * c0 + lane; // column c: panel c / 4, its column c % 4
+            asm volatile("" : "+v"(pw));
+            double col[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                col[c] = ps[64 * c];
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (lane >= c0 + c)
+                    pw[(long)c * lda] = col[c];
+        }
+        if (NW == 4) {
             double *pw = Ab + lane + (long)(4 * w) * lda;
             asm volatile("" : "+v"(pw));
 #pragma unroll
@@ -364,15 +386,18 @@ __device__ __forceinline__ void potf2f_body(double *__restrict__ Ab, long lda, i
                 pw += 4 * NW * lda;
             }
         }
-        if (w < 4) {
+        // reciprocal pivots + failure report and log|K|: waves 4 and 5 of eight, else 1 and 2
+        constexpr int WR = NW == 8 ? 4 : 1, WL = NW == 8 ? 5 : 2;
+        if (w < 4)
             potf2f_inverse(slots, w, dinv_b + 64 + 256 * w, lane);
-        } else if (w == 4) {
+        if (w == WR) {
             const double dg = slots[256 * (lane >> 2) + 64 * (lane & 3) + lane];
             dinv_b[lane] = potf2f_rcp(dg);
             const unsigned long long badm = __ballot(!(dg > 0.0) || !(dg < 1.7e308));
             if (lane == 0 && badm != 0ull && info_b[0] == 0)
                 info_b[0] = j0 + __builtin_ctzll(badm) + 1;
-        } else if (w == 5 && logdet) {
+        }
+        if (w == WL && logdet) {
             const double lg = potf2f_wave_sum(log(slots[256 * (lane >> 2) + 64 * (lane & 3) + lane]));
             if (lane == 0)
                 *logdet = ld0 + 2.0 * lg;
