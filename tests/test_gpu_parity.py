@@ -1070,6 +1070,60 @@ def test_predict_m1000_at_benched_size(engine, oracle):
     fit.close()
 
 
+def test_diagonal_factor_block_inverses_and_pivots(engine):
+    """The 64 x 64 diagonal factor alone (bq_probe_potf2: four and eight waves, the block read from
+    global memory and handed over through LDS): L against LAPACK, the reciprocal pivots, and the four
+    16 x 16 block inverses every panel solve multiplies by -- W_b L_bb = I to rounding --; the four
+    forms agree bit for bit (the epilogue's slices over the lane groups apply the substitution's
+    operations in the substitution's order); a non-positive pivot is reported at its column."""
+    import ctypes as C
+    from bayesian_quadrature_amd import _lib as L
+
+    def probe(A, flags):
+        A = np.asfortranarray(A, dtype=np.float64)
+        Lo = np.zeros((64, 64), order="F")
+        dv = np.zeros(64 + 4 * 256)
+        info = C.c_int32(0)
+        us = C.c_double(0)
+        st = (C.c_int64 * 136)()
+        engine._check(engine._lib.bq_probe_potf2(engine._ctx, L.dptr(A), flags, 2, L.dptr(Lo),
+                                                 L.dptr(dv), C.byref(info),
+                                                 C.cast(C.byref(us), L._dp), st))
+        return np.tril(Lo), dv, info.value
+
+    rs = np.random.RandomState(11)
+    x = np.linspace(-5, 5, 1024)[:64]
+    dx = 10.0 / 1023
+    K = np.exp(-0.5 * (x[:, None] - x[None]) ** 2 / dx ** 2) / (np.sqrt(2 * np.pi) * dx)
+    K += 1e-6 * np.eye(64)
+    S = rand_spd(rs, 64)
+    for A in (K, S):
+        Lr = np.linalg.cholesky(A)
+        outs = [probe(A, fl) for fl in (0, 1, 2, 3)]
+        for Lo, dv, info in outs:
+            assert info == 0
+            assert np.max(np.abs(Lo - Lr)) <= 1e-13 * np.max(np.abs(Lr))
+            assert np.max(np.abs(dv[:64] * np.diag(Lr) - 1.0)) < 1e-13
+            for b in range(4):
+                W = np.tril(dv[64 + 256 * b:64 + 256 * (b + 1)].reshape(16, 16, order="F"))
+                Lb = Lr[16 * b:16 * b + 16, 16 * b:16 * b + 16]
+                assert np.max(np.abs(W.dot(Lb) - np.eye(16))) < 1e-12
+        for Lo, dv, info in outs[1:]:
+            assert np.array_equal(Lo, outs[0][0])
+            assert np.array_equal(dv[:64], outs[0][1][:64])
+            for b in range(4):
+                Wa = dv[64 + 256 * b:64 + 256 * (b + 1)].reshape(16, 16, order="F")
+                Wr = outs[0][1][64 + 256 * b:64 + 256 * (b + 1)].reshape(16, 16, order="F")
+                assert np.array_equal(np.tril(Wa), np.tril(Wr))
+    B = S.copy()
+    Lr = np.linalg.cholesky(S)
+    B[37, 37] = Lr[37, :37].dot(Lr[37, :37]) - 1e-3
+    for fl in (0, 1, 2, 3):
+        Lo, dv, info = probe(B, fl)
+        assert info == 38
+        assert np.max(np.abs(Lo[:, :37] - Lr[:, :37])) < 1e-12
+
+
 def test_potf2_eight_waves_is_the_same_factor(engine):
     """The one-launch steps' diagonal factor on eight waves (slab_step_kernel<., 8>,
     potf2f_body<8>; BQ_POTF2_8W, read when a context is created) applies the same updates to
