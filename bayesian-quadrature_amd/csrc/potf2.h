@@ -8,7 +8,8 @@
 // rows (lane = row) and a quarter of the columns: wave w owns the columns 16q + 4w + s
 // (q, s = 0..3), i.e. the matrix is cut into sixteen 4-column panels dealt round-robin to the
 // waves.  Panel p is factored by its owner (in-panel updates by v_readlane) and published to
-// a ring of three LDS slots; after ONE workgroup barrier per panel every wave applies the
+// its LDS slot (a full block keeps all sixteen -- the epilogue reads the factor out of them --, a
+// padded one a ring of three); after ONE workgroup barrier per panel every wave applies the
 // rank-4 update to its own later columns.  What was measured on gfx950 and shaped this file
 // (tools/potf2_probe.py, per-wave barrier stamps):
 //   * a wave's time per panel is set by the waves that only update in the early panels
@@ -27,7 +28,7 @@ template <int NW> struct Potf2FT {
 };
 using Potf2F = Potf2FT<4>;
 
-// LDS of the factor: a ring of three panel slots (4 x 64 doubles each) inside the first 4096
+// LDS of the factor: the panels' slots (4 x 64 doubles each: sixteen, or a ring of three) in the first 4096
 // doubles -- the region may hold the factor's own input block, which every wave has in
 // registers before the first panel is published --, then the four 16 x 16 diagonal
 // sub-blocks (1024 doubles)
@@ -246,7 +247,7 @@ __device__ __forceinline__ double potf2f_wave_sum(double v)
 }
 
 // Step P, entered with panel P factored by its owner (wave P & 3) and on its way to slot
-// P % 3 of the ring; ONE workgroup barrier per panel:
+// P % 3 of the ring (EARLY: slot P); ONE workgroup barrier per panel:
 //   * the owner of panel P + 1 brings only that panel up to date, runs its pivot chain and
 //     publishes; what its later groups owe panel P waits until step P + 1;
 //   * the owner of panel P pays that debt for panel P - 1 (slot (P - 1) % 3 is not reused
