@@ -124,6 +124,8 @@ static int ctx_init(bq_ctx *c, int device)
         c->pair_border = std::atoi(e);
     if (const char *e = std::getenv("BQ_DF_HALVES"))
         c->df_halves = std::atoi(e);
+    if (const char *e = std::getenv("BQ_ROWS_TAIL"))
+        c->rows_tail = std::atoi(e);
     if (const char *e = std::getenv("BQ_DF_SHARING"))
         c->df_sharing = std::atoi(e);
     if (const char *e = std::getenv("BQ_LA_MIN"))

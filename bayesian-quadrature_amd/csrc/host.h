@@ -96,6 +96,7 @@ struct bq_ctx {
     int pair_border = 1; // bq_pair_esm as S factorisations + border rows (BQ_PAIR_BORDER=0: the S Ma
                          // full bordered systems)
     int df_halves = 0;   // the diagonal-first sweep as two half-batches on the two streams (BQ_DF_HALVES)
+    int rows_tail = 128; // a large row sweep's last updates as split-k tiles: from this many LDS tiles down (BQ_ROWS_TAIL)
     int df_sharing = 0;  // gemm_lds_tile's sharing mode while a diagonal factor runs beside an update
                          // (0: the rule of a product alone -- C5 shard 5.73 ms against 6.05 with 1)
     int la_min = 3072;   // look-ahead only while the bulk update has at least this many rows (BQ_LA_MIN)
@@ -177,7 +178,7 @@ inline unsigned long long launch_config_key(const bq_ctx *c)
     const int f[] = {c->nb_override, c->lookahead, c->split_batch, c->la_min, c->gemm_lds,
                      c->gemm_lds64, c->slab_nb_max, c->slab_max, c->fold_readout, c->potf2_8w,
                      c->gemm_ksplit, c->gemm_tile, c->diag_first, c->df_sweep, c->df_wg,
-                     c->df_halves, c->df_sharing};
+                     c->df_halves, c->df_sharing, c->rows_tail};
     unsigned long long h = 1469598103934665603ull;
     for (int v : f)
         h = (h ^ (unsigned long long)(unsigned)v) * 1099511628211ull;

@@ -226,6 +226,32 @@ static int rows_fused(bq_ctx *c, bool forward, double *Xin, double *Xout, long l
                 Qu = L + Jp;
             }
         }
+        // The last steps' updates are few 64 x 64 tiles of one k loop each (22 us however few):
+        // there the update goes out as 32 x 32 split-k tiles too (rows_step_kernel), a quarter of
+        // a tile's k loop per wave.  rows_tail: from how many LDS tiles down in the forward sweep
+        // (0: never); the backward sweep's Q is strided across a tile's columns there and gains
+        // only from a quarter of that on (N = 4096, 256 rows, step times in us, forward 30 26 26 25
+        // 17 -> 29 23 21 17 16, backward 28 26 26 25 19 -> 28 26 26 19 19; tools/rows_tail_check.py).
+        const long lds_tiles = (long)(mrows / 64) * (nu / 64);
+        if (!first && nu > 0 && c->rows_tail > 0 &&
+            lds_tiles <= (forward ? c->rows_tail : c->rows_tail / 4) &&
+            (mrows % 32) == 0 && (nu % 32) == 0 && (bp % 16) == 0) {
+            RowsJob b = a;
+            b.C = Cu;
+            b.P1 = Pu;
+            b.ldp1 = ldx;
+            b.Q1 = Qu;
+            b.qsj1 = forward ? 1 : ldq;
+            b.qsk1 = forward ? ldq : 1;
+            b.k1 = bp;
+            b.k2 = 0;
+            b.P2 = b.P1, b.Q2 = b.Q1, b.ldp2 = ldx, b.qsj2 = b.qsj1, b.qsk2 = b.qsk1;
+            b.ny = nu / 32;
+            b.write = 0;
+            BQCHK(launch_rows_step(c, mrows, a, b,
+                                   2.0 * mrows * ((double)bJ * (a.k1 + a.k2) + (double)nu * bp)));
+            continue;
+        }
         BQCHK(launch_rows_fused(c, mrows, a, Cu, ldx, Pu, ldx, Qu, ldq, nu, bp, !forward,
                                 2.0 * mrows * ((double)bJ * (a.k1 + a.k2) + (double)nu * bp)));
     }
