@@ -126,6 +126,8 @@ static int ctx_init(bq_ctx *c, int device)
         c->df_halves = std::atoi(e);
     if (const char *e = std::getenv("BQ_ROWS_TAIL"))
         c->rows_tail = std::atoi(e);
+    if (const char *e = std::getenv("BQ_SOLVE_KCOPY"))
+        c->solve_kcopy = std::atoi(e);
     if (const char *e = std::getenv("BQ_DF_SHARING"))
         c->df_sharing = std::atoi(e);
     if (const char *e = std::getenv("BQ_LA_MIN"))

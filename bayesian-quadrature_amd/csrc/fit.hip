@@ -119,8 +119,9 @@ int fit_wide(bq_ctx *c, bq_fit *f, WideInv &w)
 // the single-vector workspace of a fit (x at vec, y at vec + npad)
 int fit_vec(bq_ctx *c, bq_fit *f)
 {
-    // x | y | the one-launch sweeps' workspace (ticket + x versions)
-    const size_t need = 2 * (size_t)f->npad + trsv_flow_ws_doubles(f->npad, wide_block(f->npad));
+    // x | y | the one-launch sweeps' workspace (ticket + x versions) | a solve's second vector
+    // and second workspace (bq_gp_solve: both sweeps' slots are filled in one launch)
+    const size_t need = 3 * (size_t)f->npad + 2 * trsv_flow_ws_doubles(f->npad, wide_block(f->npad));
     if (f->vec.bytes < sizeof(double) * need)
         HIPCHK(c, f->vec.alloc(sizeof(double) * need));
     if (!f->hvec)

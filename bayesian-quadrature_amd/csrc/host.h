@@ -97,6 +97,7 @@ struct bq_ctx {
                          // full bordered systems)
     int df_halves = 0;   // the diagonal-first sweep as two half-batches on the two streams (BQ_DF_HALVES)
     int rows_tail = 128; // a large row sweep's last updates as split-k tiles: from this many LDS tiles down (BQ_ROWS_TAIL)
+    int solve_kcopy = 1; // a one-vector solve's vector in / out and sentinel fill by kernels (BQ_SOLVE_KCOPY)
     int df_sharing = 0;  // gemm_lds_tile's sharing mode while a diagonal factor runs beside an update
                          // (0: the rule of a product alone -- C5 shard 5.73 ms against 6.05 with 1)
     int la_min = 3072;   // look-ahead only while the bulk update has at least this many rows (BQ_LA_MIN)
@@ -359,10 +360,16 @@ int launch_trsv_bwd(bq_ctx *c, const double *L, long ldl, int J, int bJ, int B, 
                     const double *nt, const double *uu, double *x, double *y, double work);
 // a whole sweep in one launch (trsvflow.h); flow_check: BQ_ERR_HIP if a hand-off of a sweep that
 // has completed on the stream timed out (call after synchronising)
-bool trsv_flow_ok(const bq_ctx *c, int npad, int B);
+bool trsv_flow_ok(const bq_ctx *c, int npad, int B, bool prefilled = false);
 size_t trsv_flow_ws_doubles(int npad, int B);
+// preset: ws and y hold the sentinel already (launch_flow_in: the right-hand side in from a mapped
+// pinned vector + every hand-off slot of both sweeps, one launch; launch_flow_out: the solution out)
 int launch_trsv_flow(bq_ctx *c, bool forward, const double *L, long ldl, int npad, int B,
-                     const double *m1, const double *m2, const double *x0, double *y, double *ws);
+                     const double *m1, const double *m2, const double *x0, double *y, double *ws,
+                     bool preset = false);
+int launch_flow_in(bq_ctx *c, const double *hsrc, int n, double *x, int npad, double *fill,
+                   size_t nfill);
+int launch_flow_out(bq_ctx *c, const double *x, int n, double *hdst);
 int flow_check(bq_ctx *c);
 
 // ---- potrf.hip ------------------------------------------------------------------------

@@ -151,16 +151,36 @@ size_t trsv_flow_ws_doubles(int npad, int B)
     return 8 + (size_t)(ns > 1 ? ns - 1 : 0) * npad;
 }
 
-bool trsv_flow_ok(const bq_ctx *c, int npad, int B)
+bool trsv_flow_ok(const bq_ctx *c, int npad, int B, bool prefilled)
 {
-    // (below 2048 rows the sweep is two to four steps: the memsets cost what the launches did)
+    // (below 2048 rows the sweep is two to four steps: the memsets cost what the launches did --
+    // unless the caller fills the slots on its way in, bq_gp_solve: then from 1024 rows, half the
+    // threshold: n = 1000 0.061 -> 0.053 ms, 1536 0.077 -> 0.074)
     return c->trsv_flow && c->flow_abort && B <= 512 && (B & 63) == 0 && (npad & 63) == 0 &&
-           npad >= c->trsv_flow_min && (npad + B - 1) / B >= 2;
+           npad >= (prefilled ? c->trsv_flow_min / 2 : c->trsv_flow_min) && (npad + B - 1) / B >= 2;
 }
 
 // ws: trsv_flow_ws_doubles(npad, B) doubles; x0 is read, y written (npad each)
+int launch_flow_in(bq_ctx *c, const double *hsrc, int n, double *x, int npad, double *fill,
+                   size_t nfill)
+{
+    const long blocks = std::min<long>(1024, (std::max<long>(npad, (long)nfill) + 255) / 256);
+    hipLaunchKernelGGL(flow_in_kernel, dim3((unsigned)blocks), dim3(256), 0, c->cur, hsrc, n, x, npad,
+                       reinterpret_cast<unsigned long long *>(fill), (long)nfill);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+int launch_flow_out(bq_ctx *c, const double *x, int n, double *hdst)
+{
+    hipLaunchKernelGGL(flow_out_kernel, dim3((n + 255) / 256), dim3(256), 0, c->cur, x, n, hdst);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
 int launch_trsv_flow(bq_ctx *c, bool forward, const double *L, long ldl, int npad, int B,
-                     const double *m1, const double *m2, const double *x0, double *y, double *ws)
+                     const double *m1, const double *m2, const double *x0, double *y, double *ws,
+                     bool preset)
 {
     const int ns = (npad + B - 1) / B, last = (npad - 1) / B * B;
     long blocks = 0;
@@ -173,8 +193,11 @@ int launch_trsv_flow(bq_ctx *c, bool forward, const double *L, long ldl, int npa
         work += (double)bJ * bJ + 2.0 * B * (bJ + 64.0 * nupd);
     }
     // every slot starts as the sentinel (all bits set); the ticket counter starts at -1 with it
-    HIPCHK(c, hipMemsetAsync(ws, 0xFF, sizeof(double) * trsv_flow_ws_doubles(npad, B), c->cur));
-    HIPCHK(c, hipMemsetAsync(y, 0xFF, sizeof(double) * (size_t)npad, c->cur));
+    // (preset: the caller has filled ws and y already -- flow_in_kernel, both sweeps of a solve)
+    if (!preset) {
+        HIPCHK(c, hipMemsetAsync(ws, 0xFF, sizeof(double) * trsv_flow_ws_doubles(npad, B), c->cur));
+        HIPCHK(c, hipMemsetAsync(y, 0xFF, sizeof(double) * (size_t)npad, c->cur));
+    }
     // (BQ_FLOW_FAULT=1, read per launch: the forward sweep loses a hand-off -- tests of the time-out)
     const int fault = std::getenv("BQ_FLOW_FAULT") ? std::atoi(std::getenv("BQ_FLOW_FAULT")) : 0;
     Bracket br(c, BQ_K_GEMM, work);

@@ -392,14 +392,42 @@ extern "C" int bq_gp_solve(bq_ctx *c, bq_fit *f, const double *B, int64_t nrhs, 
         // through the fit's pinned staging vector (zero padded): truly asynchronous copies
         std::memcpy(f->hvec, B, sizeof(double) * n);
         std::memset(f->hvec + n, 0, sizeof(double) * (npad - n));
-        HIPCHK(c, hipMemcpyAsync(x, f->hvec, sizeof(double) * npad, hipMemcpyHostToDevice,
-                                 c->stream));
+        if (c->solve_kcopy && trsv_flow_ok(c, npad, wv.B, true)) {
+            // [x | y | ws_f | x_out | ws_b]: the vector comes in and goes out through kernels on
+            // the mapped pinned vector, and one of them sets both sweeps' hand-off slots
+            double *hdev = nullptr;
+            HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&hdev), f->hvec, 0));
+            const size_t wsn = trsv_flow_ws_doubles(npad, wv.B);
+            double *wsf = y + npad, *xo = wsf + wsn, *wsb = xo + npad;
+            BQCHK(launch_flow_in(c, hdev, n, x, npad, y, 2 * (size_t)npad + 2 * wsn));
+            BQCHK(launch_trsv_flow(c, true, f->A.d(), f->ldl, npad, wv.B, wv.nr, wv.tt, x, y, wsf,
+                                   true));
+            BQCHK(launch_trsv_flow(c, false, f->A.d(), f->ldl, npad, wv.B, wv.nt, wv.uu, y, xo, wsb,
+                                   true));
+            BQCHK(launch_flow_out(c, xo, n, hdev));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            BQCHK(flow_check(c));
+            std::memcpy(X, f->hvec, sizeof(double) * n);
+            return BQ_OK;
+        }
+        double *hmap = nullptr;
+        if (c->solve_kcopy)
+            HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&hmap), f->hvec, 0));
+        if (hmap)
+            BQCHK(launch_flow_in(c, hmap, n, x, npad, nullptr, 0));
+        else
+            HIPCHK(c, hipMemcpyAsync(x, f->hvec, sizeof(double) * npad, hipMemcpyHostToDevice,
+                                     c->stream));
         BQCHK(fit_replay(c, f, 0, [&]() -> int {
             double *ws = f->vec.d() + 2 * (size_t)npad;
             BQCHK(enqueue_forward_vec(c, x, y, f->A.d(), f->ldl, npad, wv, ws));
             return enqueue_backward_vec(c, y, x, f->A.d(), f->ldl, npad, wv, ws);
         }));
-        HIPCHK(c, hipMemcpyAsync(f->hvec, x, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        if (hmap)
+            BQCHK(launch_flow_out(c, x, n, hmap));
+        else
+            HIPCHK(c, hipMemcpyAsync(f->hvec, x, sizeof(double) * n, hipMemcpyDeviceToHost,
+                                     c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         BQCHK(flow_check(c));
         std::memcpy(X, f->hvec, sizeof(double) * n);

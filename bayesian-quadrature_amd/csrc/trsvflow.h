@@ -363,3 +363,29 @@ __global__ __launch_bounds__(1024) void trsv_bwd_flow_kernel(const double *__res
     if (lane < 4)
         flow_st(xv + (long)(st - 1) * npad + i0 + lane, xin - mine);
 }
+
+// The host side of a one-vector solve through kernels instead of the copy engine and memsets
+// (tools/stream_ops_bench.hip: a pinned copy costs a stream 8-9 us, a memset 2.7, a further kernel
+// 2.9): flow_in_kernel brings the right-hand side in from the caller's mapped pinned vector
+// (coalesced, zero padded to npad) and sets every hand-off slot of BOTH sweeps to the sentinel in
+// the same launch; flow_out_kernel takes the solution out.  grid: enough 256-thread blocks for
+// max(npad, nfill).
+__global__ __launch_bounds__(256) void flow_in_kernel(const double *__restrict__ hsrc, int n,
+                                                      double *__restrict__ x, int npad,
+                                                      unsigned long long *__restrict__ fill,
+                                                      long nfill)
+{
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i < npad)
+        x[i] = i < n ? hsrc[i] : 0.0;
+    for (long k = i; k < nfill; k += (long)gridDim.x * 256)
+        fill[k] = BQ_FLOW_SENT;
+}
+
+__global__ __launch_bounds__(256) void flow_out_kernel(const double *__restrict__ x, int n,
+                                                       double *__restrict__ hdst)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+        hdst[i] = x[i];
+}
