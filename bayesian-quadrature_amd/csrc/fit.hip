@@ -10,8 +10,11 @@ namespace bqh {
 
 // pm / pv: device buffers for the posterior mean / variance of the layout's M border points
 // (bq_gp_refit_predict), or null
+// npts_words: that many doubles of border points wait in the staging buffer (hfit + HF_PTS) for
+// their place behind the fit's own points
 static int fit_factor(bq_ctx *c, bq_fit *f, double *pm = nullptr, double *pv = nullptr,
-                      double *hpost = nullptr) // hpost: host copy of misc[8 .. 8 + 128) on return
+                      double *hpost = nullptr, // hpost: host copy of misc[8 .. 8 + 128) on return
+                      size_t npts_words = 0)
 {
     const int ntot = f->L.ntot;
     int *info = f->misc.i();
@@ -27,8 +30,25 @@ static int fit_factor(bq_ctx *c, bq_fit *f, double *pm = nullptr, double *pv = n
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&f->hfit),
                                 sizeof(double) * (HF_PTS + 64 * BQ_MAXD)));
     std::memcpy(f->hfit + HF_PAR, &f->g, sizeof f->g);
-    HIPCHK(c, hipMemcpyAsync(f->gp.p, f->hfit + HF_PAR, sizeof f->g, hipMemcpyHostToDevice,
-                             c->stream));
+    // The call's small transfers -- kernel parameters (and border points) in, the record out -- go
+    // through one kernel each on the mapped staging buffer: a copy-engine operation costs the
+    // stream 8-9 us, a further kernel 2.9 (tools/stream_ops_bench.hip); a refit at the reference's
+    // own sizes is 40 us in all.
+    double *hmap = nullptr;
+    if (c->solve_kcopy)
+        HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&hmap), f->hfit, 0));
+    static_assert(sizeof(GaussParams) % 8 == 0, "GaussParams is copied in 8-byte words");
+    if (hmap) {
+        BQCHK(launch_copy_words2(c, f->gp.p, hmap + HF_PAR, sizeof f->g / 8,
+                                 f->pts.d() + (size_t)f->d * f->npad, hmap + HF_PTS, npts_words));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(f->gp.p, f->hfit + HF_PAR, sizeof f->g, hipMemcpyHostToDevice,
+                                 c->stream));
+        if (npts_words)
+            HIPCHK(c, hipMemcpyAsync(f->pts.d() + (size_t)f->d * f->npad, f->hfit + HF_PTS,
+                                     sizeof(double) * npts_words, hipMemcpyHostToDevice,
+                                     c->stream));
+    }
     double *scratch = f->dinv.d() + f->npad;
     FirstStep fs;
     const bool fuse = sweep_is_slab(c, ntot, f->npad, 1, f->panel.bytes / sizeof(double));
@@ -56,8 +76,11 @@ static int fit_factor(bq_ctx *c, bq_fit *f, double *pm = nullptr, double *pv = n
         BQCHK(launch_finalize(c, f->A.d(), f->ldl, 0L, f->L, scal, pm, pv, 64L, 1));
     // one read-back: misc = [info (int, 8 bytes) | pad | scal[4] | pad | mean[64] | var[64]]
     double *hm = f->hfit;
-    HIPCHK(c, hipMemcpyAsync(hm, f->misc.p, sizeof(double) * (hpost ? 8 + 128 : 6),
-                             hipMemcpyDeviceToHost, c->stream));
+    if (hmap)
+        BQCHK(launch_copy_words2(c, hmap, f->misc.p, hpost ? 8 + 128 : 6, nullptr, nullptr, 0));
+    else
+        HIPCHK(c, hipMemcpyAsync(hm, f->misc.p, sizeof(double) * (hpost ? 8 + 128 : 6),
+                                 hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (hpost)
         std::memcpy(hpost, hm + 8, sizeof(double) * 128);
@@ -294,11 +317,9 @@ extern "C" int bq_gp_refit_predict(bq_ctx *c, bq_fit *f, double h, const double 
             HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&f->hfit),
                                     sizeof(double) * (HF_PTS + 64 * BQ_MAXD)));
         std::memcpy(f->hfit + HF_PTS, xo, sizeof(double) * f->d * M);
-        HIPCHK(c, hipMemcpyAsync(f->pts.d() + (size_t)f->d * f->npad, f->hfit + HF_PTS,
-                                 sizeof(double) * f->d * M, hipMemcpyHostToDevice, c->stream));
     }
     double hv[128];
-    BQCHK(fit_factor(c, f, f->misc.d() + 8, f->misc.d() + 8 + 64, hv));
+    BQCHK(fit_factor(c, f, f->misc.d() + 8, f->misc.d() + 8 + 64, hv, (size_t)f->d * (size_t)M));
     for (int64_t i = 0; i < M; ++i) {
         if (mean)
             mean[i] = hv[i];

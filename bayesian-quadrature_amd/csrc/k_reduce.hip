@@ -171,6 +171,18 @@ int launch_flow_in(bq_ctx *c, const double *hsrc, int n, double *x, int npad, do
     return BQ_OK;
 }
 
+int launch_copy_words2(bq_ctx *c, void *d1, const void *s1, size_t n1, void *d2, const void *s2,
+                       size_t n2)
+{
+    hipLaunchKernelGGL(copy_words2_kernel, dim3(1), dim3(256), 0, c->cur,
+                       static_cast<unsigned long long *>(d1),
+                       static_cast<const unsigned long long *>(s1), (int)n1,
+                       static_cast<unsigned long long *>(d2),
+                       static_cast<const unsigned long long *>(s2), (int)n2);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
 int launch_flow_out(bq_ctx *c, const double *x, int n, double *hdst)
 {
     hipLaunchKernelGGL(flow_out_kernel, dim3((n + 255) / 256), dim3(256), 0, c->cur, x, n, hdst);

@@ -389,3 +389,19 @@ __global__ __launch_bounds__(256) void flow_out_kernel(const double *__restrict_
     if (i < n)
         hdst[i] = x[i];
 }
+
+// Small host <-> device transfers of a latency-bound call as ONE kernel on the mapped pinned staging
+// buffer instead of copy-engine operations (+2.9 us on the stream instead of +8..9 each): up to two
+// (dst, src, words) pairs of 8-byte words.  grid (1), block 256.
+__global__ __launch_bounds__(256) void copy_words2_kernel(unsigned long long *__restrict__ d1,
+                                                          const unsigned long long *__restrict__ s1,
+                                                          int n1,
+                                                          unsigned long long *__restrict__ d2,
+                                                          const unsigned long long *__restrict__ s2,
+                                                          int n2)
+{
+    for (int i = threadIdx.x; i < n1; i += 256)
+        d1[i] = s1[i];
+    for (int i = threadIdx.x; i < n2; i += 256)
+        d2[i] = s2[i];
+}
