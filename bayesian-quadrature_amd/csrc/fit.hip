@@ -422,8 +422,16 @@ extern "C" int bq_gp_predict(bq_ctx *c, bq_fit *f, const double *xo, int64_t M, 
         f->hio_len = need;
     }
     std::memcpy(f->hio, xo, sizeof(double) * d * M);
-    HIPCHK(c, hipMemcpyAsync(xod.p, f->hio, sizeof(double) * d * M, hipMemcpyHostToDevice,
-                             c->stream));
+    // (points in and results out through kernels on the mapped staging buffer: a copy-engine
+    // operation costs the stream 8-9 us, a further kernel 2.9 -- tools/stream_ops_bench.hip)
+    double *hmap = nullptr;
+    if (c->solve_kcopy)
+        HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&hmap), f->hio, 0));
+    if (hmap)
+        BQCHK(launch_flow_in(c, hmap, d * (int)M, xod.d(), d * (int)M, nullptr, 0));
+    else
+        HIPCHK(c, hipMemcpyAsync(xod.p, f->hio, sizeof(double) * d * M, hipMemcpyHostToDevice,
+                                 c->stream));
     GaussParams g = f->g;
     if (!var && !cov) {
         // mean only: fused cross-Gram x alpha
@@ -439,13 +447,9 @@ extern "C" int bq_gp_predict(bq_ctx *c, bq_fit *f, const double *xo, int64_t M, 
         HIPCHK(c, hipMemsetAsync(V0.p, 0, sizeof(double) * (size_t)Mp * npad, c->stream));
         BQCHK(launch_gram_cross(c, d, xod.d(), (int)M, f->pts.d(), n, g, V0.d(), Mp));
         BQCHK(enqueue_forward_rows(c, V0.d(), V.d(), Mp, Mp, f->A.d(), f->ldl, npad, wi));
-        // z lives in row yrow of the factor with stride ldl: gather it
-        DevBuf &z = f->wz;
-        HIPCHK(c, grow(z, sizeof(double) * npad));
-        HIPCHK(c, hipMemcpy2DAsync(z.p, sizeof(double), f->A.d() + f->L.yrow,
-                                   sizeof(double) * f->ldl, sizeof(double), npad,
-                                   hipMemcpyDeviceToDevice, c->stream));
-        BQCHK(launch_rowdot(c, V.d(), (long)Mp, (int)M, Mp, npad, z.d(), g.c, out.d(), out.d() + Mp));
+        // z lives in row yrow of the factor with stride ldl: read where it is
+        BQCHK(launch_rowdot(c, V.d(), (long)Mp, (int)M, Mp, npad, f->A.d() + f->L.yrow, g.c, out.d(),
+                            out.d() + Mp, f->ldl));
         if (cov) {
             // cov = K(xo,xo) - V V^T  (Mp x Mp on device, M x M out)
             DevBuf Cd, gd;
@@ -461,12 +465,15 @@ extern "C" int bq_gp_predict(bq_ctx *c, bq_fit *f, const double *xo, int64_t M, 
                               npad, 0, 1));
             HIPCHK(c, hipMemcpy2DAsync(cov, sizeof(double) * M, Cd.p, sizeof(double) * Mp,
                                        sizeof(double) * M, M, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream)); // Cd goes out of scope
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream)); // Cd goes out of scope
     }
     double *hres = f->hio + (size_t)d * M; // [mean (Mp) | var (Mp)], one copy
-    HIPCHK(c, hipMemcpyAsync(hres, out.p, sizeof(double) * 2 * (size_t)Mp, hipMemcpyDeviceToHost,
-                             c->stream));
+    if (hmap)
+        BQCHK(launch_flow_out(c, out.d(), 2 * Mp, hmap + (size_t)d * M));
+    else
+        HIPCHK(c, hipMemcpyAsync(hres, out.p, sizeof(double) * 2 * (size_t)Mp,
+                                 hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (mean)
         std::memcpy(mean, hres, sizeof(double) * M);

@@ -343,7 +343,7 @@ int launch_plan_readout(bq_ctx *c, const double *A, long lda, long astride, Layo
                         const GaussParams *gp, double *scal, double *mean, double *var,
                         long mstride, int batch);
 int launch_rowdot(bq_ctx *c, const double *V, long ldv, int M, int Mp, int npad, const double *z,
-                  double k0, double *mean, double *var);
+                  double k0, double *mean, double *var, long zstride = 1);
 int launch_predict_mean(bq_ctx *c, int d, const double *xo, int M, const double *pts, int n,
                         const double *alpha, const GaussParams &g, double *mean);
 int launch_neg_identity(bq_ctx *c, double *nr, int B, int npad);

@@ -30,11 +30,11 @@ int launch_plan_readout(bq_ctx *c, const double *A, long lda, long astride, Layo
 
 // mean_i = v_i . z, var_i = k0 - |v_i|^2 over the Mp (multiple of 16) rows of V
 int launch_rowdot(bq_ctx *c, const double *V, long ldv, int M, int Mp, int npad, const double *z,
-                  double k0, double *mean, double *var)
+                  double k0, double *mean, double *var, long zstride)
 {
     Bracket br(c, BQ_K_REDUCE);
     hipLaunchKernelGGL(rowdot_kernel, dim3(Mp / 16), dim3(1024), 0, c->stream, V, ldv, M, npad, z,
-                       k0, mean, var);
+                       zstride, k0, mean, var);
     HIPCHK(c, hipGetLastError());
     return BQ_OK;
 }

@@ -56,9 +56,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict_
 // border took 78 us of a 200 us prediction.  grid: ceil(m / 16).
 __global__ __launch_bounds__(1024) void rowdot_kernel(const double *__restrict__ V, long ldv,
                                                       int m, int n, const double *__restrict__ z,
-                                                      double k0, double *__restrict__ mean,
+                                                      long zs, double k0,
+                                                      double *__restrict__ mean,
                                                       double *__restrict__ var)
 {
+    // (zs: stride of z -- the fit's z lives in a row of its factor)
     const int t = threadIdx.x, r = t & 15, sl = t >> 4;
     const int row = blockIdx.x * 16 + r;
     double sm = 0.0, sv = 0.0;
@@ -73,14 +75,14 @@ __global__ __launch_bounds__(1024) void rowdot_kernel(const double *__restrict__
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if (z)
-                    sm = fma(v[u], z[j + 64 * u], sm);
+                    sm = fma(v[u], z[(long)(j + 64 * u) * zs], sm);
                 sv = fma(v[u], v[u], sv);
             }
         }
         for (; j < n; j += 64) {
             const double v = p[(long)j * ldv];
             if (z)
-                sm = fma(v, z[j], sm);
+                sm = fma(v, z[(long)j * zs], sm);
             sv = fma(v, v, sv);
         }
     }
