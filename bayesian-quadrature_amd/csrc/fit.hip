@@ -163,9 +163,7 @@ int fit_alpha(bq_ctx *c, bq_fit *f)
     BQCHK(fit_vec(c, f));
     // (the gather stays outside the captured chain: the y row moves when the fit carries
     // border points, bq_gp_refit_predict)
-    HIPCHK(c, hipMemcpy2DAsync(f->vec.p, sizeof(double), f->A.d() + f->L.yrow,
-                               sizeof(double) * f->ldl, sizeof(double), f->npad,
-                               hipMemcpyDeviceToDevice, c->stream));
+    BQCHK(launch_gather_row(c, f->vec.d(), f->A.d() + f->L.yrow, f->ldl, f->npad));
     BQCHK(fit_replay(c, f, 1, [&]() -> int {
         return enqueue_backward_vec(c, f->vec.d(), f->alpha.d(), f->A.d(), f->ldl, f->npad, w,
                                     f->vec.d() + 2 * (size_t)f->npad);

@@ -370,6 +370,7 @@ int launch_trsv_flow(bq_ctx *c, bool forward, const double *L, long ldl, int npa
 int launch_flow_in(bq_ctx *c, const double *hsrc, int n, double *x, int npad, double *fill,
                    size_t nfill);
 int launch_flow_out(bq_ctx *c, const double *x, int n, double *hdst);
+int launch_gather_row(bq_ctx *c, double *dst, const double *src, long stride, int n);
 // up to two small copies of 8-byte words in one launch (either side may be mapped pinned memory)
 int launch_copy_words2(bq_ctx *c, void *d1, const void *s1, size_t n1, void *d2, const void *s2,
                        size_t n2);

@@ -183,6 +183,14 @@ int launch_copy_words2(bq_ctx *c, void *d1, const void *s1, size_t n1, void *d2,
     return BQ_OK;
 }
 
+int launch_gather_row(bq_ctx *c, double *dst, const double *src, long stride, int n)
+{
+    hipLaunchKernelGGL(gather_row_kernel, dim3((n + 255) / 256), dim3(256), 0, c->cur, dst, src,
+                       stride, n);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
 int launch_flow_out(bq_ctx *c, const double *x, int n, double *hdst)
 {
     hipLaunchKernelGGL(flow_out_kernel, dim3((n + 255) / 256), dim3(256), 0, c->cur, x, n, hdst);

@@ -405,3 +405,14 @@ __global__ __launch_bounds__(256) void copy_words2_kernel(unsigned long long *__
     for (int i = threadIdx.x; i < n2; i += 256)
         d2[i] = s2[i];
 }
+
+// dst[j] = src[j * stride], j < n: a row of a column-major matrix as a vector (the fit's z out of its
+// factor) by a kernel rather than a strided copy-engine operation
+__global__ __launch_bounds__(256) void gather_row_kernel(double *__restrict__ dst,
+                                                         const double *__restrict__ src, long stride,
+                                                         int n)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n)
+        dst[j] = src[(long)j * stride];
+}
