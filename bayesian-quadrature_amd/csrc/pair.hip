@@ -221,10 +221,23 @@ extern "C" void bq_pair_destroy(bq_ctx *c, bq_pair *pr)
 static int pair_llh_enqueue(bq_ctx *c, bq_pair *pr)
 {
     const int S = pr->S, nsc = pr->nsc, ns = pr->ns, nc = pr->nc;
+    // (parameters in and the records out through kernels on the mapped pinned staging: a
+    // copy-engine operation costs the stream -- or the captured graph -- 8-9 us, a kernel 2.9)
+    GaussParams *hpar_d = nullptr;
+    double *hres_d = nullptr;
+    if (c->solve_kcopy) {
+        HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&hpar_d), pr->hpar, 0));
+        HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&hres_d), pr->hres, 0));
+    }
+    static_assert(sizeof(GaussParams) % 8 == 0, "GaussParams is copied in 8-byte words");
+    constexpr size_t GW = sizeof(GaussParams) / 8;
     if (pr->merged) {
         // one plan of 2 S systems: [GP1 under the S sets | GP2 under the S sets]
-        HIPCHK(c, hipMemcpyAsync(pr->p1->gp.p, pr->hpar, sizeof(GaussParams) * 2 * S,
-                                 hipMemcpyHostToDevice, c->stream));
+        if (hpar_d)
+            BQCHK(launch_copy_words2(c, pr->p1->gp.p, hpar_d, GW * 2 * S, nullptr, nullptr, 0));
+        else
+            HIPCHK(c, hipMemcpyAsync(pr->p1->gp.p, pr->hpar, sizeof(GaussParams) * 2 * S,
+                                     hipMemcpyHostToDevice, c->stream));
         BQCHK(plan_enqueue(c, pr->p1));
         HIPCHK(c, hipMemsetAsync(pr->flag.p, 0, sizeof(int) * S, c->stream));
         hipLaunchKernelGGL(pair_collect_kernel, dim3(S), dim3(64), 0, c->stream, pr->p1->scal.d(),
@@ -233,10 +246,15 @@ static int pair_llh_enqueue(bq_ctx *c, bq_pair *pr)
                            pr->dres.d());
         HIPCHK(c, hipGetLastError());
     } else {
-        HIPCHK(c, hipMemcpyAsync(pr->p1->gp.p, pr->hpar, sizeof(GaussParams) * S,
-                                 hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(pr->p2->gp.p, pr->hpar + S, sizeof(GaussParams) * S,
-                                 hipMemcpyHostToDevice, c->stream));
+        if (hpar_d) {
+            BQCHK(launch_copy_words2(c, pr->p1->gp.p, hpar_d, GW * S, pr->p2->gp.p, hpar_d + S,
+                                     GW * S));
+        } else {
+            HIPCHK(c, hipMemcpyAsync(pr->p1->gp.p, pr->hpar, sizeof(GaussParams) * S,
+                                     hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(pr->p2->gp.p, pr->hpar + S, sizeof(GaussParams) * S,
+                                     hipMemcpyHostToDevice, c->stream));
+        }
         BQCHK(plan_enqueue(c, pr->p1));
         HIPCHK(c, hipMemsetAsync(pr->flag.p, 0, sizeof(int) * S, c->stream));
         const long ms = std::max(nc, 1), ys = pr->p2->L.npad;
@@ -251,8 +269,11 @@ static int pair_llh_enqueue(bq_ctx *c, bq_pair *pr)
                            pr->dres.d());
         HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipMemcpyAsync(pr->hres, pr->dres.p, sizeof(double) * (size_t)S * (5 + nc),
-                             hipMemcpyDeviceToHost, c->stream));
+    if (hres_d)
+        BQCHK(launch_copy_words2(c, hres_d, pr->dres.p, (size_t)S * (5 + nc), nullptr, nullptr, 0));
+    else
+        HIPCHK(c, hipMemcpyAsync(pr->hres, pr->dres.p, sizeof(double) * (size_t)S * (5 + nc),
+                                 hipMemcpyDeviceToHost, c->stream));
     return BQ_OK;
 }
 
