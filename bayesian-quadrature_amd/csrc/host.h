@@ -371,6 +371,11 @@ int launch_flow_in(bq_ctx *c, const double *hsrc, int n, double *x, int npad, do
                    size_t nfill);
 int launch_flow_out(bq_ctx *c, const double *x, int n, double *hdst);
 int launch_gather_row(bq_ctx *c, double *dst, const double *src, long stride, int n);
+// a small plan's inputs out of / results into one mapped pinned staging buffer (trsvflow.h)
+int launch_plan_scatter(bq_ctx *c, const double *stage, int nprob, int d, int n, int M, int ntot,
+                        int npad, int gw, double *gp, double *pts, double *yd);
+int launch_plan_gather(bq_ctx *c, double *out, const double *scal, const int *info,
+                       const double *mean, const double *var, int nb, int M);
 // up to two small copies of 8-byte words in one launch (either side may be mapped pinned memory)
 int launch_copy_words2(bq_ctx *c, void *d1, const void *s1, size_t n1, void *d2, const void *s2,
                        size_t n2);
@@ -450,10 +455,15 @@ struct bq_plan {
     int graph_state = 0; // 0 = not tried, 1 = ready, -1 = unavailable (eager launches)
     unsigned long long graph_key = 0; // launch_config_key the graph was captured under
     double *hres = nullptr; // pinned staging of bq_plan_results: [scal 4 nb | info nb | mean | var]
+    double *hin = nullptr;  // pinned staging of a small plan's inputs (bq_plan_set_inputs)
+    size_t hin_len = 0;
+    bool in_flight = false; // the scatter out of hin may not have run yet
     ~bq_plan()
     {
         if (hres)
             (void)hipHostFree(hres);
+        if (hin)
+            (void)hipHostFree(hin);
     }
 };
 

@@ -183,6 +183,26 @@ int launch_copy_words2(bq_ctx *c, void *d1, const void *s1, size_t n1, void *d2,
     return BQ_OK;
 }
 
+int launch_plan_scatter(bq_ctx *c, const double *stage, int nprob, int d, int n, int M, int ntot,
+                        int npad, int gw, double *gp, double *pts, double *yd)
+{
+    const long total = (long)nprob * (gw + (long)d * n + (long)d * M + n);
+    hipLaunchKernelGGL(plan_scatter_kernel, dim3((unsigned)std::min<long>(256, (total + 255) / 256)),
+                       dim3(256), 0, c->cur, stage, nprob, d, n, M, ntot, npad, gw, gp, pts, yd);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+int launch_plan_gather(bq_ctx *c, double *out, const double *scal, const int *info,
+                       const double *mean, const double *var, int nb, int M)
+{
+    const long total = std::max<long>(4L * nb, (long)M * nb);
+    hipLaunchKernelGGL(plan_gather_kernel, dim3((unsigned)std::min<long>(64, (total + 255) / 256)),
+                       dim3(256), 0, c->cur, out, scal, info, mean, var, nb, M);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
 int launch_gather_row(bq_ctx *c, double *dst, const double *src, long stride, int n)
 {
     hipLaunchKernelGGL(gather_row_kernel, dim3((n + 255) / 256), dim3(256), 0, c->cur, dst, src,

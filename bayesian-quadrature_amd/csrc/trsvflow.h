@@ -416,3 +416,56 @@ __global__ __launch_bounds__(256) void gather_row_kernel(double *__restrict__ ds
     if (j < n)
         dst[j] = src[(long)j * stride];
 }
+
+// A small plan's inputs out of ONE mapped pinned staging buffer into their places (bq_plan_set_inputs
+// below 256 KB: four copy operations from pageable memory and a synchronisation otherwise).  stage:
+// [parameters gw nprob | x (d n) nprob | xo (d M) nprob | y n nprob] in 8-byte words; pts: a d x ntot
+// block per problem, x at its columns [0, n), xo at [npad, npad + M); yd: npad per problem.
+__global__ __launch_bounds__(256) void plan_scatter_kernel(const double *__restrict__ stage,
+                                                           int nprob, int d, int n, int M, int ntot,
+                                                           int npad, int gw,
+                                                           double *__restrict__ gp,
+                                                           double *__restrict__ pts,
+                                                           double *__restrict__ yd)
+{
+    const long ng = (long)gw * nprob, nx = (long)d * n * nprob, nxo = (long)d * M * nprob,
+               ny = (long)n * nprob;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < ng + nx + nxo + ny;
+         i += (long)gridDim.x * 256) {
+        const double v = stage[i];
+        if (i < ng) {
+            gp[i] = v;
+        } else if (i < ng + nx) {
+            const long k = i - ng, b = k / ((long)d * n), r = k % ((long)d * n);
+            pts[b * (long)d * ntot + r] = v;
+        } else if (i < ng + nx + nxo) {
+            const long k = i - ng - nx, b = k / ((long)d * M), r = k % ((long)d * M);
+            pts[b * (long)d * ntot + (long)d * npad + r] = v;
+        } else {
+            const long k = i - ng - nx - nxo, b = k / n, r = k % n;
+            yd[b * (long)npad + r] = v;
+        }
+    }
+}
+
+// ... and its results into one: [scal 4 nb | info nb (ints) | mean M nb | var M nb]
+__global__ __launch_bounds__(256) void plan_gather_kernel(double *__restrict__ out,
+                                                          const double *__restrict__ scal,
+                                                          const int *__restrict__ info,
+                                                          const double *__restrict__ mean,
+                                                          const double *__restrict__ var, int nb,
+                                                          int M)
+{
+    const long o_info = 4L * nb, o_mean = o_info + nb, o_var = o_mean + (long)M * nb;
+    int *oi = reinterpret_cast<int *>(out + o_info);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < 4L * nb; i += (long)gridDim.x * 256)
+        out[i] = scal[i];
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < nb; i += (long)gridDim.x * 256)
+        oi[i] = info[i];
+    if (mean)
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < (long)M * nb; i += (long)gridDim.x * 256)
+            out[o_mean + i] = mean[i];
+    if (var)
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < (long)M * nb; i += (long)gridDim.x * 256)
+            out[o_var + i] = var[i];
+}
