@@ -219,6 +219,9 @@ extern "C" void bq_ctx_destroy(bq_ctx *c)
         (void)hipEventDestroy(c->t0);
     if (c->t1)
         (void)hipEventDestroy(c->t1);
+    if (c->hstage)
+        (void)hipHostFree(c->hstage);
+    c->hstage = nullptr;
     for (hipEvent_t e : {c->ev_panel, c->ev_next, c->ev_fork})
         if (e)
             (void)hipEventDestroy(e);

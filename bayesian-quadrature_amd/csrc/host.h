@@ -98,6 +98,8 @@ struct bq_ctx {
     int df_halves = 0;   // the diagonal-first sweep as two half-batches on the two streams (BQ_DF_HALVES)
     int rows_tail = 128; // a large row sweep's last updates as split-k tiles: from this many LDS tiles down (BQ_ROWS_TAIL)
     int solve_kcopy = 1; // a one-vector solve's vector in / out and sentinel fill by kernels (BQ_SOLVE_KCOPY)
+    double *hstage = nullptr; // mapped pinned staging of the small host-buffer calls (ctx_stage)
+    size_t hstage_len = 0;
     int df_sharing = 0;  // gemm_lds_tile's sharing mode while a diagonal factor runs beside an update
                          // (0: the rule of a product alone -- C5 shard 5.73 ms against 6.05 with 1)
     int la_min = 3072;   // look-ahead only while the bulk update has at least this many rows (BQ_LA_MIN)
@@ -371,6 +373,10 @@ int launch_flow_in(bq_ctx *c, const double *hsrc, int n, double *x, int npad, do
                    size_t nfill);
 int launch_flow_out(bq_ctx *c, const double *x, int n, double *hdst);
 int launch_gather_row(bq_ctx *c, double *dst, const double *src, long stride, int n);
+// small host matrices through the context's mapped pinned staging buffer (trsvflow.h)
+int launch_mat_in(bq_ctx *c, const double *stage, int n, double *A, long lda, int ntot, int *info);
+int launch_mat_out(bq_ctx *c, double *out, const double *A, long lda, int n, const int *info);
+int ctx_stage(bq_ctx *c, size_t words, double **host, double **dev);
 // a small plan's inputs out of / results into one mapped pinned staging buffer (trsvflow.h)
 int launch_plan_scatter(bq_ctx *c, const double *stage, int nprob, int d, int n, int M, int ntot,
                         int npad, int gw, double *gp, double *pts, double *yd);

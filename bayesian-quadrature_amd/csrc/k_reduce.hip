@@ -203,6 +203,40 @@ int launch_plan_gather(bq_ctx *c, double *out, const double *scal, const int *in
     return BQ_OK;
 }
 
+int launch_mat_in(bq_ctx *c, const double *stage, int n, double *A, long lda, int ntot, int *info)
+{
+    const long total = (long)ntot * ntot;
+    hipLaunchKernelGGL(mat_in_kernel, dim3((unsigned)std::min<long>(256, (total + 255) / 256)),
+                       dim3(256), 0, c->cur, stage, n, A, lda, ntot, info);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+int launch_mat_out(bq_ctx *c, double *out, const double *A, long lda, int n, const int *info)
+{
+    const long total = (long)n * n;
+    hipLaunchKernelGGL(mat_out_kernel, dim3((unsigned)std::min<long>(256, (total + 255) / 256)),
+                       dim3(256), 0, c->cur, out, A, lda, n, info);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+// the context's mapped pinned staging buffer, at least `words` doubles: host and device views
+int ctx_stage(bq_ctx *c, size_t words, double **host, double **dev)
+{
+    if (c->hstage_len < words) {
+        if (c->hstage)
+            (void)hipHostFree(c->hstage);
+        c->hstage = nullptr;
+        c->hstage_len = 0;
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->hstage), sizeof(double) * words));
+        c->hstage_len = words;
+    }
+    *host = c->hstage;
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(dev), c->hstage, 0));
+    return BQ_OK;
+}
+
 int launch_gather_row(bq_ctx *c, double *dst, const double *src, long stride, int n)
 {
     hipLaunchKernelGGL(gather_row_kernel, dim3((n + 255) / 256), dim3(256), 0, c->cur, dst, src,

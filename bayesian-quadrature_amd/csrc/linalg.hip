@@ -37,22 +37,52 @@ extern "C" int bq_cho_factor(bq_ctx *c, const double *C, double *L, int64_t n, i
     DevBuf A, ws;
     int ntot;
     long lda;
-    BQCHK(upload_padded(c, C, (int)n, A, ntot, lda));
+    // a small matrix (the reference's own sizes): in and out through the mapped staging buffer,
+    // one kernel each way and ONE synchronisation
+    const bool small = c->solve_kcopy && (size_t)n * n + 1 <= (32u << 10);
+    double *hs = nullptr, *ds = nullptr;
     HIPCHK(c, ws.alloc(BQ_DINV_STRIDE * sizeof(double) + 64));
     double *dinv = ws.d();
     int *info = reinterpret_cast<int *>(ws.d() + BQ_DINV_STRIDE);
-    HIPCHK(c, hipMemsetAsync(info, 0, sizeof(int), c->stream));
+    if (small) {
+        BQCHK(ctx_stage(c, (size_t)n * n + 1, &hs, &ds));
+        ntot = (int)roundup(n, 64);
+        lda = pick_ld(ntot);
+        HIPCHK(c, A.alloc(sizeof(double) * (size_t)lda * ntot));
+        std::memcpy(hs + 1, C, sizeof(double) * (size_t)n * n);
+        BQCHK(launch_mat_in(c, ds + 1, (int)n, A.d(), lda, ntot, info));
+    } else {
+        BQCHK(upload_padded(c, C, (int)n, A, ntot, lda));
+        HIPCHK(c, hipMemsetAsync(info, 0, sizeof(int), c->stream));
+    }
     if (c->panel_ws.bytes < sizeof(double) * panel_ws_doubles(ntot, 1))
         HIPCHK(c, c->panel_ws.alloc(sizeof(double) * panel_ws_doubles(ntot, 1)));
     BQCHK(enqueue_potrf_partial(c, A.d(), lda, 0, 1, ntot, ntot, dinv, info, c->panel_ws.d(),
                                 c->panel_ws.bytes / sizeof(double)));
     int hinfo = 0;
-    HIPCHK(c, hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (small) {
+        BQCHK(launch_mat_out(c, ds, A.d(), lda, (int)n, info));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hinfo = (int)hs[0];
+    } else {
+        HIPCHK(c, hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     if (hinfo != 0) {
         if (info_out)
             *info_out = hinfo;
         return fail(c, BQ_ERR_NOT_PD, "matrix is not positive definite");
+    }
+    if (small) {
+        // the lower triangle out of the staging buffer; the strict upper part of L keeps what the
+        // caller had there (C's values after the reference's C -> L copy)
+        const double *src = hs + 1;
+        for (int64_t j = 0; j < n; ++j) {
+            if (C != L && j > 0)
+                std::memcpy(L + j * n, C + j * n, sizeof(double) * (size_t)j);
+            std::memcpy(L + j + j * n, src + j + j * n, sizeof(double) * (size_t)(n - j));
+        }
+        return BQ_OK;
     }
     // copy back only the lower triangle; the strict upper part of L keeps what
     // the caller had there (C's values after the reference's C -> L copy)
@@ -85,8 +115,22 @@ extern "C" int bq_cho_solve(bq_ctx *c, const double *L, const double *B, double 
     DevBuf A, ws, Xd;
     int npad;
     long ldl;
-    // the strict upper triangle of L is never read by the sweeps
-    BQCHK(upload_padded(c, L, (int)n, A, npad, ldl));
+    // one vector against a small factor (the reference's own sizes): factor and vector in, solution
+    // out through the mapped staging buffer -- [x n | L n^2 | b n] -- by kernels
+    const bool small = c->solve_kcopy && nrhs == 1 && (size_t)n * n + 2 * (size_t)n <= (32u << 10);
+    double *hs = nullptr, *ds = nullptr;
+    if (small) {
+        BQCHK(ctx_stage(c, (size_t)n * n + 2 * (size_t)n, &hs, &ds));
+        npad = (int)roundup(n, 64);
+        ldl = pick_ld(npad);
+        HIPCHK(c, A.alloc(sizeof(double) * (size_t)ldl * npad));
+        std::memcpy(hs + n, L, sizeof(double) * (size_t)n * n);
+        std::memcpy(hs + n + (size_t)n * n, B, sizeof(double) * (size_t)n);
+        BQCHK(launch_mat_in(c, ds + n, (int)n, A.d(), ldl, npad, nullptr));
+    } else {
+        // the strict upper triangle of L is never read by the sweeps
+        BQCHK(upload_padded(c, L, (int)n, A, npad, ldl));
+    }
     // the block inverses of the factor's diagonal: 16 x 16 (panel solve), then B wide
     DevBuf wide, X2;
     HIPCHK(c, ws.alloc(sizeof(double) * BQ_DINV_HALF * (size_t)(npad / 64)));
@@ -98,12 +142,20 @@ extern "C" int bq_cho_solve(bq_ctx *c, const double *L, const double *B, double 
         // one right-hand side: the GEMV sweeps (trsv.h)
         HIPCHK(c, Xd.alloc(sizeof(double) * (2 * (size_t)npad + trsv_flow_ws_doubles(npad, w.B))));
         HIPCHK(c, hipMemsetAsync(Xd.p, 0, sizeof(double) * 2 * (size_t)npad, c->stream));
-        HIPCHK(c, hipMemcpyAsync(Xd.p, B, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
         double *x = Xd.d(), *y = Xd.d() + npad, *fw = Xd.d() + 2 * (size_t)npad;
+        if (small)
+            BQCHK(launch_flow_in(c, ds + n + (size_t)n * n, (int)n, x, npad, nullptr, 0));
+        else
+            HIPCHK(c, hipMemcpyAsync(Xd.p, B, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
         BQCHK(enqueue_forward_vec(c, x, y, A.d(), ldl, npad, w, fw));
         BQCHK(enqueue_backward_vec(c, y, x, A.d(), ldl, npad, w, fw));
-        HIPCHK(c, hipMemcpyAsync(X, x, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        if (small)
+            BQCHK(launch_flow_out(c, x, (int)n, ds));
+        else
+            HIPCHK(c, hipMemcpyAsync(X, x, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (small)
+            std::memcpy(X, hs, sizeof(double) * (size_t)n);
         return flow_check(c);
     }
     return solve_rows_host(c, A.d(), ldl, (int)n, npad, w, B, nrhs, X);

@@ -469,3 +469,33 @@ __global__ __launch_bounds__(256) void plan_gather_kernel(double *__restrict__ o
         for (long i = blockIdx.x * 256L + threadIdx.x; i < (long)M * nb; i += (long)gridDim.x * 256)
             out[o_var + i] = var[i];
 }
+
+// A small host matrix (n x n, ld n, in the mapped pinned staging buffer) into its padded device
+// matrix (ntot x ntot, identity in the padding) and the failure flag cleared, one launch; and the
+// result back behind the flag: out[0] = *info, out[1 + i + j n] = A[i + j lda].  The linalg_c
+// drop-ins at the reference's own sizes are a handful of launches: every copy-engine operation and
+// every extra synchronisation costs them more than a kernel does (tools/stream_ops_bench.hip).
+__global__ __launch_bounds__(256) void mat_in_kernel(const double *__restrict__ stage, int n,
+                                                     double *__restrict__ A, long lda, int ntot,
+                                                     int *__restrict__ info)
+{
+    if (info && blockIdx.x == 0 && threadIdx.x == 0)
+        *info = 0;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)ntot * ntot;
+         e += (long)gridDim.x * 256) {
+        const int i = (int)(e % ntot), j = (int)(e / ntot);
+        A[i + (long)j * lda] = (i < n && j < n) ? stage[i + (long)j * n] : (i == j ? 1.0 : 0.0);
+    }
+}
+
+__global__ __launch_bounds__(256) void mat_out_kernel(double *__restrict__ out,
+                                                      const double *__restrict__ A, long lda, int n,
+                                                      const int *__restrict__ info)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        out[0] = (double)*info;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)n * n; e += (long)gridDim.x * 256) {
+        const int i = (int)(e % n), j = (int)(e / n);
+        out[1 + e] = A[i + (long)j * lda];
+    }
+}
