@@ -176,6 +176,17 @@ extern "C" int bq_logdet(bq_ctx *c, const double *L, int64_t n, double *out)
     std::vector<double> diag((size_t)n);
     for (int64_t i = 0; i < n; ++i)
         diag[(size_t)i] = L[i + i * n];
+    if (c->solve_kcopy && n + 1 <= (32 << 10)) {
+        // (the diagonal and the result through the mapped staging buffer: one launch, no
+        // allocation, no copy operation)
+        double *hs = nullptr, *ds = nullptr;
+        BQCHK(ctx_stage(c, (size_t)n + 1, &hs, &ds));
+        std::memcpy(hs + 1, diag.data(), sizeof(double) * (size_t)n);
+        BQCHK(launch_logdet(c, ds + 1, 0L, (int)n, ds));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        *out = hs[0];
+        return BQ_OK;
+    }
     DevBuf dv;
     HIPCHK(c, dv.alloc(sizeof(double) * (n + 1)));
     HIPCHK(c, hipMemcpyAsync(dv.p, diag.data(), sizeof(double) * n, hipMemcpyHostToDevice,
