@@ -377,6 +377,8 @@ int launch_gather_row(bq_ctx *c, double *dst, const double *src, long stride, in
 int launch_mat_in(bq_ctx *c, const double *stage, int n, double *A, long lda, int ntot, int *info);
 int launch_mat_out(bq_ctx *c, double *out, const double *A, long lda, int n, const int *info);
 int ctx_stage(bq_ctx *c, size_t words, double **host, double **dev);
+// (L L^T) X = B, n <= 64, nrhs <= 64, one launch on the staging buffer [X | L | B]
+int launch_small_potrs(bq_ctx *c, double *stage, int n, int nrhs);
 // a small plan's inputs out of / results into one mapped pinned staging buffer (trsvflow.h)
 int launch_plan_scatter(bq_ctx *c, const double *stage, int nprob, int d, int n, int M, int ntot,
                         int npad, int gw, double *gp, double *pts, double *yd);

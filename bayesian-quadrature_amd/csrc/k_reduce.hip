@@ -203,6 +203,13 @@ int launch_plan_gather(bq_ctx *c, double *out, const double *scal, const int *in
     return BQ_OK;
 }
 
+int launch_small_potrs(bq_ctx *c, double *stage, int n, int nrhs)
+{
+    hipLaunchKernelGGL(small_potrs_kernel, dim3(1), dim3(1024), 0, c->cur, stage, n, nrhs);
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
 int launch_mat_in(bq_ctx *c, const double *stage, int n, double *A, long lda, int ntot, int *info)
 {
     const long total = (long)ntot * ntot;

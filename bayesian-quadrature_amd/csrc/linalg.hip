@@ -34,6 +34,38 @@ extern "C" int bq_cho_factor(bq_ctx *c, const double *C, double *L, int64_t n, i
     if (n > 65536)
         return fail(c, BQ_ERR_BAD_ARG, "n too large");
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->solve_kcopy && n <= 64) {
+        // one 64 x 64 block: the diagonal factor's kernel straight on the mapped staging buffer
+        // ([flag | the block with its identity padding]), one launch, one synchronisation
+        double *hs = nullptr, *ds = nullptr;
+        BQCHK(ctx_stage(c, 1 + 4096, &hs, &ds));
+        if (c->panel_ws.bytes < sizeof(double) * panel_ws_doubles(64, 1))
+            HIPCHK(c, c->panel_ws.alloc(sizeof(double) * panel_ws_doubles(64, 1)));
+        hs[0] = 0.0; // (the flag is its first four bytes)
+        double *blk = hs + 1;
+        std::memset(blk, 0, sizeof(double) * 4096);
+        for (int64_t j = 0; j < 64; ++j) {
+            if (j < n)
+                std::memcpy(blk + 64 * j, C + j * n, sizeof(double) * (size_t)n);
+            else
+                blk[65 * j] = 1.0;
+        }
+        BQCHK(launch_potf2(c, ds + 1, 64, 0, 0, c->panel_ws.d(), 0, reinterpret_cast<int *>(ds), 1));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        int hinfo = 0;
+        std::memcpy(&hinfo, hs, sizeof hinfo);
+        if (hinfo != 0) {
+            if (info_out)
+                *info_out = hinfo;
+            return fail(c, BQ_ERR_NOT_PD, "matrix is not positive definite");
+        }
+        for (int64_t j = 0; j < n; ++j) {
+            if (C != L && j > 0)
+                std::memcpy(L + j * n, C + j * n, sizeof(double) * (size_t)j);
+            std::memcpy(L + j + j * n, blk + j + 64 * j, sizeof(double) * (size_t)(n - j));
+        }
+        return BQ_OK;
+    }
     DevBuf A, ws;
     int ntot;
     long lda;
@@ -112,6 +144,18 @@ extern "C" int bq_cho_solve(bq_ctx *c, const double *L, const double *B, double 
     if (n == 0 || nrhs == 0)
         return BQ_OK;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->solve_kcopy && n <= 64 && nrhs <= 64) {
+        // the reference's own sizes: one launch on the mapped staging buffer [X | L | B]
+        double *hs = nullptr, *ds = nullptr;
+        const size_t nx = (size_t)n * nrhs;
+        BQCHK(ctx_stage(c, 2 * nx + (size_t)n * n, &hs, &ds));
+        std::memcpy(hs + nx, L, sizeof(double) * (size_t)n * n);
+        std::memcpy(hs + nx + (size_t)n * n, B, sizeof(double) * nx);
+        BQCHK(launch_small_potrs(c, ds, (int)n, (int)nrhs));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::memcpy(X, hs, sizeof(double) * nx);
+        return BQ_OK;
+    }
     DevBuf A, ws, Xd;
     int npad;
     long ldl;

@@ -499,3 +499,40 @@ __global__ __launch_bounds__(256) void mat_out_kernel(double *__restrict__ out,
         out[1 + e] = A[i + (long)j * lda];
     }
 }
+
+// (L L^T) X = B for a factor of at most 64 rows and at most 64 right-hand sides -- the linalg_c
+// drop-ins at the reference's own sizes -- as ONE launch on the mapped staging buffer:
+// stage = [X (n x nrhs, out) | L (n x n, ld n, lower) | B (n x nrhs)].  One workgroup: the factor goes
+// to LDS (row stride 65), a wave takes a column at a time, lane = row, and runs the forward and
+// the backward substitution with the column in one register (2 n steps of a v_readlane, an LDS read
+// and an FMA).  block 1024.
+__global__ __launch_bounds__(1024) void small_potrs_kernel(double *__restrict__ stage, int n,
+                                                           int nrhs)
+{
+    __shared__ double Ls[64 * 65];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    double *X = stage;
+    const double *L = stage + (long)n * nrhs, *B = L + (long)n * n;
+    for (int e = t; e < n * n; e += 1024) {
+        const int i = e % n, j = e / n;
+        Ls[i * 65 + j] = L[e];
+    }
+    __syncthreads();
+    const double rc = lane < n ? 1.0 / Ls[lane * 65 + lane] : 0.0;
+    for (int r = wave; r < nrhs; r += 16) {
+        double y = lane < n ? B[lane + (long)r * n] : 0.0;
+        for (int k = 0; k < n; ++k) {
+            const double yk = readlane_f64(y, k) * readlane_f64(rc, k);
+            const double lik = lane < n ? Ls[lane * 65 + k] : 0.0;
+            y = lane > k ? __builtin_fma(-lik, yk, y) : (lane == k ? yk : y);
+        }
+        for (int k = n - 1; k >= 0; --k) {
+            const double xk = readlane_f64(y, k) * readlane_f64(rc, k);
+            const double lki = lane < n ? Ls[k * 65 + lane] : 0.0;
+            y = lane < k ? __builtin_fma(-lki, xk, y) : (lane == k ? xk : y);
+        }
+        if (lane < n)
+            X[lane + (long)r * n] = y;
+    }
+}
