@@ -1070,6 +1070,67 @@ def test_predict_m1000_at_benched_size(engine, oracle):
     fit.close()
 
 
+def test_kernel_copies_match_the_copy_engine_route(engine):
+    """BQ_SOLVE_KCOPY (default on): the small transfers of the latency-bound calls go through kernels
+    on mapped pinned staging buffers instead of copy-engine operations and memsets, and the smallest
+    linalg_c drop-ins are one launch.  The same calls with BQ_SOLVE_KCOPY=0 give the same bits where
+    the same kernels do the arithmetic, and agree to rounding where the one-launch forms replace
+    them (cho_solve up to 64 rows)."""
+    import os
+    from bayesian_quadrature_amd import Engine
+    old = os.environ.get("BQ_SOLVE_KCOPY")
+    os.environ["BQ_SOLVE_KCOPY"] = "0"
+    try:
+        eng0 = Engine(0)
+    finally:
+        if old is None:
+            os.environ.pop("BQ_SOLVE_KCOPY", None)
+        else:
+            os.environ["BQ_SOLVE_KCOPY"] = old
+    try:
+        rs = np.random.RandomState(4)
+        # a resident fit: one-vector solves (one-launch sweeps and the per-block route), posterior
+        for n in (700, 1500, 2100):
+            c = wl.c4(n)
+            xo = rs.uniform(-5, 5, 100)
+            b = rs.randn(n)
+            res = []
+            for eng in (engine, eng0):
+                fit = eng.gp_fit(c["x"], wl.norm_logpdf(c["x"]), c["h"], c["w"] * 3.0, c["s"])
+                m, v, _ = fit.predict(xo)
+                res.append((fit.solve(b), m, v, fit.logml, fit.refit_predict(c["h"], c["w"] * 2.5,
+                                                                          c["s"], xo[:10])))
+                fit.close()
+            assert np.array_equal(res[0][0], res[1][0])
+            assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+            assert res[0][3] == res[1][3]
+            assert np.array_equal(res[0][4][0], res[1][4][0])
+            assert np.array_equal(res[0][4][1], res[1][4][1])
+        # the host-buffer plan call (scatter / gather kernels against four copies each way)
+        c2 = wl.c2()
+        a = engine.fit_predict(c2["x"], c2["y"], c2["h"], c2["w"], c2["s"], c2["xo"])
+        b0 = eng0.fit_predict(c2["x"], c2["y"], c2["h"], c2["w"], c2["s"], c2["xo"])
+        for u, v in zip(a, b0):
+            assert np.array_equal(np.asarray(u), np.asarray(v))
+        # linalg drop-ins: small (one launch), middle (staged), large (copies)
+        for n in (7, 64, 65, 150, 300):
+            A = rand_spd(rs, n)
+            La, Lb = np.zeros_like(A), np.zeros_like(A)
+            engine.cho_factor(A, La)
+            eng0.cho_factor(A, Lb)
+            assert np.array_equal(np.tril(La), np.tril(Lb))
+            bvec = rs.randn(n)
+            xa, xb = np.empty(n), np.empty(n)
+            engine.cho_solve(La, bvec, xa, 1)
+            eng0.cho_solve(La, bvec, xb, 1)
+            assert np.max(np.abs(xa - xb)) <= 1e-12 * np.max(np.abs(xb))
+            if n > 64:
+                assert np.array_equal(xa, xb)
+            assert engine.logdet(La) == eng0.logdet(La)
+    finally:
+        eng0.close()
+
+
 def test_diagonal_factor_block_inverses_and_pivots(engine):
     """The 64 x 64 diagonal factor alone (bq_probe_potf2: four and eight waves, the block read from
     global memory and handed over through LDS): L against LAPACK, the reciprocal pivots, and the four
