@@ -390,6 +390,32 @@ void bqo_gp_predict(const double *x, int d, int n, double h, const double *w, co
     }
 }
 
+/* full posterior covariance at M points xo (d x M), column-major M x M:
+ *   cov = K(xo,xo) - K(xo,x) Kxx^-1 K(x,xo) = K(xo,xo) - V'V,  V = L^-1 K(x,xo)
+ * (gp.GP.cov as consumed whole at bq.py:325 and as a 1 x 1 block at bq.py:496; the
+ * formula is SURVEY appendix B's restatement of the absent gp package).  K(xo,xo)
+ * carries no noise term (gp.GP.Kxoxo, bq.py:465).  work is n x M doubles. */
+void bqo_gp_cov(const double *x, int d, int n, double h, const double *w, const double *L,
+                const double *xo, int M, double *cov, double *work)
+{
+    bqo_gram_gauss_cross(x, n, xo, M, d, h, w, work); /* n x M: column i = k*_i */
+    bqo_trsm_lower(L, n, n, work, M, n);               /* V */
+    bqo_gram_gauss_cross(xo, M, xo, M, d, h, w, cov);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int j = 0; j < M; ++j) {
+        const double *vj = &A_(work, n, 0, j);
+        for (int i = j; i < M; ++i) {
+            const double *vi = &A_(work, n, 0, i);
+            double q = 0.0;
+            for (int k = 0; k < n; ++k)
+                q += vi[k] * vj[k];
+            const double c = A_(cov, M, i, j) - q;
+            A_(cov, M, i, j) = c;
+            A_(cov, M, j, i) = c;
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ */
 /* gauss_c.pyx, closed forms                                           */
 /* ------------------------------------------------------------------ */

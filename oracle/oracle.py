@@ -72,6 +72,7 @@ class Oracle(object):
             "bqo_gram_gauss": (None, [_dp, i, i, d, _dp, d, _dp]),
             "bqo_gp_fit": (i, [_dp, _dp, i, i, d, _dp, d, _dp, _dp, _dp]),
             "bqo_gp_predict": (None, [_dp, i, i, d, _dp, _dp, _dp, _dp, i, _dp, _dp, _dp]),
+            "bqo_gp_cov": (None, [_dp, i, i, d, _dp, _dp, _dp, i, _dp, _dp]),
             "bqo_mvn_logpdf": (d, [_dp, _dp, _dp, d, i]),
             "bqo_int_exp_norm": (d, [d, d, d]),
             "bqo_int_K": (i, [_dp, _dp, i, i, d, _dp, _dp, _dp]),
@@ -195,6 +196,18 @@ class Oracle(object):
         self.lib.bqo_gp_predict(_p(x), d, n, float(h), _p(w), _p(L), _p(alpha), _p(xo), M,
                                 _p(mean), _p(var) if want_var else None, _p(work))
         return (mean, var) if want_var else mean
+
+    def gp_cov(self, x, h, w, L, xo):
+        """Full posterior covariance K(xo,xo) - K(xo,x) Kxx^-1 K(x,xo), M x M (gp.GP.cov)."""
+        x, xo = _pts(x), _pts(xo)
+        d, n = x.shape
+        M = xo.shape[1]
+        w = _vec(w, d)
+        L = _f(L)
+        cov = np.empty((M, M), order="F")
+        work = np.empty((n, M), order="F")
+        self.lib.bqo_gp_cov(_p(x), d, n, float(h), _p(w), _p(L), _p(xo), M, _p(cov), _p(work))
+        return cov
 
     # -- gauss_c --------------------------------------------------------
     def mvn_logpdf(self, x, m, L, logdet):

@@ -58,9 +58,7 @@ class FitDouble(object):
         mean, var = self.o.gp_predict(self.x, self.h, self.w, self._L, self._alpha, xo)
         cov = None
         if want_cov:
-            Ks = self.o.gram_cross(self.x, xo, self.h, self.w)      # n x M
-            V = self.o.trsm_lower(self._L, Ks)
-            cov = np.asfortranarray(self.o.gram_cross(xo, xo, self.h, self.w) - V.T.dot(V))
+            cov = self.o.gp_cov(self.x, self.h, self.w, self._L, xo)
         return (mean if want_mean else None), (var if want_var else None), cov
 
 

@@ -284,6 +284,11 @@ def test_gp_predict(engine, oracle, n, M):
     assert relmax(v, vo, scale=k0) < RTOL       # variance relative to the prior scale
     assert relmax(np.diag(c), vo, scale=k0) < RTOL
     assert np.allclose(c, c.T, rtol=0, atol=1e-12 * k0)
+    # every one of the M^2 entries of gp.GP.cov (bq.py:325,496) against the oracle's
+    # K(xo,xo) - V'V, relative to the prior scale like the variance
+    co = oracle.gp_cov(x, h, w, Lo, xo)
+    assert c.shape == (M, M)
+    assert float(np.max(np.abs(c - co))) / k0 < RTOL
     m2 = fit.predict(xo, want_var=False)[0]    # fused mean-only path through alpha
     assert relmax(m2, mo) < RTOL
     fit.close()
@@ -694,6 +699,54 @@ def test_device_integrals_nd(engine, oracle, d):
                   oracle.int_int_K1_K2_K1(x, 0.7, w1, 1.2, w2, mu, cov)) < 1e-11
     assert relmax(engine.int_int_K1_K2(x, 0.7, w1, 1.2, w2, mu, cov),
                   oracle.int_int_K1_K2(x, 0.7, w1, 1.2, w2, mu, cov)) < 1e-12
+
+
+@pytest.mark.parametrize("n,d", [(9, 1), (300, 1), (1000, 1), (70, 2)])
+def test_device_integrals_same(engine, n, d):
+    """The reference's "_same" contracts (tests/test_gauss_c.py:40-56,107-143,173-209,237-272,
+    300-335: twenty calls on the same inputs, compared with ==) for the device integrals and
+    for the fused V(Z): no atomics, no launch-order-dependent summation."""
+    rs = np.random.RandomState(100 * n + d)
+    if d == 1:
+        x, x2 = np.sort(rs.uniform(-5, 5, n)), np.sort(rs.uniform(-6, 4, n // 2 + 3))
+        mu, cov = MU1, COV1
+    else:
+        x, x2 = rs.uniform(-2, 2, (d, n)), rs.uniform(-2, 2, (d, n // 2 + 3))
+        A = rs.rand(d, d)
+        mu, cov = rs.uniform(-0.5, 0.5, d), A.dot(A.T) + d * np.eye(d)
+    w1, w2 = rs.uniform(0.9, 1.5, d), rs.uniform(1.6, 2.2, d)
+    calls = {
+        "int_K": lambda: engine.int_K(x, 0.2, w1, mu, cov),
+        "int_K1_K2": lambda: engine.int_K1_K2(x, x2, 0.2, w1, 15.0, w2, mu, cov),
+        "int_int_K1_K2_K1": lambda: engine.int_int_K1_K2_K1(x, 0.2, w1, 15.0, w2, mu, cov),
+        "int_int_K1_K2": lambda: engine.int_int_K1_K2(x, 0.2, w1, 15.0, w2, mu, cov),
+    }
+    for name, f in calls.items():
+        first = np.array(f(), copy=True)
+        assert np.all(np.isfinite(first)), name
+        for _ in range(19):
+            assert np.array_equal(np.asarray(f()), first), name
+
+
+@pytest.mark.parametrize("ns,nc", [(9, 2), (200, 17), (700, 64)])
+def test_device_Z_var_same(engine, ns, nc):
+    """bq_bq_Z_var (and Z_mean) twenty times on the same resident fits: == (the reference's
+    test_bq_object.py:136-141 asserts == for Z_mean; its gauss_c "_same" tests for the terms)."""
+    rs = np.random.RandomState(ns)
+    dx = 10.0 / (ns - 1)
+    xs = np.linspace(-5, 5, ns) + rs.uniform(-dx / 4, dx / 4, ns)
+    ls = np.exp(wl.norm_logpdf(xs))
+    xc = np.sort(rs.uniform(-6, 6, nc))
+    xsc = np.concatenate([xs, xc])
+    lsc = np.concatenate([ls, np.exp(wl.norm_logpdf(xc))])
+    f1 = engine.gp_fit(xs, np.log(ls), 15.0, 1.5 * dx, 1e-3)
+    f2 = engine.gp_fit(xsc, lsc, 0.2, 1.5 * dx, 1e-3)
+    zv = [engine.Z_var(f1, f2, MU1, COV1) for _ in range(20)]
+    zm = [engine.Z_mean(f2, MU1, COV1) for _ in range(20)]
+    assert np.isfinite(zv[0]) and np.isfinite(zm[0])
+    assert all(v == zv[0] for v in zv)
+    assert all(m == zm[0] for m in zm)
+    f1.close(), f2.close()
 
 
 def test_device_moments_known_answers(engine, oracle):

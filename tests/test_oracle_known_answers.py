@@ -198,6 +198,13 @@ def test_gp_fit_consistency(oracle):
     assert np.allclose(mean, Ks.dot(alpha), atol=1e-9)
     cov = _K(h, w, xo, xo) - Ks.dot(np.linalg.solve(K, Ks.T))
     assert np.allclose(var, np.diag(cov), atol=1e-9)
+    # the full posterior covariance (gp.GP.cov, bq.py:325,496): every entry against the
+    # textbook formula, its diagonal against the marginal variance, symmetric to the bit
+    co = oracle.gp_cov(x, h, w, L, xo)
+    assert co.shape == (37, 37)
+    assert np.allclose(co, cov, rtol=0, atol=1e-9)
+    assert np.allclose(np.diag(co), var, rtol=0, atol=1e-14)
+    assert (co == co.T).all()
 
 
 def test_gp_2d(oracle):
