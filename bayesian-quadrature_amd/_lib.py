@@ -38,6 +38,7 @@ SIGNATURES = {
     "bq_set_lookahead": (C.c_int, [_vp, C.c_int]),
     "bq_set_lookahead_rows": (C.c_int, [_vp, C.c_int]),
     "bq_get_config": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bq_ctx_stats": (C.c_int, [_vp, _i64p, C.c_int]),
     "bq_ctx_trim": (C.c_int, [_vp]),
     "bq_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "bq_dev_free": (C.c_int, [_vp, _vp]),

@@ -295,6 +295,19 @@ extern "C" int bq_get_config(bq_ctx *c, int *nb, int *lookahead, int *min_rows)
     return BQ_OK;
 }
 
+extern "C" int bq_ctx_stats(bq_ctx *c, int64_t *out, int n)
+{
+    if (!c)
+        return BQ_ERR_BAD_ARG;
+    if (!out || n < 0)
+        return fail(c, BQ_ERR_BAD_ARG, "illegal value");
+    for (int i = 0; i < n; ++i)
+        out[i] = 0;
+    if (n > 0)
+        out[0] = c->n_flow_fallback;
+    return BQ_OK;
+}
+
 extern "C" int bq_set_lookahead_rows(bq_ctx *c, int min_rows)
 {
     if (!c || min_rows < 0)

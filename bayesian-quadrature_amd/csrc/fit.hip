@@ -163,13 +163,15 @@ int fit_alpha(bq_ctx *c, bq_fit *f)
     BQCHK(fit_vec(c, f));
     // (the gather stays outside the captured chain: the y row moves when the fit carries
     // border points, bq_gp_refit_predict)
-    BQCHK(launch_gather_row(c, f->vec.d(), f->A.d() + f->L.yrow, f->ldl, f->npad));
-    BQCHK(fit_replay(c, f, 1, [&]() -> int {
-        return enqueue_backward_vec(c, f->vec.d(), f->alpha.d(), f->A.d(), f->ldl, f->npad, w,
-                                    f->vec.d() + 2 * (size_t)f->npad);
+    BQCHK(with_flow_fallback(c, [&]() -> int {
+        BQCHK(launch_gather_row(c, f->vec.d(), f->A.d() + f->L.yrow, f->ldl, f->npad));
+        BQCHK(fit_replay(c, f, 1, [&]() -> int {
+            return enqueue_backward_vec(c, f->vec.d(), f->alpha.d(), f->A.d(), f->ldl, f->npad, w,
+                                        f->vec.d() + 2 * (size_t)f->npad);
+        }));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return BQ_OK;
     }));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    BQCHK(flow_check(c));
     f->have_alpha = true;
     return BQ_OK;
 }

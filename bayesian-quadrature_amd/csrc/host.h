@@ -93,6 +93,8 @@ struct bq_ctx {
                          // (trsvflow.h; BQ_TRSV_FLOW=0: one launch per block column)
     int trsv_flow_min = 2048; // ... from this many rows on (BQ_TRSV_FLOW_MIN)
     int *flow_abort = nullptr; // mapped host word a timed-out hand-off raises
+    long n_flow_fallback = 0;  // solves re-issued on the per-block sweeps after such a time-out
+                               // (bq_ctx_stats)
     int pair_border = 1; // bq_pair_esm as S factorisations + border rows (BQ_PAIR_BORDER=0: the S Ma
                          // full bordered systems)
     int df_halves = 0;   // the diagonal-first sweep as two half-batches on the two streams (BQ_DF_HALVES)
@@ -577,6 +579,25 @@ int fit_replay(bq_ctx *c, bq_fit *f, int slot, F &&enqueue)
         return BQ_OK;
     }
     return enqueue();
+}
+// A one-launch sweep whose hand-off timed out (trsvflow.h: a shared device, a lost slot) has raised
+// the context's abort word and every spinner has left: the results of `attempt` are garbage.
+// Degrade, do not fail: clear the word, count the event (bq_ctx_stats) and re-issue the SAME
+// solve -- `attempt` restages its inputs and ends with the stream synchronised -- on the per-block
+// kernels, which compute the same bits (test_flow_sweeps_same_bits_as_per_block_launches).
+bool flow_timed_out(bq_ctx *c);
+template <class F>
+int with_flow_fallback(bq_ctx *c, F &&attempt)
+{
+    int st = attempt();
+    if (st != BQ_OK || !flow_timed_out(c))
+        return st;
+    ++c->n_flow_fallback;
+    const int saved = c->trsv_flow;
+    c->trsv_flow = 0;
+    st = attempt();
+    c->trsv_flow = saved;
+    return st;
 }
 // plan.hip: new kernel parameters for every problem of a plan, nothing else re-uploaded
 int plan_set_params(bq_ctx *c, bq_plan *p, const double *h, const double *w, const double *s);

@@ -300,13 +300,23 @@ int launch_trsv_flow(bq_ctx *c, bool forward, const double *L, long ldl, int npa
     return BQ_OK;
 }
 
-int flow_check(bq_ctx *c)
+// reads and clears the abort word (call with the stream synchronised)
+bool flow_timed_out(bq_ctx *c)
 {
     if (c->flow_abort && *static_cast<volatile int *>(c->flow_abort) != 0) {
         *c->flow_abort = 0;
+        return true;
+    }
+    return false;
+}
+
+// a time-out nobody handled (every entry point that launches a one-launch sweep re-issues the
+// solve itself: with_flow_fallback): bq_ctx_sync reports it
+int flow_check(bq_ctx *c)
+{
+    if (flow_timed_out(c))
         return fail(c, BQ_ERR_HIP, "single-vector sweep: a hand-off between workgroups timed out "
                                    "(BQ_TRSV_FLOW=0 selects the one-launch-per-block sweeps)");
-    }
     return BQ_OK;
 }
 

@@ -1,6 +1,7 @@
 // linalg.hip -- the linalg_c drop-ins (cho_factor, cho_solve, logdet: linalg_c.pyx:55-210) on
 // host buffers, the Gram entry points and the device-resident Cholesky.
 #include "host.h"
+#include <vector>
 
 using namespace bqh;
 
@@ -185,22 +186,33 @@ extern "C" int bq_cho_solve(bq_ctx *c, const double *L, const double *B, double 
     if (nrhs == 1) {
         // one right-hand side: the GEMV sweeps (trsv.h)
         HIPCHK(c, Xd.alloc(sizeof(double) * (2 * (size_t)npad + trsv_flow_ws_doubles(npad, w.B))));
-        HIPCHK(c, hipMemsetAsync(Xd.p, 0, sizeof(double) * 2 * (size_t)npad, c->stream));
         double *x = Xd.d(), *y = Xd.d() + npad, *fw = Xd.d() + 2 * (size_t)npad;
-        if (small)
-            BQCHK(launch_flow_in(c, ds + n + (size_t)n * n, (int)n, x, npad, nullptr, 0));
-        else
-            HIPCHK(c, hipMemcpyAsync(Xd.p, B, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-        BQCHK(enqueue_forward_vec(c, x, y, A.d(), ldl, npad, w, fw));
-        BQCHK(enqueue_backward_vec(c, y, x, A.d(), ldl, npad, w, fw));
-        if (small)
-            BQCHK(launch_flow_out(c, x, (int)n, ds));
-        else
-            HIPCHK(c, hipMemcpyAsync(X, x, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        // (X may alias B, linalg_c.pyx:128: the right-hand side is staged before any attempt
+        // writes X; a timed-out hand-off re-issues the solve on the per-block kernels)
+        std::vector<double> b0;
+        if (!small && X == B)
+            b0.assign(B, B + n);
+        const double *bsrc = b0.empty() ? B : b0.data();
+        BQCHK(with_flow_fallback(c, [&]() -> int {
+            HIPCHK(c, hipMemsetAsync(Xd.p, 0, sizeof(double) * 2 * (size_t)npad, c->stream));
+            if (small)
+                BQCHK(launch_flow_in(c, ds + n + (size_t)n * n, (int)n, x, npad, nullptr, 0));
+            else
+                HIPCHK(c, hipMemcpyAsync(Xd.p, bsrc, sizeof(double) * n, hipMemcpyHostToDevice,
+                                         c->stream));
+            BQCHK(enqueue_forward_vec(c, x, y, A.d(), ldl, npad, w, fw));
+            BQCHK(enqueue_backward_vec(c, y, x, A.d(), ldl, npad, w, fw));
+            if (small)
+                BQCHK(launch_flow_out(c, x, (int)n, ds));
+            else
+                HIPCHK(c, hipMemcpyAsync(X, x, sizeof(double) * n, hipMemcpyDeviceToHost,
+                                         c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            return BQ_OK;
+        }));
         if (small)
             std::memcpy(X, hs, sizeof(double) * (size_t)n);
-        return flow_check(c);
+        return BQ_OK;
     }
     return solve_rows_host(c, A.d(), ldl, (int)n, npad, w, B, nrhs, X);
 }

@@ -389,47 +389,49 @@ extern "C" int bq_gp_solve(bq_ctx *c, bq_fit *f, const double *B, int64_t nrhs, 
         BQCHK(fit_wide(c, f, wv));
         BQCHK(fit_vec(c, f));
         double *x = f->vec.d(), *y = f->vec.d() + npad;
-        // through the fit's pinned staging vector (zero padded): truly asynchronous copies
-        std::memcpy(f->hvec, B, sizeof(double) * n);
-        std::memset(f->hvec + n, 0, sizeof(double) * (npad - n));
-        if (c->solve_kcopy && trsv_flow_ok(c, npad, wv.B, true)) {
-            // [x | y | ws_f | x_out | ws_b]: the vector comes in and goes out through kernels on
-            // the mapped pinned vector, and one of them sets both sweeps' hand-off slots
-            double *hdev = nullptr;
-            HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&hdev), f->hvec, 0));
-            const size_t wsn = trsv_flow_ws_doubles(npad, wv.B);
-            double *wsf = y + npad, *xo = wsf + wsn, *wsb = xo + npad;
-            BQCHK(launch_flow_in(c, hdev, n, x, npad, y, 2 * (size_t)npad + 2 * wsn));
-            BQCHK(launch_trsv_flow(c, true, f->A.d(), f->ldl, npad, wv.B, wv.nr, wv.tt, x, y, wsf,
-                                   true));
-            BQCHK(launch_trsv_flow(c, false, f->A.d(), f->ldl, npad, wv.B, wv.nt, wv.uu, y, xo, wsb,
-                                   true));
-            BQCHK(launch_flow_out(c, xo, n, hdev));
+        // (a timed-out hand-off of the one-launch sweeps re-issues the solve on the per-block
+        // kernels: with_flow_fallback)
+        BQCHK(with_flow_fallback(c, [&]() -> int {
+            // through the fit's pinned staging vector (zero padded): truly asynchronous copies
+            std::memcpy(f->hvec, B, sizeof(double) * n);
+            std::memset(f->hvec + n, 0, sizeof(double) * (npad - n));
+            if (c->solve_kcopy && trsv_flow_ok(c, npad, wv.B, true)) {
+                // [x | y | ws_f | x_out | ws_b]: the vector comes in and goes out through kernels
+                // on the mapped pinned vector, and one of them sets both sweeps' hand-off slots
+                double *hdev = nullptr;
+                HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&hdev), f->hvec, 0));
+                const size_t wsn = trsv_flow_ws_doubles(npad, wv.B);
+                double *wsf = y + npad, *xo = wsf + wsn, *wsb = xo + npad;
+                BQCHK(launch_flow_in(c, hdev, n, x, npad, y, 2 * (size_t)npad + 2 * wsn));
+                BQCHK(launch_trsv_flow(c, true, f->A.d(), f->ldl, npad, wv.B, wv.nr, wv.tt, x, y,
+                                       wsf, true));
+                BQCHK(launch_trsv_flow(c, false, f->A.d(), f->ldl, npad, wv.B, wv.nt, wv.uu, y, xo,
+                                       wsb, true));
+                BQCHK(launch_flow_out(c, xo, n, hdev));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                return BQ_OK;
+            }
+            double *hmap = nullptr;
+            if (c->solve_kcopy)
+                HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&hmap), f->hvec, 0));
+            if (hmap)
+                BQCHK(launch_flow_in(c, hmap, n, x, npad, nullptr, 0));
+            else
+                HIPCHK(c, hipMemcpyAsync(x, f->hvec, sizeof(double) * npad, hipMemcpyHostToDevice,
+                                         c->stream));
+            BQCHK(fit_replay(c, f, 0, [&]() -> int {
+                double *ws = f->vec.d() + 2 * (size_t)npad;
+                BQCHK(enqueue_forward_vec(c, x, y, f->A.d(), f->ldl, npad, wv, ws));
+                return enqueue_backward_vec(c, y, x, f->A.d(), f->ldl, npad, wv, ws);
+            }));
+            if (hmap)
+                BQCHK(launch_flow_out(c, x, n, hmap));
+            else
+                HIPCHK(c, hipMemcpyAsync(f->hvec, x, sizeof(double) * n, hipMemcpyDeviceToHost,
+                                         c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            BQCHK(flow_check(c));
-            std::memcpy(X, f->hvec, sizeof(double) * n);
             return BQ_OK;
-        }
-        double *hmap = nullptr;
-        if (c->solve_kcopy)
-            HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&hmap), f->hvec, 0));
-        if (hmap)
-            BQCHK(launch_flow_in(c, hmap, n, x, npad, nullptr, 0));
-        else
-            HIPCHK(c, hipMemcpyAsync(x, f->hvec, sizeof(double) * npad, hipMemcpyHostToDevice,
-                                     c->stream));
-        BQCHK(fit_replay(c, f, 0, [&]() -> int {
-            double *ws = f->vec.d() + 2 * (size_t)npad;
-            BQCHK(enqueue_forward_vec(c, x, y, f->A.d(), f->ldl, npad, wv, ws));
-            return enqueue_backward_vec(c, y, x, f->A.d(), f->ldl, npad, wv, ws);
         }));
-        if (hmap)
-            BQCHK(launch_flow_out(c, x, n, hmap));
-        else
-            HIPCHK(c, hipMemcpyAsync(f->hvec, x, sizeof(double) * n, hipMemcpyDeviceToHost,
-                                     c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        BQCHK(flow_check(c));
         std::memcpy(X, f->hvec, sizeof(double) * n);
         return BQ_OK;
     }
@@ -488,23 +490,25 @@ extern "C" int bq_bq_Z_var(bq_ctx *c, bq_fit *gp_tl, bq_fit *gp_l, const double 
     // alpha' (int int K_l K_tl K_l) alpha
     BQCHK(dev_iikk(c, d, gp_l->pts.d(), nsc, gp_l->h, gp_l->w, gp_tl->h, gp_tl->w, mu, S, work,
                    nullptr, gp_l->alpha.d(), part, scal));
-    // beta = (int K_tl K_l) alpha
-    HIPCHK(c, hipMemsetAsync(sol, 0, sizeof(double) * (size_t)npad, c->stream));
-    BQCHK(dev_int_K1_K2(c, d, gp_tl->pts.d(), ns, gp_l->pts.d(), nsc, gp_tl->w, gp_l->w, mu, S,
-                        (gp_tl->h * gp_tl->h) * (gp_l->h * gp_l->h), nullptr, gp_l->alpha.d(),
-                        sol));
-    // beta' K_tl^-1 beta = |L_tl^-1 beta|^2: the forward sweep alone and a sum of squares
-    // (the reference solves with both sweeps and takes the dot product, bq_c.pyx:348-351; the
-    // symmetric form errs with cond(L) instead of cond(K))
-    BQCHK(fit_replay(c, gp_tl, 2, [&]() -> int {
-        return enqueue_forward_vec(c, sol, X, gp_tl->A.d(), gp_tl->ldl, npad, wi,
-                                   gp_tl->vec.d() + 2 * (size_t)npad);
-    }));
-    BQCHK(launch_neg_sumsq(c, X, npad, scal + 1));
     double hs[2];
-    HIPCHK(c, hipMemcpyAsync(hs, scal, sizeof hs, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    BQCHK(flow_check(c));
+    BQCHK(with_flow_fallback(c, [&]() -> int {
+        // beta = (int K_tl K_l) alpha
+        HIPCHK(c, hipMemsetAsync(sol, 0, sizeof(double) * (size_t)npad, c->stream));
+        BQCHK(dev_int_K1_K2(c, d, gp_tl->pts.d(), ns, gp_l->pts.d(), nsc, gp_tl->w, gp_l->w, mu, S,
+                            (gp_tl->h * gp_tl->h) * (gp_l->h * gp_l->h), nullptr, gp_l->alpha.d(),
+                            sol));
+        // beta' K_tl^-1 beta = |L_tl^-1 beta|^2: the forward sweep alone and a sum of squares
+        // (the reference solves with both sweeps and takes the dot product, bq_c.pyx:348-351; the
+        // symmetric form errs with cond(L) instead of cond(K))
+        BQCHK(fit_replay(c, gp_tl, 2, [&]() -> int {
+            return enqueue_forward_vec(c, sol, X, gp_tl->A.d(), gp_tl->ldl, npad, wi,
+                                       gp_tl->vec.d() + 2 * (size_t)npad);
+        }));
+        BQCHK(launch_neg_sumsq(c, X, npad, scal + 1));
+        HIPCHK(c, hipMemcpyAsync(hs, scal, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return BQ_OK;
+    }));
     *out = hs[0] + hs[1]; // hs[1] holds -|L^-1 beta|^2
     return BQ_OK;
 }

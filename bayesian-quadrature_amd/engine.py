@@ -111,6 +111,13 @@ class Engine(object):
         self._check(self._lib.bq_get_config(self._ctx, C.byref(nb), C.byref(la), C.byref(mr)))
         return nb.value, bool(la.value), mr.value
 
+    def stats(self):
+        """Counters of the context: ``flow_fallbacks`` = single-vector solves re-issued on the
+        per-block sweeps after a hand-off of the one-launch sweeps timed out."""
+        v = (C.c_int64 * 4)()
+        self._check(self._lib.bq_ctx_stats(self._ctx, v, 4))
+        return {"flow_fallbacks": int(v[0])}
+
     def trim(self):
         """Release the workspace the batched calls keep between calls."""
         self._check(self._lib.bq_ctx_trim(self._ctx))

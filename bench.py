@@ -124,6 +124,9 @@ def parse():
     ap.add_argument("--workload", default=None, choices=["c2", "c5"],
                     help="default: c2 on one GPU, c5 (the batched config) on several")
     ap.add_argument("--batch", type=int, default=0, help="problems per GPU per step (0 = default)")
+    ap.add_argument("--curve-batch", type=int, default=0,
+                    help="problems per GPU of the scaling-curve workload (C5 shard) measured as "
+                         "scale_point at N = 1 (0 = --batch when the workload is c5, else 64)")
     ap.add_argument("--no-extras", action="store_true", help="skip the C3/C4 roofline runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nb", type=int, default=0, help="outer Cholesky block override")
@@ -133,6 +136,8 @@ def parse():
     a = ap.parse_args()
     if a.workload is None:
         a.workload = "c2" if a.gpus == 1 else "c5"
+    if not a.curve_batch:
+        a.curve_batch = (a.batch if a.workload == CURVE_WORKLOAD else 0) or 64
     return a
 
 
@@ -150,8 +155,9 @@ def self_launch(a):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
-                                      env=env))
+        # (the script this process was started as: tests wrap main() in a launcher of their own)
+        script = os.path.abspath(sys.argv[0]) if sys.argv and sys.argv[0] else os.path.abspath(__file__)
+        procs.append(subprocess.Popen([sys.executable, script] + sys.argv[1:], env=env))
     rcs = [None] * len(procs)
     # a rank that dies leaves the others in the gloo barrier: stop them instead of waiting
     while any(rc is None for rc in rcs):
@@ -220,6 +226,29 @@ class Dist(object):
             self.td.destroy_process_group()
 
 
+def device_count():
+    """HIP devices visible to libbqhip.so (0 without a GPU: there is no CPU fallback)."""
+    import ctypes as C
+    from bayesian_quadrature_amd import _lib as L_
+    ndev = C.c_int(0)
+    L_.load_library().bq_device_count(C.byref(ndev))
+    return ndev.value
+
+
+# the workload of the 1 -> N scaling curve: a C5 shard per GPU (BASELINE config 5, SURVEY 8e)
+CURVE_WORKLOAD = "c5"
+NOISE_NOTE = ("s != 0 noise form unpinned by the reference: every reference-held number has "
+              "s = 0; Kxx = K + s^2 I is the textbook form recalled for the absent gp package "
+              "(BASELINE.md section 3, SURVEY 8c)")
+
+
+def make_workload_desc(name, batch):
+    """The description string make_workload(name, batch, .) puts in `desc` (no data built)."""
+    if name == "c2":
+        return "C2: d=1 N=1024 M=256 Gaussian integrand, w=dx, s=1e-3"
+    return "C5 shard: %d x (d=1 N=2048 M=256), w=dx, s=1e-2" % (batch or 64)
+
+
 def make_workload(name, batch, rank):
     from bayesian_quadrature_amd import workloads as wl
     if name == "c2":
@@ -228,15 +257,50 @@ def make_workload(name, batch, rank):
         x = np.repeat(c["x"][None], B, axis=0)
         y = np.repeat(c["y"][None], B, axis=0)
         xo = np.repeat(c["xo"][None], B, axis=0)
-        desc = "C2: d=1 N=1024 M=256 Gaussian integrand, w=dx, s=1e-3"
+        desc = make_workload_desc("c2", B)
         return dict(x=x, y=y, xo=xo, h=c["h"], w=c["w"], s=c["s"], d=1, n=1024, M=256, B=B,
                     desc=desc)
     B = batch or 64
     probs = [rank * B + i for i in range(B)]  # each rank owns its own block of problems
     c = wl.c5(probs)
-    desc = "C5 shard: %d x (d=1 N=2048 M=256), w=dx, s=1e-2" % B
+    desc = make_workload_desc("c5", B)
     return dict(x=c["x"], y=c["y"], xo=c["xo"], h=c["h"], w=c["w"], s=c["s"], d=1, n=2048, M=256,
                 B=B, desc=desc)
+
+
+def scale_point(eng, batch, passes=3):
+    """The N = 1 point of the scaling curve: rank 0's block of the curve workload (a C5 shard)
+    on this one GPU, inputs resident, HIP events around `passes` plan passes -- the same
+    measurement an N > 1 line reports as n1_same_workload and the same per-GPU work as its
+    `value`."""
+    wk = make_workload(CURVE_WORKLOAD, batch, 0)
+    plan = eng.plan(wk["B"], wk["d"], wk["n"], wk["M"])
+    plan.set_inputs(wk["x"], wk["y"], wk["xo"], wk["h"], wk["w"], wk["s"])
+    plan.run()
+    eng.sync()
+    eng.timer_start()
+    for _ in range(passes):
+        plan.run()
+    ms = eng.timer_stop_ms() / passes
+    status = plan.results()[3]
+    plan.close()
+    return {"workload": wk["desc"], "value": wk["B"] / ms * 1e3, "unit": "problems/s",
+            "ms_per_step": ms, "problems_per_gpu_per_step": wk["B"], "n_gpus": 1,
+            "failed": int((status != 0).sum()),
+            "note": "the N = 1 point of the C5 curve: N > 1 lines report this workload as "
+                    "`value` (whole job) and repeat this measurement as n1_same_workload"}
+
+
+def host_buffer_step(eng, wk, reps=10):
+    """One problem of the timed workload through the host-buffer entry point (bq_fit_predict:
+    plan creation, H2D, run, D2H, synchronisation inside every call) -- what a BQ user's call
+    costs; never the headline `value`."""
+    x, y, xo = wk["x"][0], wk["y"][0], wk["xo"][0]
+    eng.fit_predict(x, y, wk["h"], wk["w"], wk["s"], xo)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.fit_predict(x, y, wk["h"], wk["w"], wk["s"], xo)
+    return (time.perf_counter() - t0) / reps * 1e3
 
 
 def run_main(eng, wk, steps, warmup, dist):
@@ -324,7 +388,8 @@ def parity_spotcheck(wk, res):
     return {"mean_rel": float(np.max(np.abs(res["mean"][0] - m)) / np.max(np.abs(m))),
             "var_rel_prior": float(np.max(np.abs(res["var"][0] - v)) / k0),
             "logml_rel": float(abs(res["logml"][0] - lm) / abs(lm)),
-            "tolerance": 1e-10}
+            "tolerance": 1e-10, "against": "oracle/bq_oracle.c (CPU restatement)",
+            "noise_form": NOISE_NOTE}
 
 
 def cpu_baseline(wk, budget_s=12.0):
@@ -488,9 +553,14 @@ def extras(eng, nb_override):
             prd = dense_profile()
             eng.download(hinfo, info)
             eng.set_lookahead(True)
-            syd = prd["syrk_trailing"]
+            syd, smd = prd["syrk_trailing"], prd["syrk_trailing_small"]
             achd = syd["work"] / (syd["ms"] * 1e-3) / 1e12
+            whole_d = tfl / ((syd["ms"] + smd["ms"]) * 1e-3) / 1e12
             out["trailing_update_n16384_dense"] = {
+                "whole_trailing_update": {
+                    "algorithmic_flops": tfl, "ms_total": syd["ms"] + smd["ms"],
+                    "launches": syd["launches"] + smd["launches"], "achieved": whole_d,
+                    "frac": whole_d / PEAK_FP64_TFLOPS},
                 "kernel": TRAILING_KERNEL, "bound": "mfma", "achieved": achd,
                 "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": achd / PEAK_FP64_TFLOPS,
                 "traffic": traffic, "traffic_source": src, "launches": syd["launches"],
@@ -787,22 +857,39 @@ def batched_configs(eng):
     return out
 
 
+def curve_fields(line, wk, solo_ms, world):
+    """Top-level fields of an N > 1 line from which a reader builds the 1 -> N curve without
+    any other file: the same workload's N = 1 throughput measured in this run (rank 0 passes
+    over its shard alone while the others wait) and the efficiency against it."""
+    if solo_ms is None or world <= 1:
+        return
+    solo = wk["B"] / solo_ms * 1e3
+    line["n1_same_workload"] = {
+        "workload": wk["desc"], "value": solo, "unit": "problems/s", "ms_per_step": solo_ms,
+        "n_gpus": 1, "problems_per_gpu_per_step": wk["B"],
+        "note": "rank 0's shard of the same workload run alone (other ranks idle at the "
+                "barrier) just before the timed region; equals scale_point.value of the "
+                "--gpus 1 line"}
+    line["scaling_efficiency"] = line["value"] / (solo * world) if line["value"] else None
+    line["scaling_efficiency_note"] = ("value / (n_gpus x n1_same_workload.value): weak scaling, "
+                                       "per-GPU work fixed (a block of %d problems per rank)"
+                                       % wk["B"])
+
+
 def inproc_main(a):
     """--gpus N --inproc: the second launch mode ("one Python thread per device").
     This process creates the N contexts itself -- an EnginePool, one host thread per engine --
     and every engine passes over its own block of problems; the threads meet at a barrier
     before and after the timed region, the time is first start to last end."""
     import threading
-    import ctypes as C
-    from bayesian_quadrature_amd import EnginePool, _lib as L_
-    ndev = C.c_int(0)
-    L_.load_library().bq_device_count(C.byref(ndev))
+    from bayesian_quadrature_amd import EnginePool
+    ndev = device_count()
     share = os.environ.get("BQ_BENCH_SHARE_DEVICE", "0") == "1"
-    if ndev.value <= 0 or (ndev.value < a.gpus and not share):
+    if ndev <= 0 or (ndev < a.gpus and not share):
         print("bench.py: --gpus %d --inproc needs %d HIP devices, this box has %d"
-              % (a.gpus, a.gpus, ndev.value), file=sys.stderr)
+              % (a.gpus, a.gpus, ndev), file=sys.stderr)
         sys.exit(2)
-    pool = EnginePool([r % ndev.value for r in range(a.gpus)])
+    pool = EnginePool([r % ndev for r in range(a.gpus)])
     barrier = threading.Barrier(a.gpus)
 
     def job(rank):
@@ -813,6 +900,15 @@ def inproc_main(a):
             for _ in range(a.warmup):
                 plan.run()
             eng.sync()
+            # the N = 1 point of the curve in the same run: rank 0 alone, the others wait
+            solo_ms = None
+            barrier.wait(timeout=600)
+            if rank == 0:
+                k = max(3, min(a.steps, 10))
+                eng.timer_start()
+                for _ in range(k):
+                    plan.run()
+                solo_ms = eng.timer_stop_ms() / k
             barrier.wait(timeout=600)
             t0 = time.perf_counter()
             for _ in range(a.steps):
@@ -833,7 +929,7 @@ def inproc_main(a):
             plan.close()
             return dict(rank=rank, device=eng.device, t0=t0, t1=t1, wk=wk, mean=mean, var=var,
                         logml=logml, status=status, info=eng.info() if rank == 0 else None,
-                        host_issue_ms_per_step=(ti1 - ti0) / ki * 1e3,
+                        solo_ms=solo_ms, host_issue_ms_per_step=(ti1 - ti0) / ki * 1e3,
                         device_ms_per_step=(ti2 - ti0) / ki * 1e3)
 
         def run(eng):
@@ -864,7 +960,8 @@ def inproc_main(a):
         "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": wk["desc"], "problems_per_gpu_per_step": wk["B"],
+        "config": {"workload": wk["desc"], "value_is": "problems/s of the whole job on: " + wk["desc"],
+                   "curve_workload": wk["desc"], "problems_per_gpu_per_step": wk["B"],
                    "sharding": "independent problems per device, no data-path collective",
                    "launch_mode": "inproc: one process, an engine and a host thread per device",
                    "ranks": [{"rank": r["rank"], "device": r["device"],
@@ -874,6 +971,7 @@ def inproc_main(a):
         "failed_problems": nfail, "device": res[0]["info"],
         "parity": parity_spotcheck(wk, res[0]),
     }
+    curve_fields(line, wk, res[0]["solo_ms"], a.gpus)
     p = line["parity"]
     if not (p["mean_rel"] < 1e-10 and p["var_rel_prior"] < 1e-10 and p["logml_rel"] < 1e-10) \
             or nfail:
@@ -896,22 +994,19 @@ def main():
     # The engine (HIP context on LOCAL_RANK) exists before torch is imported; torch is used
     # for the gloo barrier and reductions on CPU tensors only and never initialises HIP.
     from bayesian_quadrature_amd import Engine
-    import ctypes as C
-    from bayesian_quadrature_amd import _lib as L_
-    ndev = C.c_int(0)
-    L_.load_library().bq_device_count(C.byref(ndev))
-    if ndev.value <= 0:
+    ndev = device_count()
+    if ndev <= 0:
         print("bench.py needs a HIP device (no CPU fallback)", file=sys.stderr)
         sys.exit(2)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # one device per rank; BQ_BENCH_SHARE_DEVICE=1 lets several ranks share a device (the
     # two-rank rehearsal on a one-GPU box in tests/test_sharding.py), never a measurement
     share = os.environ.get("BQ_BENCH_SHARE_DEVICE", "0") == "1"
-    if ndev.value < world and not share:
+    if ndev < world and not share:
         print("bench.py: --gpus %d needs %d HIP devices, this box has %d"
-              % (a.gpus, world, ndev.value), file=sys.stderr)
+              % (a.gpus, world, ndev), file=sys.stderr)
         sys.exit(2)
-    eng = Engine(local_rank % ndev.value)
+    eng = Engine(local_rank % ndev)
     dist = Dist(a.gpus)
     if a.nb:
         eng.set_block(a.nb)
@@ -983,7 +1078,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": wk["desc"], "problems_per_gpu_per_step": wk["B"],
+            "config": {"workload": wk["desc"],
+                       "value_is": "problems/s of the whole job on: " + wk["desc"],
+                       "curve_workload": make_workload_desc(CURVE_WORKLOAD, a.curve_batch),
+                       "curve_note": "the 1 -> N scaling curve is on curve_workload: N = 1 reads "
+                                     "scale_point.value of the --gpus 1 line (whose `value` is "
+                                     "config.workload), N > 1 reads `value`; every N > 1 line "
+                                     "repeats the N = 1 point as n1_same_workload",
+                       "problems_per_gpu_per_step": wk["B"],
                        "bordered_system": ntot, "sharding": "independent problems per rank, "
                        "no data-path collective",
                        "ranks": res["ranks"]},
@@ -996,16 +1098,23 @@ def main():
             "plan_bytes": res["plan_bytes"],
             "roofline": roof,
         }
-        if res["solo_ms"] is not None:
-            solo = wk["B"] / res["solo_ms"] * 1e3
-            line["single_rank_reference"] = {
-                "ms_per_step": res["solo_ms"], "problems_per_s": solo,
-                "parallel_efficiency_in_run": value / (solo * dist.world),
-                "note": "rank 0's shard of the same workload run alone (other ranks idle at "
-                        "the barrier) just before the timed region; informational -- the "
-                        "driver computes scaling from the per-N `value`s"}
+        curve_fields(line, wk, res["solo_ms"], dist.world)
         line["parity"] = parity_spotcheck(wk, res)
         if dist.world == 1:
+            # the N = 1 point of the C5 curve, whatever the headline workload is
+            if a.workload == CURVE_WORKLOAD:
+                line["scale_point"] = {
+                    "workload": wk["desc"], "value": value, "unit": "problems/s",
+                    "ms_per_step": res["wall"] / a.steps * 1e3, "n_gpus": 1,
+                    "problems_per_gpu_per_step": wk["B"], "failed": int(nfail),
+                    "note": "this line's own value: the headline workload is the curve workload"}
+            else:
+                line["scale_point"] = scale_point(eng, a.curve_batch)
+            line["ms_per_step_host_buffers"] = host_buffer_step(eng, wk)
+            line["ms_per_step_host_buffers_note"] = (
+                "one problem of config.workload through bq_fit_predict with host buffers: plan "
+                "creation + H2D + run + D2H + synchronisation per call (what a BQ user's call "
+                "costs); `value` / ms_per_step have the inputs resident")
             try:
                 line["probes"] = {"mfma_f64_tflops": eng.probe_mfma_f64(),
                                   "mfma_f64_4x4x4_4b_tflops": eng.probe_mfma_variant(1, 8, 2),
@@ -1025,8 +1134,20 @@ def main():
                 # `rooflines` and is reproducible from profiles/ 
                 rl = line["rooflines"]
                 roof = line["roofline"]
-                roof["trailing_update_n16384_frac_dense"] = rl["trailing_update_n16384_dense"]["frac"]
-                roof["trailing_update_n16384_frac_c4_data"] = rl["trailing_update_n16384"]["frac"]
+                # 1.4318e12 flop / sum of ALL trailing kernel time (bulk launches on
+                # gemm_lds_kernel + the small ones + the one-launch steps' updates); the bulk
+                # launches' own rate stays beside it under its own name
+                roof["trailing_update_n16384_frac_dense"] = \
+                    rl["trailing_update_n16384_dense"]["whole_trailing_update"]["frac"]
+                roof["trailing_update_n16384_frac_c4_data"] = \
+                    rl["trailing_update_n16384"]["whole_trailing_update"]["frac"]
+                roof["trailing_update_n16384_frac_definition"] = (
+                    "sum_k m_k^2 nb = 1.4318e12 flop / the time of every trailing-update launch "
+                    "(sequential launches, HIP events per launch)")
+                roof["trailing_update_n16384_bulk_launches_frac_dense"] = \
+                    rl["trailing_update_n16384_dense"]["frac"]
+                roof["trailing_update_n16384_bulk_launches_frac_c4_data"] = \
+                    rl["trailing_update_n16384"]["frac"]
                 roof["gram_n4096_frac"] = rl["gram_n4096_d2"]["frac"]
                 roof["gram_n4096_frac_note"] = "134 MB: Infinity-Cache resident, not an HBM figure"
                 roof["gram_n16384_frac"] = rl["gram_n16384_d1"]["frac"]

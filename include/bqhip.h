@@ -70,6 +70,12 @@ int bq_set_lookahead_rows(bq_ctx *ctx, int min_rows);
 /* the three settings above as they stand (a caller that changes them for a while reads them
  * first and puts them back; any pointer may be NULL) */
 int bq_get_config(bq_ctx *ctx, int *nb, int *lookahead, int *min_rows);
+/* counters of the context since its creation, out[0 .. n): [0] single-vector solves that were
+ * re-issued on the per-block sweeps after a hand-off of the one-launch sweeps timed out (the
+ * call still returned BQ_OK with the right answer; non-zero on a healthy, unshared device means
+ * something is wrong with it).  Entries beyond the ones defined are set to 0.  No reference
+ * counterpart (linalg_c.pyx:96-136 is a LAPACK call) */
+int bq_ctx_stats(bq_ctx *ctx, int64_t *out, int n);
 /* bq_batch_fit_predict and bq_gp_logml_grid keep their device workspace (up to half of
  * the free HBM) in the context between calls, so that a hyper-parameter loop
  * (bq.py:536-550) does not allocate and release it on every evaluation; this releases it */

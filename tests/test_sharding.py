@@ -143,6 +143,54 @@ def _run_bench(args, env_extra):
                           capture_output=True, text=True, timeout=900)
 
 
+def _line_of(r):
+    import json
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_lines_carry_the_same_curve_workload():
+    """The 1 -> N scaling curve can be computed from bench.py's own lines:
+    ``--gpus 1`` (headline C2) carries ``scale_point`` on the C5 shard, ``--gpus 2`` (two real
+    ranks over gloo) carries the same workload as ``value`` and repeats the N = 1 point as
+    ``n1_same_workload``; both name the workload under the same key.  On the CPU through
+    tests/bench_double_main.py (an oracle-backed double; the numbers mean nothing here)."""
+    import subprocess
+    launcher = os.path.join(ROOT, "tests", "bench_double_main.py")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+
+    def run(args):
+        return subprocess.run([sys.executable, launcher] + args, env=env, capture_output=True,
+                              text=True, timeout=600)
+
+    common = ["--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"]
+    one = _line_of(run(["--gpus", "1", "--curve-batch", "2"] + common))
+    two = _line_of(run(["--gpus", "2", "--batch", "2"] + common))
+    # N = 1: the headline stays C2 (BASELINE configs[1]); the curve's point is beside it
+    assert one["n_gpus"] == 1 and one["config"]["workload"].startswith("C2")
+    sp = one["scale_point"]
+    assert sp["workload"].startswith("C5 shard: 2 x") and sp["value"] > 0 and sp["n_gpus"] == 1
+    assert one["config"]["curve_workload"] == sp["workload"]
+    assert one["ms_per_step_host_buffers"] > 0
+    assert "n1_same_workload" not in one and "scaling_efficiency" not in one
+    # N = 2: value is the curve workload, the N = 1 point measured in the same run
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak"
+    assert two["config"]["workload"] == two["config"]["curve_workload"] == sp["workload"]
+    n1 = two["n1_same_workload"]
+    assert n1["workload"] == sp["workload"] and n1["value"] > 0 and n1["n_gpus"] == 1
+    assert abs(two["scaling_efficiency"] - two["value"] / (2 * n1["value"])) < 1e-12
+    assert sorted(r_["rank"] for r_ in two["config"]["ranks"]) == [0, 1]
+    assert len({r_["pid"] for r_ in two["config"]["ranks"]}) == 2
+    for line in (one, two):
+        assert line["value"] is not None and line["failed_problems"] == 0
+        assert line["parity"]["logml_rel"] < 1e-10 and "unpinned" in line["parity"]["noise_form"]
+        assert line["config"]["value_is"].endswith(line["config"]["workload"])
+
+
 @pytest.mark.gpu
 def test_bench_launches_its_own_ranks(engine):
     """``bench.py --gpus 2`` started bare spawns two ranks itself.  On a one-GPU box that
@@ -166,7 +214,9 @@ def test_bench_launches_its_own_ranks(engine):
     ranks = line["config"]["ranks"]
     assert sorted(r_["rank"] for r_ in ranks) == [0, 1]
     assert len({r_["pid"] for r_ in ranks}) == 2
-    assert line["single_rank_reference"]["ms_per_step"] > 0
+    assert line["n1_same_workload"]["ms_per_step"] > 0
+    assert line["n1_same_workload"]["workload"] == line["config"]["workload"]
+    assert 0 < line["scaling_efficiency"] < 1.5
     assert line["parity"]["logml_rel"] < 1e-10
 
 
@@ -300,6 +350,7 @@ def test_bench_inproc_mode(engine):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert line["n_gpus"] == 2 and line["value"] is not None and line["failed_problems"] == 0
     assert line["config"]["launch_mode"].startswith("inproc")
+    assert line["n1_same_workload"]["workload"] == line["config"]["workload"]
     assert sorted(r_["rank"] for r_ in line["config"]["ranks"]) == [0, 1]
     assert line["parity"]["logml_rel"] < 1e-10
 
