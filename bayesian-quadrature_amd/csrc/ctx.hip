@@ -93,6 +93,7 @@ static int ctx_init(bq_ctx *c, int device)
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_next, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_top, hipEventDisableTiming));
 
     int lo = 0, hi = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -122,8 +123,8 @@ static int ctx_init(bq_ctx *c, int device)
         c->df_wg = std::atoi(e);
     if (const char *e = std::getenv("BQ_PAIR_BORDER"))
         c->pair_border = std::atoi(e);
-    if (const char *e = std::getenv("BQ_DF_HALVES"))
-        c->df_halves = std::atoi(e);
+    if (const char *e = std::getenv("BQ_DF_EARLY"))
+        c->df_early = std::atoi(e);
     if (const char *e = std::getenv("BQ_ROWS_TAIL"))
         c->rows_tail = std::atoi(e);
     if (const char *e = std::getenv("BQ_SOLVE_KCOPY"))
@@ -222,7 +223,7 @@ extern "C" void bq_ctx_destroy(bq_ctx *c)
     if (c->hstage)
         (void)hipHostFree(c->hstage);
     c->hstage = nullptr;
-    for (hipEvent_t e : {c->ev_panel, c->ev_next, c->ev_fork})
+    for (hipEvent_t e : {c->ev_panel, c->ev_next, c->ev_fork, c->ev_top})
         if (e)
             (void)hipEventDestroy(e);
     if (c->flow_abort)

@@ -81,7 +81,7 @@ struct bq_ctx {
     hipStream_t stream = nullptr; // main stream: everything is ordered on it
     hipStream_t aux = nullptr;    // high-priority panel stream of the look-ahead Cholesky
     hipStream_t cur = nullptr;    // stream the launch helpers enqueue on (stream or aux)
-    hipEvent_t ev_panel = nullptr, ev_next = nullptr, ev_fork = nullptr;
+    hipEvent_t ev_panel = nullptr, ev_next = nullptr, ev_fork = nullptr, ev_top = nullptr;
     int lookahead = 1;
     int split_batch = 1; // halves of a mid-sized batch on the two streams (BQ_SPLIT=0: lock-step)
     int diag_first = 1;  // batches: every outer block as diagonal factor, ONE panel solve, update
@@ -97,7 +97,8 @@ struct bq_ctx {
                                // (bq_ctx_stats)
     int pair_border = 1; // bq_pair_esm as S factorisations + border rows (BQ_PAIR_BORDER=0: the S Ma
                          // full bordered systems)
-    int df_halves = 0;   // the diagonal-first sweep as two half-batches on the two streams (BQ_DF_HALVES)
+    int df_early = 1;    // the diagonal-first sweep forks before the panel solve: the next diagonal block's
+                         // rows are solved, updated and factored beside the rest of the solve (BQ_DF_EARLY)
     int rows_tail = 128; // a large row sweep's last updates as split-k tiles: from this many LDS tiles down (BQ_ROWS_TAIL)
     int solve_kcopy = 1; // a one-vector solve's vector in / out and sentinel fill by kernels (BQ_SOLVE_KCOPY)
     double *hstage = nullptr; // mapped pinned staging of the small host-buffer calls (ctx_stage)
@@ -183,7 +184,7 @@ inline unsigned long long launch_config_key(const bq_ctx *c)
     const int f[] = {c->nb_override, c->lookahead, c->split_batch, c->la_min, c->gemm_lds,
                      c->gemm_lds64, c->slab_nb_max, c->slab_max, c->fold_readout, c->potf2_8w,
                      c->gemm_ksplit, c->gemm_tile, c->diag_first, c->df_sweep, c->df_wg,
-                     c->df_halves, c->df_sharing, c->rows_tail};
+                     c->df_sharing, c->rows_tail, c->df_early};
     unsigned long long h = 1469598103934665603ull;
     for (int v : f)
         h = (h ^ (unsigned long long)(unsigned)v) * 1099511628211ull;

@@ -352,9 +352,11 @@ static int enqueue_potrf_group(bq_ctx *c, double *A, long lda, long astride, int
 // The whole batch moves in lock-step through launches that each fill the chip.
 // ---------------------------------------------------------------------------------------------
 static size_t dfirst_rec_doubles(int nb, int batch) { return (size_t)(nb / 64) * BQ_DINV_HALF * batch; }
+// (two sets of records: with the early fork the next block's diagonal factor writes its own while
+// the rest of this block's panel solve still reads this block's)
 static size_t dfirst_ws_doubles(int nb, int batch)
 {
-    return panel_ws_doubles(nb, batch) + dfirst_rec_doubles(nb, batch);
+    return panel_ws_doubles(nb, batch) + 2 * dfirst_rec_doubles(nb, batch);
 }
 
 static bool dfirst_applies(const bq_ctx *c, int ntot, int ncols, int batch)
@@ -413,26 +415,35 @@ static int enqueue_potrf_dfirst(bq_ctx *c, double *A, long lda, long astride, in
                                 int ncols, int *info, double *ws, bool skip_border)
 {
     const int NB = std::min(auto_nb(c, ntot, batch), ncols);
-    double *rec = ws + panel_ws_doubles(NB, batch);
+    double *recs[2] = {ws + panel_ws_doubles(NB, batch),
+                       ws + panel_ws_doubles(NB, batch) + dfirst_rec_doubles(NB, batch)};
     const long rstride = (long)(NB / 64) * BQ_DINV_HALF;
     const bool la = c->lookahead && c->aux && c->cur == c->stream;
-    auto diag = [&](int K0, int KB) {
+    // df_early: the streams fork BEFORE the panel solve.  The next diagonal block's chain -- the
+    // panel solve of ITS rows (the top nw of the panel), its update, its factor -- starts on the
+    // second stream at once, beside the solve of the other rows; round 4 forked after the whole
+    // panel solve, and in the late blocks the update was shorter than the chain it should hide
+    // (C5 shard: 0.11-0.14 ms exposed after three of four blocks, tools/plan_timeline.py).
+    const bool early = la && c->df_early;
+    auto diag = [&](int K0, int KB, double *rec) {
         if (dfirst_wg(c, batch))
             return launch_potrf_wg(c, A + K0 + (long)K0 * lda, lda, astride, KB, rec, rstride, info,
                                    K0, batch);
         return enqueue_slab_sweep(c, A + K0 + (long)K0 * lda, lda, astride, batch, KB, KB, rec, info,
                                   ws, K0, false, rstride);
     };
-    BQCHK(diag(0, NB));
+    BQCHK(diag(0, NB, recs[0]));
     Sharing scope(c, la ? c->df_sharing : c->sharing);
-    for (int K0 = 0; K0 < ncols; K0 += NB) {
+    int par = 0;
+    for (int K0 = 0; K0 < ncols; K0 += NB, par ^= 1) {
         const int KB = std::min(NB, ncols - K0), r0 = K0 + KB, m2 = ntot - r0;
         if (m2 <= 0)
             break;
-        BQCHK(enqueue_panel_solve(c, A, lda, astride, batch, r0, m2, K0, KB, rec, rstride));
+        const double *rec = recs[par];
         const double *P = A + r0 + (long)K0 * lda;
         const int nw = r0 < ncols ? std::min(NB, ncols - r0) : 0;
         if (nw == 0) {
+            BQCHK(enqueue_panel_solve(c, A, lda, astride, batch, r0, m2, K0, KB, rec, rstride));
             // what is left is the Schur complement of the border: nobody reads it when the
             // results come off the border rows
             if (!skip_border)
@@ -440,29 +451,49 @@ static int enqueue_potrf_dfirst(bq_ctx *c, double *A, long lda, long astride, in
                                   astride, P, 1, lda, astride, m2, m2, KB, 1, batch));
             break;
         }
-        // the next diagonal block: updated and factored (on the second stream, beside the rest)
+        const int r1 = r0 + nw;
+        if (!early)
+            BQCHK(enqueue_panel_solve(c, A, lda, astride, batch, r0, m2, K0, KB, rec, rstride));
+        // the next diagonal block: (its rows of the panel solved,) updated and factored -- on the
+        // second stream, beside the rest
         if (la) {
             HIPCHK(c, hipEventRecord(c->ev_next, c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_next, 0));
             c->cur = c->aux;
         }
-        int st = launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda, astride, P,
+        int st = BQ_OK;
+        if (early) {
+            st = enqueue_panel_solve(c, A, lda, astride, batch, r0, nw, K0, KB, rec, rstride);
+            if (st == BQ_OK)
+                HIPCHK(c, hipEventRecord(c->ev_top, c->aux));
+        }
+        if (st == BQ_OK)
+            st = launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda, astride, P,
                              1, lda, astride, nw, nw, KB, 1, batch);
         if (st == BQ_OK)
-            st = diag(r0, nw);
+            st = diag(r0, nw, recs[par ^ 1]);
         if (la) {
             c->cur = c->stream;
             if (st == BQ_OK)
                 HIPCHK(c, hipEventRecord(c->ev_panel, c->aux));
         }
         BQCHK(st);
-        const int r1 = r0 + nw;
         if (r1 < ntot) {
             const double *P1 = A + r1 + (long)K0 * lda;
-            // the rows below it: the next panel's columns, then the square behind them
+            if (early) {
+                BQCHK(enqueue_panel_solve(c, A, lda, astride, batch, r1, ntot - r1, K0, KB, rec,
+                                          rstride));
+                // the column update reads the top rows as its Q operand
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_top, 0));
+            }
+            // the rows below it: the next panel's columns, then the square behind them.  (ONE
+            // launch over everything right of the panel with the next diagonal block's tiles
+            // skipped -- one launch tail instead of two -- was measured in round 5 and gained
+            // nothing: C5 5.67 / 256 x C2 4.21 / C3 177-183 either way; removed.)
+            const bool sq = !(skip_border && r1 >= ncols);
             BQCHK(launch_gemm(c, BQ_K_SYRK, A + r1 + (long)r0 * lda, lda, astride, P1, lda, astride,
                               P, 1, lda, astride, ntot - r1, nw, KB, 0, batch));
-            if (!(skip_border && r1 >= ncols))
+            if (sq)
                 BQCHK(launch_gemm(c, BQ_K_SYRK, A + r1 + (long)r1 * lda, lda, astride, P1, lda,
                                   astride, P1, 1, lda, astride, ntot - r1, ntot - r1, KB, 1, batch,
                                   -1, nullptr, 0, nullptr, skip_border ? ncols - r1 : 0));
@@ -489,31 +520,13 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
     const int NB = auto_nb(c, ntot, batch);
     if (dfirst_applies(c, ntot, ncols, batch) && panel_ws &&
         panel_ws_len >= dfirst_ws_doubles(std::min(NB, ncols), batch)) {
-        // (df_halves: the two halves of the batch on the two streams, each in lock-step with its
-        // diagonal factors on its own stream -- one half's tails and factor chains beside the
-        // other half's launches)
-        if (c->df_halves && c->aux && c->cur == c->stream && batch >= 8) {
-            const int b0 = batch / 2, b1 = batch - b0;
-            const int nbw = std::min(NB, ncols);
-            Sharing halves(c, 2);
-            const int la_keep = c->lookahead;
-            c->lookahead = 0;
-            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-            c->cur = c->aux;
-            int st = enqueue_potrf_dfirst(c, A + (long)b0 * astride, lda, astride, b1, ntot, ncols,
-                                          info + b0, panel_ws + dfirst_ws_doubles(nbw, b0),
-                                          skip_border);
-            c->cur = c->stream;
-            if (st == BQ_OK)
-                st = enqueue_potrf_dfirst(c, A, lda, astride, b0, ntot, ncols, info, panel_ws,
-                                          skip_border);
-            c->lookahead = la_keep;
-            BQCHK(st);
-            HIPCHK(c, hipEventRecord(c->ev_panel, c->aux));
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_panel, 0));
-            return BQ_OK;
-        }
+        // (Two half-batches on the two streams, each in lock-step with its diagonal factors on its
+        // own stream, were measured in rounds 4 and 5 -- in phase: C5 shard 5.77 ms / 256 x C2 4.33
+        // against 5.67 / 4.21 for the whole batch in lock-step; out of phase, the second half
+        // starting when the first half's first panel solve is through, so that one half's
+        // panel-solve workgroups and diagonal chains run beside the other half's update tiles:
+        // 5.87 / 4.52-4.81, C3 186-188 against 177 -- and removed: every launch of a half fills
+        // the chip half as well, and two MFMA-bound kernels gain nothing from sharing CUs.)
         return enqueue_potrf_dfirst(c, A, lda, astride, batch, ntot, ncols, info, panel_ws,
                                     skip_border);
     }

@@ -1565,8 +1565,8 @@ def test_batch_dense_vs_oracle_and_variants(engine, oracle, batch, n, m):
     """A batch of DENSE 2-D problems (outer block 128: diagonal block first -- a workgroup per
     matrix from 96 matrices on, the one-launch steps below) against the oracle, and every switch of
     the batched sweep against the default on the same inputs: the recursive panels of rounds 1-3
-    (BQ_DIAG_FIRST=0), either form of the diagonal factor, the recursive panel solve, two
-    half-batches."""
+    (BQ_DIAG_FIRST=0), either form of the diagonal factor, the recursive panel solve, the fork
+    after instead of before the panel solve, no second stream."""
     import os
     from bayesian_quadrature_amd import Engine
     x, y, xo, h, w, s = _dense_batch(batch, n, m)
@@ -1579,7 +1579,7 @@ def test_batch_dense_vs_oracle_and_variants(engine, oracle, batch, n, m):
         assert relmax(var[i], vo, scale=oracle.kernel_scale(2, h, w)) < RTOL
         assert abs(logml[i] - lmo) <= RTOL * abs(lmo)
     for env in ({"BQ_DIAG_FIRST": "0"}, {"BQ_DF_WG": "0"}, {"BQ_DF_WG": "1"}, {"BQ_DF_SWEEP": "0"},
-                {"BQ_DF_HALVES": "1"}, {"BQ_LOOKAHEAD": "0"}):
+                {"BQ_DF_EARLY": "0"}, {"BQ_LOOKAHEAD": "0"}):
         os.environ.update(env)
         try:
             e2 = Engine(0)
