@@ -123,6 +123,8 @@ static int ctx_init(bq_ctx *c, int device)
         c->df_wg = std::atoi(e);
     if (const char *e = std::getenv("BQ_PAIR_BORDER"))
         c->pair_border = std::atoi(e);
+    if (const char *e = std::getenv("BQ_DF_WG_ROWS"))
+        c->df_wg_rows = std::atoi(e);
     if (const char *e = std::getenv("BQ_DF_EARLY"))
         c->df_early = std::atoi(e);
     if (const char *e = std::getenv("BQ_ROWS_TAIL"))

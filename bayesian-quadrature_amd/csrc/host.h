@@ -97,6 +97,8 @@ struct bq_ctx {
                                // (bq_ctx_stats)
     int pair_border = 1; // bq_pair_esm as S factorisations + border rows (BQ_PAIR_BORDER=0: the S Ma
                          // full bordered systems)
+    int df_wg_rows = 1000; // ... and, below that batch size, for the blocks with at least this many rows
+                         // below them: the factors an update hides (BQ_DF_WG_ROWS; 0: never)
     int df_early = 1;    // the diagonal-first sweep forks before the panel solve: the next diagonal block's
                          // rows are solved, updated and factored beside the rest of the solve (BQ_DF_EARLY)
     int rows_tail = 128; // a large row sweep's last updates as split-k tiles: from this many LDS tiles down (BQ_ROWS_TAIL)
@@ -184,7 +186,7 @@ inline unsigned long long launch_config_key(const bq_ctx *c)
     const int f[] = {c->nb_override, c->lookahead, c->split_batch, c->la_min, c->gemm_lds,
                      c->gemm_lds64, c->slab_nb_max, c->slab_max, c->fold_readout, c->potf2_8w,
                      c->gemm_ksplit, c->gemm_tile, c->diag_first, c->df_sweep, c->df_wg,
-                     c->df_sharing, c->rows_tail, c->df_early};
+                     c->df_sharing, c->rows_tail, c->df_early, c->df_wg_rows};
     unsigned long long h = 1469598103934665603ull;
     for (int v : f)
         h = (h ^ (unsigned long long)(unsigned)v) * 1099511628211ull;

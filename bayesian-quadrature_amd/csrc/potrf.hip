@@ -425,8 +425,14 @@ static int enqueue_potrf_dfirst(bq_ctx *c, double *A, long lda, long astride, in
     // panel solve, and in the late blocks the update was shorter than the chain it should hide
     // (C5 shard: 0.11-0.14 ms exposed after three of four blocks, tools/plan_timeline.py).
     const bool early = la && c->df_early;
+    // A factor that has a long update to hide behind (df_wg_rows rows or more below its block) goes
+    // to the workgroup-per-matrix kernel whatever the batch: slower alone (366 against 236 us for
+    // 64 blocks of 448), but its `batch` workgroups take far fewer slots from the update beside it
+    // than the one-launch steps' redundant tiles (C5 shard 5.65 -> 5.57 ms; the first block's
+    // factor and the late ones, which nothing hides, stay on the steps)
     auto diag = [&](int K0, int KB, double *rec) {
-        if (dfirst_wg(c, batch))
+        if (dfirst_wg(c, batch) ||
+            (c->df_wg < 0 && c->df_wg_rows > 0 && K0 > 0 && ntot - K0 - KB >= c->df_wg_rows))
             return launch_potrf_wg(c, A + K0 + (long)K0 * lda, lda, astride, KB, rec, rstride, info,
                                    K0, batch);
         return enqueue_slab_sweep(c, A + K0 + (long)K0 * lda, lda, astride, batch, KB, KB, rec, info,

@@ -1579,7 +1579,8 @@ def test_batch_dense_vs_oracle_and_variants(engine, oracle, batch, n, m):
         assert relmax(var[i], vo, scale=oracle.kernel_scale(2, h, w)) < RTOL
         assert abs(logml[i] - lmo) <= RTOL * abs(lmo)
     for env in ({"BQ_DIAG_FIRST": "0"}, {"BQ_DF_WG": "0"}, {"BQ_DF_WG": "1"}, {"BQ_DF_SWEEP": "0"},
-                {"BQ_DF_EARLY": "0"}, {"BQ_LOOKAHEAD": "0"}):
+                {"BQ_DF_EARLY": "0"}, {"BQ_DF_WG_ROWS": "0"}, {"BQ_DF_WG_ROWS": "300"},
+                {"BQ_LOOKAHEAD": "0"}):
         os.environ.update(env)
         try:
             e2 = Engine(0)
