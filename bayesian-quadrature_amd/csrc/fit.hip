@@ -427,7 +427,14 @@ extern "C" int bq_gp_predict(bq_ctx *c, bq_fit *f, const double *xo, int64_t M, 
     double *hmap = nullptr;
     if (c->solve_kcopy)
         HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&hmap), f->hio, 0));
-    if (hmap)
+    // mean + variance without the covariance (BQ.l_var, _set_gp_log_l_params: bq.py:227-228,
+    // 942-943) is six launches: the cross Gram reads the points out of the mapped staging buffer
+    // and writes its own zero padding, the row reductions write the results into it (round 5:
+    // flow_in, the memset and flow_out gone, 59 -> 48 us of kernels at N = 1024, M = 256)
+    const bool direct = hmap && var && !cov;
+    if (direct)
+        ;
+    else if (hmap)
         BQCHK(launch_flow_in(c, hmap, d * (int)M, xod.d(), d * (int)M, nullptr, 0));
     else
         HIPCHK(c, hipMemcpyAsync(xod.p, f->hio, sizeof(double) * d * M, hipMemcpyHostToDevice,
@@ -444,12 +451,17 @@ extern "C" int bq_gp_predict(bq_ctx *c, bq_fit *f, const double *xo, int64_t M, 
         DevBuf &V0 = f->wV, &V = f->wV2;
         HIPCHK(c, grow(V0, sizeof(double) * (size_t)Mp * npad));
         HIPCHK(c, grow(V, sizeof(double) * (size_t)Mp * npad));
-        HIPCHK(c, hipMemsetAsync(V0.p, 0, sizeof(double) * (size_t)Mp * npad, c->stream));
-        BQCHK(launch_gram_cross(c, d, xod.d(), (int)M, f->pts.d(), n, g, V0.d(), Mp));
+        if (direct) {
+            BQCHK(launch_gram_cross_pad(c, d, hmap, (int)M, Mp, f->pts.d(), n, npad, g, V0.d(), Mp));
+        } else {
+            HIPCHK(c, hipMemsetAsync(V0.p, 0, sizeof(double) * (size_t)Mp * npad, c->stream));
+            BQCHK(launch_gram_cross(c, d, xod.d(), (int)M, f->pts.d(), n, g, V0.d(), Mp));
+        }
         BQCHK(enqueue_forward_rows(c, V0.d(), V.d(), Mp, Mp, f->A.d(), f->ldl, npad, wi));
         // z lives in row yrow of the factor with stride ldl: read where it is
-        BQCHK(launch_rowdot(c, V.d(), (long)Mp, (int)M, Mp, npad, f->A.d() + f->L.yrow, g.c, out.d(),
-                            out.d() + Mp, f->ldl));
+        double *omean = direct ? hmap + (size_t)d * M : out.d();
+        BQCHK(launch_rowdot(c, V.d(), (long)Mp, (int)M, Mp, npad, f->A.d() + f->L.yrow, g.c, omean,
+                            omean + Mp, f->ldl));
         if (cov) {
             // cov = K(xo,xo) - V V^T  (Mp x Mp on device, M x M out)
             DevBuf Cd, gd;
@@ -469,7 +481,9 @@ extern "C" int bq_gp_predict(bq_ctx *c, bq_fit *f, const double *xo, int64_t M, 
         }
     }
     double *hres = f->hio + (size_t)d * M; // [mean (Mp) | var (Mp)], one copy
-    if (hmap)
+    if (direct)
+        ;
+    else if (hmap)
         BQCHK(launch_flow_out(c, out.d(), 2 * Mp, hmap + (size_t)d * M));
     else
         HIPCHK(c, hipMemcpyAsync(hres, out.p, sizeof(double) * 2 * (size_t)Mp,

@@ -146,6 +146,39 @@ __global__ __launch_bounds__(256) void gram_cross_kernel(const double *__restric
     }
 }
 
+// The same with the zero padding written by the kernel itself: K is n1p x n2p (multiples of 64),
+// rows >= n1 and columns >= n2 are zeros -- the right-hand sides of a posterior's forward sweep
+// (fit.hip, bq_gp_predict) without a memset in front.  x1 may be mapped host memory (the
+// prediction points straight out of the caller's staging buffer: every workgroup reads its 64
+// points once).  Real entries: the arithmetic of gram_cross_kernel.  grid (n1p / 64, n2p / 64).
+template <int D>
+__global__ __launch_bounds__(256) void gram_cross_pad_kernel(const double *__restrict__ x1, int n1,
+                                                             const double *__restrict__ x2, int n2,
+                                                             GaussParams g, double *__restrict__ K,
+                                                             long ldk)
+{
+    const int t = threadIdx.x;
+    const int i = blockIdx.x * 64 + (t & 63);
+    const int jbase = blockIdx.y * 64 + (t >> 6) * 16;
+    const bool row = i < n1;
+    double xi[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+        xi[k] = row ? x1[k + (long)i * D] : 0.0;
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = jbase + jj;
+        double v = 0.0;
+        if (row && j < n2) {
+            double xj[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+                xj[k] = x2[k + (long)j * D];
+            v = g.c * exp_gauss(gauss_q<D>(xi, xj, g));
+        }
+        K[i + (long)j * ldk] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Bordered GP system, lower triangle only (tiles strictly above the diagonal
 // are skipped).  Index space of size ntot (multiple of 64):

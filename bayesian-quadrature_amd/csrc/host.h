@@ -289,6 +289,8 @@ int launch_gram_sym(bq_ctx *c, int d, const double *x, long xstride, const Gauss
                     int gpstride, double *K, long ldk, long kstride, int n, int batch);
 int launch_gram_cross(bq_ctx *c, int d, const double *x1, int n1, const double *x2, int n2,
                       const GaussParams &g, double *K, long ldk);
+int launch_gram_cross_pad(bq_ctx *c, int d, const double *x1, int n1, int n1p, const double *x2,
+                          int n2, int n2p, const GaussParams &g, double *K, long ldk);
 
 // ---- k_panel.hip ----------------------------------------------------------------------
 // fs: when set, the first launch of the slab sweep rides in the assembly (assemble_first_kernel)
@@ -424,7 +426,11 @@ inline int wide_block(int npad)
     static const int forced = std::getenv("BQ_WIDE_B") ? std::atoi(std::getenv("BQ_WIDE_B")) : 0;
     if (forced > 0)
         return std::min(npad, forced);
-    return npad < 2048 ? std::min(npad, 256) : 512;
+    // (round 5, tools/wide_b_check.py, 256 against 512 on resident fits of 1024 / 1536 points:
+    // posterior mean + variance at 256 points 0.064 -> 0.056 / 0.094 -> 0.073 ms, one-vector solve
+    // 0.053 -> 0.039 / 0.070 -> 0.047 -- half the dependent steps --; the inverses cost 0.06 ms
+    // more to rebuild after a refit: 0.43 -> 0.50 ms for refit + first posterior)
+    return npad < 1024 ? std::min(npad, 256) : 512;
 }
 inline size_t wide_doubles(int npad) { return (size_t)npad * wide_block(npad); }
 // NR, NT, TT, UU and the scratch of T before its transposition (a full B x B per block)

@@ -49,6 +49,35 @@ void launch_gram_cross_d(bq_ctx *c, const double *x1, int n1, const double *x2, 
                        ldk);
 }
 
+// K (n1p x n2p, zero padded beyond n1 x n2) in one launch: gram_cross_pad_kernel
+int launch_gram_cross_pad(bq_ctx *c, int d, const double *x1, int n1, int n1p, const double *x2,
+                          int n2, int n2p, const GaussParams &g, double *K, long ldk)
+{
+    if (n1p <= 0 || n2p <= 0)
+        return BQ_OK;
+    if ((n1p & 63) || (n2p & 63) || n1 > n1p || n2 > n2p)
+        return fail(c, BQ_ERR_BAD_ARG, "gram_cross_pad: padded sizes must be multiples of 64");
+    Bracket br(c, BQ_K_GRAM, 8.0 * n1p * n2p);
+    dim3 grid(n1p / 64, n2p / 64, 1);
+#define GCP(D_)                                                                                    \
+    hipLaunchKernelGGL(gram_cross_pad_kernel<D_>, grid, dim3(256), 0, c->cur, x1, n1, x2, n2, g, K, \
+                       ldk)
+    switch (d) {
+    case 1: GCP(1); break;
+    case 2: GCP(2); break;
+    case 3: GCP(3); break;
+    case 4: GCP(4); break;
+    case 5: GCP(5); break;
+    case 6: GCP(6); break;
+    case 7: GCP(7); break;
+    case 8: GCP(8); break;
+    default: return fail(c, BQ_ERR_BAD_ARG, "d must be in 1..%d", BQ_MAXD);
+    }
+#undef GCP
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
 int launch_gram_cross(bq_ctx *c, int d, const double *x1, int n1, const double *x2, int n2,
                       const GaussParams &g, double *K, long ldk)
 {

@@ -167,8 +167,9 @@ int enqueue_forward_rows_blk(bq_ctx *c, double *X, long ldx, int mrows, const do
 // a row sweep: systems too small to give 64 x 64 LDS-staged tiles half a chip of workgroups
 static bool rows_small(const bq_ctx *c, int mrows, int npad, const WideInv &w)
 {
-    // (with 256-column steps -- npad < 2048 -- the split-k tiles stay ahead: the posterior at
-    // 1000 points over N = 1024 takes 77 us with them, 90 us with the fused large-system steps)
+    // (below 2048 rows the split-k tiles stay ahead: the posterior at 1000 points over N = 1024
+    // took 77 us with them, 90 us with the fused large-system steps -- round 3, 256-column steps;
+    // 66 us with round 5's 512-column steps)
     return (mrows % 32) == 0 && (w.B % 64) == 0 &&
            (long)(mrows / 32) * (npad / 32) <= 4L * c->cus &&
            ((mrows % 64) != 0 || !c->gemm_lds64 || npad < 2048 ||
