@@ -1,15 +1,17 @@
-"""Condenses the rocprofv3 runs of tools/r04_profiles.sh into the small tables that are
+"""Condenses the rocprofv3 runs of tools/<tag>_profiles.sh into the small tables that are
 committed under profiles/ (run on the GPU box; results come back through gpurun_out/):
 
-    python3 tools/pmc_summary.py gpurun_out/r04p r04 [outdir]
+    python3 tools/pmc_summary.py gpurun_out/r05p r05 [outdir]
 
 Per pass P of tools/roofline_run.py (one rocprofv3 run each, never blended):
     <tag>_<P>_kernel_stats.csv     copy of the --stats summary of `t_<P>`
     <tag>_bench_kernel_stats.csv   the same for `python3 bench.py --steps 200`
 and
-    <tag>_trailing_dispatches.csv  one row per gemm_lds_kernel launch of the sequential
-                                   N=16384, tile-256 potrf: dispatch, grid, m, ns, flop --
-                                   sum(m^2 nb) / sum(ns) is the trailing-update roofline line
+    <tag>_trailing_dispatches.csv  one row per launch with trailing-update work of the sequential
+                                   N=16384, tile-256 potrf (128-tile and 64-tile products, the
+                                   one-launch steps of the last rows): dispatch, grid, m, ns, flop --
+                                   1.4318e12 / sum(ns) is SURVEY 8(d)'s trailing-update line, the
+                                   bulk launches' own sum(m^2 nb) / sum(ns) stays beside it
     <tag>_pmc_traffic.json         WRITE_SIZE / FETCH_SIZE per kernel and pass, RAW, plus clearly
                                    labelled estimates (see below)
     <tag>_mfma_util.json           SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_VALU_MFMA_MOPS_F64 of
@@ -75,34 +77,57 @@ def main():
       tr = find(os.path.join(O, "t_" + tpass), "*_kernel_trace.csv")
       summary = {}
       if tr:
-          rows = [r for r in csv.DictReader(open(tr)) if "gemm_lds_kernel" in r["Kernel_Name"]]
+          # EVERY launch that carries trailing-update work (1.4318e12 flop over the sum
+          # of all trailing kernel time): the 128-tile and 64-tile LDS products and the one-launch
+          # steps that take over for the last rows (slab_step_kernel: solve + update + next factor)
+          names = ("gemm_lds_kernel", "gemm_lds64_kernel", "slab_step_kernel")
+          rows = [r for r in csv.DictReader(open(tr)) if any(k in r["Kernel_Name"] for k in names)]
           rows.sort(key=lambda r: int(r["Start_Timestamp"]))
           nb = 256
-          table, tot = [], {"bulk": [0, 0.0, 0], "small": [0, 0.0, 0]}
+          table, tot = [], {"bulk": [0, 0.0, 0], "small": [0, 0.0, 0], "tail_steps": [0, 0.0, 0]}
           for r in rows:
               wgs = int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])
-              T = int(((8 * wgs + 1) ** 0.5 - 1) / 2 + 0.5)
-              assert T * (T + 1) // 2 == wgs, (wgs, T)
-              m = 128 * T
               ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-              fl = float(m) * m * nb
-              cls = "bulk" if wgs >= 256 else "small"     # launch_gemm's SYRK / SYRK_SMALL split
+              kname = r["Kernel_Name"].split("(")[0].replace("void ", "")
+              T = int(((8 * wgs + 1) ** 0.5 - 1) / 2 + 0.5)
+              if "slab_step_kernel" in kname:
+                  # one 64-column step over the m = 64 T rows below it: m^2 64 (+ m 64^2 of solve)
+                  m, kk, cls = 64 * T, 64, "tail_steps"
+                  fl = float(m) * m * 64 if T * (T + 1) // 2 == wgs else 0.0
+              else:
+                  tile = 64 if "gemm_lds64_kernel" in kname else 128
+                  if T * (T + 1) // 2 != wgs:   # not a square lower update: a panel-internal product
+                      continue
+                  m, kk = tile * T, nb
+                  fl = float(m) * m * nb
+                  cls = "bulk" if (tile == 128 and wgs >= 256) else "small"
               tot[cls][0] += 1
               tot[cls][1] += fl
               tot[cls][2] += ns
-              table.append((r["Dispatch_Id"], wgs, m, nb, ns, fl, cls))
+              table.append((r["Dispatch_Id"], kname[:40], wgs, m, kk, ns, fl, cls))
           with open(os.path.join(outdir, "%s_trailing_dispatches%s.csv" % (tag, "" if tpass == "potrf256" else "_dense")), "w") as f:
-              f.write("# gemm_lds_kernel launches of ONE sequential N=16384 potrf, outer block 256 "
-                      "(python3 tools/roofline_run.py %s under rocprofv3 --kernel-trace); " % tpass +
-                      "flop = m^2 nb (the lower half of 2 m^2 nb)\n")
-              f.write("dispatch_id,workgroups,m,nb,duration_ns,algorithmic_flop,class\n")
+              f.write("# every launch with trailing-update work of ONE sequential N=16384 potrf, outer "
+                      "block 256 (python3 tools/roofline_run.py %s under rocprofv3 --kernel-trace); " % tpass +
+                      "flop = m^2 k (the lower half of 2 m^2 k); tail_steps: the one-launch 64-column "
+                      "steps over the last rows (their time includes the panel solve and the next "
+                      "diagonal factor)\n")
+              f.write("dispatch_id,kernel,workgroups,m,k,duration_ns,algorithmic_flop,class\n")
               for t in table:
-                  f.write("%s,%d,%d,%d,%d,%.0f,%s\n" % t)
-              for cls in ("bulk", "small"):
+                  f.write("%s,%s,%d,%d,%d,%d,%.0f,%s\n" % t)
+              for cls in ("bulk", "small", "tail_steps"):
                   n, fl, ns = tot[cls]
                   if n:
                       f.write("# %s: %d launches, %.4e flop, %.3f ms -> %.2f TFLOP/s = %.3f of 78.6\n"
                               % (cls, n, fl, ns / 1e6, fl / ns / 1e3, fl / ns * 1e9 / PEAK))
+              nall = sum(v[0] for v in tot.values())
+              nsall = sum(v[2] for v in tot.values())
+              if nsall:
+                  f.write("# SURVEY 8(d): all %d trailing launches, 1.4318e12 flop / %.3f ms -> %.2f "
+                          "TFLOP/s = %.3f of 78.6\n"
+                          % (nall, nsall / 1e6, 1.4318e12 / nsall / 1e3, 1.4318e12 / nsall * 1e9 / PEAK))
+                  summary["all_trailing_8d"] = {"launches": nall, "flop": 1.4318e12, "ms": nsall / 1e6,
+                                                "tflops": 1.4318e12 / nsall / 1e3,
+                                                "frac": 1.4318e12 / nsall * 1e9 / PEAK}
           for cls in ("bulk", "small"):
               n, fl, ns = tot[cls]
               if n:
@@ -112,7 +137,7 @@ def main():
       summaries[tpass] = summary
     summary = summaries.get("potrf256", {})
     # ---- traffic ----------------------------------------------------------------------
-    out = {"_source": "tools/r04_profiles.sh: rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE, "
+    out = {"_source": "tools/" + tag + "_profiles.sh: rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE, "
                       "separate runs, one per pass of tools/roofline_run.py; bytes = KiB x 1024; "
                       "*_bytes_* are RAW counters, *_estimate_* are labelled corrections "
                       "(tools/pmc_summary.py docstring)",
@@ -164,7 +189,7 @@ def main():
     with open(os.path.join(outdir, "%s_pmc_traffic.json" % tag), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     # ---- MFMA utilisation ----------------------------------------------------------------
-    mu = {"_source": "tools/r04_profiles.sh: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES "
+    mu = {"_source": "tools/" + tag + "_profiles.sh: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES "
                      "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE (own runs, "
                      "counters only); mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 "
                      "XCDs x 256 CUs x 4 SIMDs)", "passes": {}}
