@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void gram_cross_pad_kernel(const double *__res
 // pts is d x ntot with x at [0,n) and xo at [npad, npad+M); other columns are
 // never read.  After eliminating the first npad columns, the Schur complement
 // holds the posterior covariance, -mean in row yrow and -y'K^-1 y at
-// (yrow, yrow); see DESIGN.md.
+// (yrow, yrow); see DESIGN.md section 2.
 // ---------------------------------------------------------------------------
 // (struct Layout: types.h)
 

@@ -537,7 +537,7 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
                                     skip_border);
     }
     // large systems (a look-ahead's size) in a batch that fills the chip many times over run
-    // as ONE sequential group: the product is power-bound, beside it the
+    // as ONE sequential group: the product is power-bound (docs/LABBOOK.md section 4), beside it the
     // panel chain only takes clock away (C3, 100 x N = 4096: 189.8 ms with the look-ahead,
     // 198 in two halves, 186.3 sequential; up to 32 matrices the look-ahead still gains 1-2 %)
     const bool big = ncols > NB && ntot - std::min(NB, ncols) >= c->la_min;

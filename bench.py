@@ -268,7 +268,7 @@ def make_workload(name, batch, rank):
                 B=B, desc=desc)
 
 
-def scale_point(eng, batch, passes=3):
+def scale_point(eng, batch, passes=5, warm=3):
     """The N = 1 point of the scaling curve: rank 0's block of the curve workload (a C5 shard)
     on this one GPU, inputs resident, HIP events around `passes` plan passes -- the same
     measurement an N > 1 line reports as n1_same_workload and the same per-GPU work as its
@@ -276,7 +276,8 @@ def scale_point(eng, batch, passes=3):
     wk = make_workload(CURVE_WORKLOAD, batch, 0)
     plan = eng.plan(wk["B"], wk["d"], wk["n"], wk["M"])
     plan.set_inputs(wk["x"], wk["y"], wk["xo"], wk["h"], wk["w"], wk["s"])
-    plan.run()
+    for _ in range(warm):
+        plan.run()
     eng.sync()
     eng.timer_start()
     for _ in range(passes):
@@ -787,12 +788,15 @@ def batched_configs(eng):
     c = wl.c5(list(range(B)))
     plan = eng.plan(B, 1, 2048, 256)
     plan.set_inputs(c["x"], c["y"], c["xo"], c["h"], c["w"], c["s"])
-    plan.run()
-    eng.sync()
-    eng.timer_start()
+    # (three untimed passes: the first passes of a batch run 2-4 % slower than the steady state
+    # the scaling curve is about -- tools/c5_time.py prints every pass)
     for _ in range(3):
         plan.run()
-    ms = eng.timer_stop_ms() / 3
+    eng.sync()
+    eng.timer_start()
+    for _ in range(5):
+        plan.run()
+    ms = eng.timer_stop_ms() / 5
     status = plan.results()[3]
     plan.close()
     flops = B * (2048 ** 3 / 3.0)   # the factorisation alone, per problem N^3/3
@@ -809,8 +813,9 @@ def batched_configs(eng):
         "potrf_tflops_lower_bound": flops / (ms * 1e-3) / 1e12,
         "note": "wall-derived: (N^3/3 + M N^2) per problem over the HIP-event time of a "
                 "plan pass; the kernel classes of this shard and the MFMA utilisation of its "
-                "gemm_lds_kernel launches are in profiles/r04_c5_kernel_stats.csv and "
-                "profiles/r04_mfma_util.json"}
+                "gemm_lds_kernel launches are in profiles/r05_c5_kernel_stats.csv and "
+                "profiles/r05_mfma_util.json; the pass's launch timeline in "
+                "profiles/r05_plan_timeline_c5.txt"}
     # the headline problem, 256 independent copies per step: what batching buys over the
     # latency-bound single problem of `value`
     c2 = wl.c2()
@@ -818,12 +823,13 @@ def batched_configs(eng):
     plan = eng.plan(B2, 1, 1024, 256)
     plan.set_inputs(np.repeat(c2["x"][None], B2, axis=0), np.repeat(c2["y"][None], B2, axis=0),
                     np.repeat(c2["xo"][None], B2, axis=0), c2["h"], c2["w"], c2["s"])
-    plan.run()
-    eng.sync()
-    eng.timer_start()
     for _ in range(3):
         plan.run()
-    ms2 = eng.timer_stop_ms() / 3
+    eng.sync()
+    eng.timer_start()
+    for _ in range(5):
+        plan.run()
+    ms2 = eng.timer_stop_ms() / 5
     st2 = plan.results()[3]
     plan.close()
     fl2 = B2 * (1024 ** 3 / 3.0 + 256.0 * 1024 * 1024)
@@ -853,7 +859,7 @@ def batched_configs(eng):
                                "note": "wall-derived: N^3/3 per grid point over the host wall "
                                        "clock incl. the upload of the 400 parameter sets and the "
                                        "read-back of the 400 results; kernel classes of one chunk "
-                                       "in profiles/r04_c3_kernel_stats.csv"}
+                                       "in profiles/r05_c3_kernel_stats.csv"}
     return out
 
 
@@ -1131,7 +1137,7 @@ def main():
                 line["rooflines"] = extras(eng, a.nb)
                 # the north-star figures as flat scalars of `roofline` (a reader that keeps only
                 # scalar keys still sees them); each equals the object of the same name in
-                # `rooflines` and is reproducible from profiles/ (DESIGN.md section 6)
+                # `rooflines` and is reproducible from profiles/ (DESIGN.md section 7)
                 rl = line["rooflines"]
                 roof = line["roofline"]
                 # 1.4318e12 flop / sum of ALL trailing kernel time (bulk launches on

@@ -4,7 +4,7 @@ section 8c's list) against the oracle on the CPU and against the HIP path on the
 The GPU cases need nothing under oracle/: the headline configs (C2, one C5 problem) and the
 per-function linalg_c / gauss_c vectors are regress-testable from the files alone.  The vectors
 come from the pinned restatement (oracle/bq_oracle.c), not from the reference itself, which
-cannot run in this pipeline (DESIGN.md section 5); the s != 0 noise form they contain
+cannot run in this pipeline (DESIGN.md section 6); the s != 0 noise form they contain
 (K + s^2 I) is unpinned by the reference.
 """
 import os
