@@ -22,6 +22,7 @@ static int fit_factor(bq_ctx *c, bq_fit *f, double *pm = nullptr, double *pv = n
     f->valid = false;
     f->stale = false;
     f->have_alpha = false;
+    f->have_zc = false;
     f->have_wide = false;
     f->have_dw = false;
     // pinned staging: [0, 136) results, then the kernel parameters, then border points
@@ -277,6 +278,7 @@ extern "C" int bq_gp_set_y(bq_ctx *c, bq_fit *f, const double *y)
     HIPCHK(c, hipSetDevice(c->device));
     f->stale = true; // the factor is intact, z / alpha / log-ML belong to the old targets
     f->have_alpha = false;
+    f->have_zc = false;
     HIPCHK(c, hipMemcpyAsync(f->y.p, y, sizeof(double) * f->n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream)); // y is the caller's buffer
     return BQ_OK;
@@ -458,10 +460,15 @@ extern "C" int bq_gp_predict(bq_ctx *c, bq_fit *f, const double *xo, int64_t M, 
             BQCHK(launch_gram_cross(c, d, xod.d(), (int)M, f->pts.d(), n, g, V0.d(), Mp));
         }
         BQCHK(enqueue_forward_rows(c, V0.d(), V.d(), Mp, Mp, f->A.d(), f->ldl, npad, wi));
-        // z lives in row yrow of the factor with stride ldl: read where it is
+        // z lives in row yrow of the factor with stride ldl: gathered once per (re)fit
+        if (!f->have_zc) {
+            HIPCHK(c, grow(f->wz, sizeof(double) * (size_t)npad));
+            BQCHK(launch_gather_row(c, f->wz.d(), f->A.d() + f->L.yrow, f->ldl, npad));
+            f->have_zc = true;
+        }
         double *omean = direct ? hmap + (size_t)d * M : out.d();
-        BQCHK(launch_rowdot(c, V.d(), (long)Mp, (int)M, Mp, npad, f->A.d() + f->L.yrow, g.c, omean,
-                            omean + Mp, f->ldl));
+        BQCHK(launch_rowdot(c, V.d(), (long)Mp, (int)M, Mp, npad, f->wz.d(), g.c, omean, omean + Mp,
+                            1));
         if (cov) {
             // cov = K(xo,xo) - V V^T  (Mp x Mp on device, M x M out)
             DevBuf Cd, gd;

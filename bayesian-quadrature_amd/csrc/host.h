@@ -507,6 +507,9 @@ struct bq_fit {
                   // of bq_gp_refit_predict (one read-back for all of it)
     DevBuf alpha; // npad, valid if have_alpha
     bool have_alpha = false;
+    bool have_zc = false; // wz holds z = L^-1 y contiguously (gathered from the factor's y row on
+                          // the first posterior after a (re)fit: the row reductions then read one
+                          // line per 8 entries instead of one per entry)
     // the single-vector sweeps (trsv.h): x | y, 2 npad doubles, and their captured launch
     // chains -- [0] solve (forward + backward), [1] backward into alpha, [2] forward; the
     // pointers survive a refit, so the graphs do too

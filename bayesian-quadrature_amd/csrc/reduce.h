@@ -67,6 +67,21 @@ __global__ __launch_bounds__(1024) void rowdot_kernel(const double *__restrict__
     if (row < m) {
         const double *p = V + row;
         int j = sl;
+        // (sixteen columns per trip: at n = 1024 a thread's whole share is in flight at once --
+        // the kernel is two memory round trips long, not bandwidth; 12.7 -> see LABBOOK round 5)
+        for (; j + 64 * 15 < n; j += 64 * 16) {
+            double v[16], zz[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                v[u] = p[(long)(j + 64 * u) * ldv];
+                zz[u] = z ? z[(long)(j + 64 * u) * zs] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                sm = fma(v[u], zz[u], sm);
+                sv = fma(v[u], v[u], sv);
+            }
+        }
         for (; j + 64 * 7 < n; j += 64 * 8) {
             double v[8];
 #pragma unroll
