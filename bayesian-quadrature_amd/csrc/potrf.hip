@@ -495,7 +495,11 @@ static int enqueue_potrf_dfirst(bq_ctx *c, double *A, long lda, long astride, in
             // the rows below it: the next panel's columns, then the square behind them.  (ONE
             // launch over everything right of the panel with the next diagonal block's tiles
             // skipped -- one launch tail instead of two -- was measured in round 5 and gained
-            // nothing: C5 5.67 / 256 x C2 4.21 / C3 177-183 either way; removed.)
+            // nothing: C5 5.67 / 256 x C2 4.21 / C3 177-183 either way; removed.  So was the square
+            // deferred to every second panel and run once with both panels as its operand, k = 2 NB
+            // -- bit-identical results, C5 5.59 / 256 x C2 4.25 / C3 174-176 against 5.60 / 4.21 /
+            // 176: what the deeper product gains, the factor that now hides behind the column
+            // update alone gives back.)
             const bool sq = !(skip_border && r1 >= ncols);
             BQCHK(launch_gemm(c, BQ_K_SYRK, A + r1 + (long)r0 * lda, lda, astride, P1, lda, astride,
                               P, 1, lda, astride, ntot - r1, nw, KB, 0, batch));
