@@ -165,17 +165,25 @@ __global__ __launch_bounds__(256) void gram_cross_pad_kernel(const double *__res
 #pragma unroll
     for (int k = 0; k < D; ++k)
         xi[k] = row ? x1[k + (long)i * D] : 0.0;
-    for (int jj = 0; jj < 16; ++jj) {
-        const int j = jbase + jj;
-        double v = 0.0;
-        if (row && j < n2) {
-            double xj[D];
+    // (the kernel is latency, not work: a thread's points of the second set are requested in
+    // batches of eight -- clamped at the end, so that no load sits under a branch -- before the
+    // first exp that needs one; the sixteen exps are independent of one another)
+#pragma unroll
+    for (int h8 = 0; h8 < 16; h8 += 8) {
+        double xj[8][D];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int j = min(jbase + h8 + jj, n2 - 1);
 #pragma unroll
             for (int k = 0; k < D; ++k)
-                xj[k] = x2[k + (long)j * D];
-            v = g.c * exp_gauss(gauss_q<D>(xi, xj, g));
+                xj[jj][k] = x2[k + (long)j * D];
         }
-        K[i + (long)j * ldk] = v;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int j = jbase + h8 + jj;
+            const double e = g.c * exp_gauss(gauss_q<D>(xi, xj[jj], g));
+            K[i + (long)j * ldk] = (row && j < n2) ? e : 0.0;
+        }
     }
 }
 
