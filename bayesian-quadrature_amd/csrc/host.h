@@ -87,6 +87,10 @@ struct bq_ctx {
     int diag_first = 1;  // batches: every outer block as diagonal factor, ONE panel solve, update
                          // (enqueue_potrf_dfirst; BQ_DIAG_FIRST=0: the recursive panels)
     int df_sweep = 1;    // the panel solve of an outer block in one launch (trsm_sweep_kernel; BQ_DF_SWEEP)
+    int sweep_rt = 0;    // ... its workgroup tile: 0 = R x 64 with R = 16 RT rows picked per launch
+                         // (trsm_sweep_tall_kernel, round 6), 4..9 = that RT forced, -1 = the 64 x 64
+                         // tile of round 4 (trsm_sweep_kernel) (BQ_SWEEP_RT)
+    int sweep_wpc3 = 0;  // ... three workgroups per CU for RT <= 6 (BQ_SWEEP_WPC3; measurements)
     int df_wg = -1;      // a batch's diagonal factor by one workgroup per matrix (potrf_wg_kernel): -1 by
                          // batch size (potrf.hip, dfirst_wg), 0 / 1 forced (BQ_DF_WG)
     int trsv_flow = 1;   // single-vector sweeps as one launch each, hand-offs through memory
