@@ -119,10 +119,6 @@ static int ctx_init(bq_ctx *c, int device)
         c->diag_first = std::atoi(e);
     if (const char *e = std::getenv("BQ_DF_SWEEP"))
         c->df_sweep = std::atoi(e);
-    if (const char *e = std::getenv("BQ_SWEEP_RT"))
-        c->sweep_rt = std::atoi(e);
-    if (const char *e = std::getenv("BQ_SWEEP_WPC3"))
-        c->sweep_wpc3 = std::atoi(e);
     if (const char *e = std::getenv("BQ_DF_WG"))
         c->df_wg = std::atoi(e);
     if (const char *e = std::getenv("BQ_PAIR_BORDER"))

@@ -433,7 +433,11 @@ extern "C" int bq_gp_predict(bq_ctx *c, bq_fit *f, const double *xo, int64_t M, 
     // 942-943) is six launches: the cross Gram reads the points out of the mapped staging buffer
     // and writes its own zero padding, the row reductions write the results into it (round 5:
     // flow_in, the memset and flow_out gone, 59 -> 48 us of kernels at N = 1024, M = 256)
-    const bool direct = hmap && var && !cov;
+    // (every workgroup column of the cross Gram re-reads the points over PCIe: npad / 64 uncached
+    // passes over d M doubles.  Measured a win at N = 1024, M = 256 / 1000; above a few MB of such
+    // reads the points go down once through flow_in instead -- ADVICE r05)
+    const bool direct = hmap && var && !cov &&
+                        (size_t)d * M * sizeof(double) * (size_t)(npad / 64) <= ((size_t)4 << 20);
     if (direct)
         ;
     else if (hmap)

@@ -87,10 +87,6 @@ struct bq_ctx {
     int diag_first = 1;  // batches: every outer block as diagonal factor, ONE panel solve, update
                          // (enqueue_potrf_dfirst; BQ_DIAG_FIRST=0: the recursive panels)
     int df_sweep = 1;    // the panel solve of an outer block in one launch (trsm_sweep_kernel; BQ_DF_SWEEP)
-    int sweep_rt = 0;    // ... its workgroup tile: 0 = R x 64 with R = 16 RT rows picked per launch
-                         // (trsm_sweep_tall_kernel, round 6), 4..9 = that RT forced, -1 = the 64 x 64
-                         // tile of round 4 (trsm_sweep_kernel) (BQ_SWEEP_RT)
-    int sweep_wpc3 = 0;  // ... three workgroups per CU for RT <= 6 (BQ_SWEEP_WPC3; measurements)
     int df_wg = -1;      // a batch's diagonal factor by one workgroup per matrix (potrf_wg_kernel): -1 by
                          // batch size (potrf.hip, dfirst_wg), 0 / 1 forced (BQ_DF_WG)
     int trsv_flow = 1;   // single-vector sweeps as one launch each, hand-offs through memory
@@ -528,6 +524,7 @@ struct bq_fit {
     hipGraph_t vgraph[3] = {nullptr, nullptr, nullptr};
     hipGraphExec_t vgexec[3] = {nullptr, nullptr, nullptr};
     bool vg_failed[3] = {false, false, false};
+    int vg_flow[3] = {0, 0, 0}; // c->trsv_flow when the slot's graph was captured
     ~bq_fit()
     {
         if (hvec)
@@ -570,8 +567,13 @@ int fit_replay(bq_ctx *c, bq_fit *f, int slot, F &&enqueue)
     if (!c->use_graph || c->prof || !c->own_stream || c->cur != c->stream ||
         (!flow_graph && trsv_flow_ok(c, f->npad, wide_block(f->npad))))
         return enqueue();
+    // a graph captured with the one-launch sweeps inside is not what a fall-back retry (or a
+    // caller that switched them off) asks for: such a call is enqueued eagerly
+    if (f->vgexec[slot] && f->vg_flow[slot] != c->trsv_flow)
+        return enqueue();
     if (!f->vgexec[slot] && !f->vg_failed[slot]) {
         f->vg_failed[slot] = true;
+        f->vg_flow[slot] = c->trsv_flow;
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
             const int st = enqueue();
             hipGraph_t g = nullptr;
@@ -613,6 +615,11 @@ int with_flow_fallback(bq_ctx *c, F &&attempt)
     c->trsv_flow = 0;
     st = attempt();
     c->trsv_flow = saved;
+    // the retry must not have gone through a one-launch sweep again (a captured graph that still
+    // holds one: fit_replay keys its graphs on trsv_flow) -- if the word is up again the results
+    // are garbage and the call says so
+    if (st == BQ_OK && flow_timed_out(c))
+        return fail(c, BQ_ERR_HIP, "a sweep's hand-off timed out again on the per-block kernels");
     return st;
 }
 // plan.hip: new kernel parameters for every problem of a plan, nothing else re-uploaded

@@ -5,10 +5,6 @@
 
 namespace bqh {
 
-// workgroups per CU of trsm_sweep_tall_kernel<RT> (its launch bounds, its LDS)
-static constexpr int sweep_wpc(int rt) { return rt <= 6 ? 3 : 2; }
-static int sweep_wpc_rt(const bq_ctx *c, int rt) { return c->sweep_wpc3 ? sweep_wpc(rt) : 2; }
-
 // function attributes of the LDS-staged kernel: 72 KiB of dynamic LDS per workgroup
 int gemm_init(bq_ctx *c)
 {
@@ -25,22 +21,6 @@ int gemm_init(bq_ctx *c)
     BQ_L64_ATTR((rows_fused_kernel<true, 2>), BQ_L64_BYTES);
     BQ_L64_ATTR(gemm_trsm64_kernel, BQ_L64_BYTES);
     BQ_L64_ATTR(trsm_sweep_kernel, BQ_L64_BYTES);
-    BQ_L64_ATTR(trsm_sweep_rl_kernel<1>, BQ_RL_LDS);
-    BQ_L64_ATTR(trsm_sweep_rl_kernel<2>, BQ_RL_LDS);
-    BQ_L64_ATTR(trsm_sweep_rl_kernel<3>, BQ_RL_LDS);
-    BQ_L64_ATTR(trsm_sweep_rl_kernel<4>, BQ_RL_LDS);
-    BQ_L64_ATTR(trsm_sweep_rl_kernel<5>, BQ_RL_LDS);
-    BQ_L64_ATTR(trsm_sweep_rl_kernel<6>, BQ_RL_LDS);
-    BQ_L64_ATTR(trsm_sweep_rl_kernel<7>, BQ_RL_LDS);
-    BQ_L64_ATTR((trsm_sweep_tall_kernel<4, 3>), SweepGeom<4>::LDS);
-    BQ_L64_ATTR((trsm_sweep_tall_kernel<5, 3>), SweepGeom<5>::LDS);
-    BQ_L64_ATTR((trsm_sweep_tall_kernel<6, 3>), SweepGeom<6>::LDS);
-    BQ_L64_ATTR((trsm_sweep_tall_kernel<4, 2>), SweepGeom<4>::LDS);
-    BQ_L64_ATTR((trsm_sweep_tall_kernel<5, 2>), SweepGeom<5>::LDS);
-    BQ_L64_ATTR((trsm_sweep_tall_kernel<6, 2>), SweepGeom<6>::LDS);
-    BQ_L64_ATTR((trsm_sweep_tall_kernel<7, sweep_wpc(7)>), SweepGeom<7>::LDS);
-    BQ_L64_ATTR((trsm_sweep_tall_kernel<8, sweep_wpc(8)>), SweepGeom<8>::LDS);
-    BQ_L64_ATTR((trsm_sweep_tall_kernel<9, sweep_wpc(9)>), SweepGeom<9>::LDS);
 #undef BQ_L64_ATTR
     return BQ_OK;
 }
@@ -225,37 +205,7 @@ int launch_gemm_trsm(bq_ctx *c, double *C, long ldc, long cstride, const double 
     return BQ_OK;
 }
 
-// Rows per workgroup of the tall sweep, 16 RT: the RT whose grid costs least under a per-CU model.
-// A CU is dealt ceil(wgs / cus) workgroups of R rows and runs wpc at a time; a full house of RT-
-// row-group workgroups moves thr[RT] rows per unit of time (larger tiles stage fewer bytes per
-// flop), a house with fewer residents less than proportionally more per workgroup (occ).
-int sweep_pick_rt(const bq_ctx *c, int m, int batch)
-{
-    if (c->sweep_rt >= 4 && c->sweep_rt <= 9)
-        return c->sweep_rt;
-    static const double thr[10] = {0, 0, 0, 0, 0.80, 0.86, 0.91, 0.95, 1.00, 1.02};
-    int best = 8;
-    double bestc = 1e300;
-    for (int rt = 4; rt <= 9; ++rt) {
-        const int R = 16 * rt, wpc = sweep_wpc_rt(c, rt);
-        const long wgs = (long)((m + R - 1) / R) * batch;
-        const long per_cu = (wgs + c->cus - 1) / c->cus;
-        const long full = per_cu / wpc, rest = per_cu % wpc;
-        // a partial house: `rest` residents share the CU; each runs faster than in a full house
-        // but the CU as a whole slower (one resident alone ~0.6 of a full house's rate at wpc 2)
-        const double occ = rest == 0 ? 0.0 : (double)rest / wpc;
-        const double tail = rest == 0 ? 0.0 : occ / (0.35 + 0.65 * occ);
-        const double cost = ((double)full + tail) * wpc * R / thr[rt];
-        if (cost < bestc) {
-            bestc = cost;
-            best = rt;
-        }
-    }
-    return best;
-}
-
-// X (m x kb) <- X L11^-T for every row block in one launch (trsm_sweep_tall_kernel; sweep_rt = -1:
-// round 4's trsm_sweep_kernel)
+// X (m x kb) <- X L11^-T for every row block in one launch (trsm_sweep_kernel)
 int launch_trsm_sweep(bq_ctx *c, double *X, long ldx, long xstride, int m, const double *L11,
                       long ldl, long lstride, const double *rec, long rstride, int kb, int batch)
 {
@@ -264,67 +214,16 @@ int launch_trsm_sweep(bq_ctx *c, double *X, long ldx, long xstride, int m, const
     if ((m & 63) || (kb & 63) || kb <= 0)
         return fail(c, BQ_ERR_BAD_ARG, "trsm_sweep: m and kb must be multiples of 64");
     Bracket br(c, BQ_K_TRSM, (double)m * kb * kb * batch);
-    if (c->sweep_rt == -1 || (c->sweep_rt == -2 && kb > 448)) {
-        const int nrb = m / 64;
+    const int nrb = m / 64;
 #ifdef BQ_TS_DBG
-        static const int dbg = std::getenv("BQ_TS_DBG") ? std::atoi(std::getenv("BQ_TS_DBG")) : 0;
-        hipLaunchKernelGGL(trsm_sweep_kernel, dim3(8 * nrb * ((batch + 7) / 8)), dim3(256),
-                           BQ_L64_BYTES, c->cur, X, ldx, xstride, L11, ldl, lstride, rec, rstride,
-                           kb, nrb, batch, dbg);
+    // ablation build (make DEFS=-DBQ_TS_DBG OUT=../libbqhip_dbg.so; tools/r06_ablate.sh)
+    static const int dbg = std::getenv("BQ_TS_DBG") ? std::atoi(std::getenv("BQ_TS_DBG")) : 0;
+    hipLaunchKernelGGL(trsm_sweep_kernel, dim3(8 * nrb * ((batch + 7) / 8)), dim3(256), BQ_L64_BYTES,
+                       c->cur, X, ldx, xstride, L11, ldl, lstride, rec, rstride, kb, nrb, batch, dbg);
 #else
-        hipLaunchKernelGGL(trsm_sweep_kernel, dim3(8 * nrb * ((batch + 7) / 8)), dim3(256),
-                           BQ_L64_BYTES, c->cur, X, ldx, xstride, L11, ldl, lstride, rec, rstride,
-                           kb, nrb, batch);
+    hipLaunchKernelGGL(trsm_sweep_kernel, dim3(8 * nrb * ((batch + 7) / 8)), dim3(256), BQ_L64_BYTES,
+                       c->cur, X, ldx, xstride, L11, ldl, lstride, rec, rstride, kb, nrb, batch);
 #endif
-        HIPCHK(c, hipGetLastError());
-        return BQ_OK;
-    }
-    if (c->sweep_rt == -2 && kb <= 448) {
-        const int nrb = m / 64;
-        const dim3 grid(8 * nrb * ((batch + 7) / 8));
-#define BQ_SWEEP_RL(NS_)                                                                           \
-    case NS_:                                                                                      \
-        hipLaunchKernelGGL(trsm_sweep_rl_kernel<NS_>, grid, dim3(256), BQ_RL_LDS, c->cur, X, ldx,  \
-                           xstride, L11, ldl, lstride, rec, rstride, nrb, batch);                  \
-        break;
-        switch (kb / 64) {
-            BQ_SWEEP_RL(1)
-            BQ_SWEEP_RL(2)
-            BQ_SWEEP_RL(3)
-            BQ_SWEEP_RL(4)
-            BQ_SWEEP_RL(5)
-            BQ_SWEEP_RL(6)
-            BQ_SWEEP_RL(7)
-        }
-#undef BQ_SWEEP_RL
-        HIPCHK(c, hipGetLastError());
-        return BQ_OK;
-    }
-    const int rt = sweep_pick_rt(c, m, batch);
-#define BQ_SWEEP_TALL(RT_)                                                                         \
-    case RT_: {                                                                                    \
-        const int nrb = (m + 16 * RT_ - 1) / (16 * RT_);                                           \
-        if (sweep_wpc_rt(c, RT_) == 3)                                                             \
-            hipLaunchKernelGGL((trsm_sweep_tall_kernel<RT_, (RT_ <= 6 ? 3 : 2)>),                  \
-                               dim3(8 * nrb * ((batch + 7) / 8)), dim3(256), SweepGeom<RT_>::LDS,  \
-                               c->cur, X, ldx, xstride, L11, ldl, lstride, rec, rstride, kb, m,    \
-                               nrb, batch);                                                        \
-        else                                                                                       \
-            hipLaunchKernelGGL((trsm_sweep_tall_kernel<RT_, 2>), dim3(8 * nrb * ((batch + 7) / 8)), \
-                               dim3(256), SweepGeom<RT_>::LDS, c->cur, X, ldx, xstride, L11, ldl,  \
-                               lstride, rec, rstride, kb, m, nrb, batch);                          \
-    } break;
-    switch (rt) {
-        BQ_SWEEP_TALL(4)
-        BQ_SWEEP_TALL(5)
-        BQ_SWEEP_TALL(6)
-        BQ_SWEEP_TALL(7)
-        BQ_SWEEP_TALL(8)
-        BQ_SWEEP_TALL(9)
-    default:
-        return fail(c, BQ_ERR_BAD_ARG, "trsm_sweep: rows per workgroup");
-    }
-#undef BQ_SWEEP_TALL
     HIPCHK(c, hipGetLastError());
     return BQ_OK;
 }

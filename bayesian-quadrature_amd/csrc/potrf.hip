@@ -470,8 +470,10 @@ static int enqueue_potrf_dfirst(bq_ctx *c, double *A, long lda, long astride, in
         int st = BQ_OK;
         if (early) {
             st = enqueue_panel_solve(c, A, lda, astride, batch, r0, nw, K0, KB, rec, rstride);
-            if (st == BQ_OK)
-                HIPCHK(c, hipEventRecord(c->ev_top, c->aux));
+            // (no early return while c->cur is the second stream: a failed record falls through
+            // to the block below that restores it -- ADVICE r05)
+            if (st == BQ_OK && hipEventRecord(c->ev_top, c->aux) != hipSuccess)
+                st = fail(c, BQ_ERR_HIP, "hipEventRecord(ev_top)");
         }
         if (st == BQ_OK)
             st = launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda, astride, P,

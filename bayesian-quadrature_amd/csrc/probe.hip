@@ -382,7 +382,7 @@ extern "C" int bq_probe_mfma_layout(bq_ctx *c, double *out256)
 // The batched panel solve alone: X (m x kb per problem) <- X L^-T against `batch` lower-triangular
 // kb x kb factors L (host, column-major, dense lower triangles), through the launches the batched
 // factorisation issues for an outer block (mode 0: as the context is configured; 1: the recursive
-// products + solves; 2 / 3 / 10 + RT: the one-launch sweep, see below).  The factors' block-inverse records are built on
+// products + solves; 2: the one-launch sweep).  The factors' block-inverse records are built on
 // the device (diag_winv_kernel).
 extern "C" int bq_probe_panel_solve(bq_ctx *c, int64_t m, int64_t kb, int64_t batch, const double *L,
                                     double *X, int mode, int64_t reps, double *ms_per_call)
@@ -404,15 +404,11 @@ extern "C" int bq_probe_panel_solve(bq_ctx *c, int64_t m, int64_t kb, int64_t ba
                                    hipMemcpyHostToDevice, c->stream));
         BQCHK(launch_diag_winv(c, A.d() + b * astride, lda, (int)kb, rec.d() + b * rstride));
     }
-    // mode 2: the 64 x 64 tile of round 4; 3: the tall tile, rows per workgroup picked per launch;
-    // 10 + RT: the tall tile with 16 RT rows per workgroup
-    const int keep = c->df_sweep, keep_rt = c->sweep_rt;
+    const int keep = c->df_sweep;
     if (mode == 1)
         c->df_sweep = 0;
-    if (mode >= 2) {
+    if (mode == 2)
         c->df_sweep = 1;
-        c->sweep_rt = mode == 2 ? -1 : (mode == 3 ? 0 : (mode == 4 ? -2 : mode - 10));
-    }
     const int st = enqueue_panel_solve(c, A.d(), lda, astride, (int)batch, (int)kb, (int)m, 0,
                                        (int)kb, rec.d(), rstride);
     if (st == BQ_OK && reps > 0 && ms_per_call) {
@@ -425,11 +421,9 @@ extern "C" int bq_probe_panel_solve(bq_ctx *c, int64_t m, int64_t kb, int64_t ba
         BQCHK(bq_timer_stop_ms(c, &ms));
         *ms_per_call = ms / (double)reps;
         c->df_sweep = keep;
-        c->sweep_rt = keep_rt;
         return BQ_OK; // (X is not downloaded: it has been solved reps + 1 times)
     }
     c->df_sweep = keep;
-    c->sweep_rt = keep_rt;
     BQCHK(st);
     for (int64_t b = 0; b < batch; ++b)
         HIPCHK(c, hipMemcpy2DAsync(X + b * m * kb, sizeof(double) * m, A.d() + b * astride + kb,

@@ -155,8 +155,13 @@ def self_launch(a):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # (the script this process was started as: tests wrap main() in a launcher of their own)
-        script = os.path.abspath(sys.argv[0]) if sys.argv and sys.argv[0] else os.path.abspath(__file__)
+        # the ranks re-run THIS file; a wrapper that drives main() itself (the CPU test double,
+        # tests/bench_double_main.py) names itself in BQ_BENCH_LAUNCHER -- argv[0] is not trusted
+        # (python -c, a harness with its own argv)
+        script = os.environ.get("BQ_BENCH_LAUNCHER") or os.path.abspath(__file__)
+        if not os.path.isfile(script):
+            print("bench.py: launcher %r does not exist" % script, file=sys.stderr)
+            sys.exit(2)
         procs.append(subprocess.Popen([sys.executable, script] + sys.argv[1:], env=env))
     rcs = [None] * len(procs)
     # a rank that dies leaves the others in the gloo barrier: stop them instead of waiting
@@ -863,6 +868,91 @@ def batched_configs(eng):
     return out
 
 
+def fit_posterior_at_n(eng, sizes=(1024, 2048, 4096, 16384), M=256):
+    """BASELINE.json's metric read literally -- "BQ fit+posterior ms at N": ONE problem (Gram,
+    Cholesky, mean + variance at M = 256 points, log-ML) through the bordered plan with the inputs
+    resident, and through bq_fit_predict with host buffers, at N = 1024 ... 16384 (C2's data
+    shape: 1-D linspace, w = dx, s = 1e-3).  Work: N^3/3 + M N^2 flop."""
+    from bayesian_quadrature_amd import workloads as wl
+    out = {}
+    for n in sizes:
+        c = wl.c2(n, M)
+        reps = 20 if n <= 2048 else (8 if n <= 4096 else 3)
+        plan = eng.plan(1, 1, n, M)
+        plan.set_inputs(c["x"][None], c["y"][None], c["xo"][None], c["h"], c["w"], c["s"])
+        for _ in range(2):
+            plan.run()
+        eng.sync()
+        eng.timer_start()
+        for _ in range(reps):
+            plan.run()
+        ms = eng.timer_stop_ms() / reps
+        status = plan.results()[3]
+        plan.close()
+        eng.fit_predict(c["x"], c["y"], c["h"], c["w"], c["s"], c["xo"])
+        t0 = time.perf_counter()
+        for _ in range(max(2, reps // 2)):
+            eng.fit_predict(c["x"], c["y"], c["h"], c["w"], c["s"], c["xo"])
+        ms_host = (time.perf_counter() - t0) / max(2, reps // 2) * 1e3
+        fl = n ** 3 / 3.0 + float(M) * n * n
+        out["n%d" % n] = {"n": n, "m": M, "ms": ms, "ms_host_buffers": ms_host,
+                          "failed": int((status != 0).sum()), "algorithmic_flops": fl,
+                          "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_FP64_TFLOPS,
+                          "achieved": fl / (ms * 1e-3) / 1e12,
+                          "frac": fl / (ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS}
+    out["note"] = ("one problem per step, HIP events around back-to-back plan passes (inputs "
+                   "resident) / host wall per bq_fit_predict call (plan creation, H2D, run, D2H, "
+                   "synchronisation); kernel classes per size: profiles/r06_fitpost_n*_kernel_stats.csv")
+    return out
+
+
+NORTHSTAR_KEYS = ("trail16k_frac", "trail16k_dense_frac", "gram4096_frac", "gram16k_frac",
+                  "c5_frac", "c3_frac")
+
+
+def northstar_first(roof, rl):
+    """`roofline` with the north-star scalars FIRST, under short names (<= 24 characters): the
+    driver's record keeps about the first twenty keys of the object and cuts names at 40
+    characters (BENCH_r05.json lost the Gram fractions that way).  Each scalar equals the object
+    of `rooflines` named in `northstar_source`; the long definitions live there."""
+    head = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic")
+    out = {k: roof[k] for k in head if k in roof}
+    # SURVEY 8(d): 1.4318e12 flop / sum of ALL trailing-update launch time at N = 16384, nb = 256
+    out["trail16k_frac"] = rl["trailing_update_n16384"]["whole_trailing_update"]["frac"]
+    out["trail16k_dense_frac"] = rl["trailing_update_n16384_dense"]["whole_trailing_update"]["frac"]
+    out["gram4096_frac"] = rl["gram_n4096_d2"]["frac"]
+    out["gram16k_frac"] = rl["gram_n16384_d1"]["frac"]
+    out["c5_frac"] = rl["c5_shard_64x2048"]["frac"]
+    out["c3_frac"] = rl["c3_grid_400x4096"]["frac"]
+    fp = rl.get("fit_posterior_ms_at_n", {})
+    for n in (1024, 2048, 4096, 16384):
+        if "n%d" % n in fp:
+            out["fitpost_n%d_ms" % n] = fp["n%d" % n]["ms"]
+    out["c2x256_frac"] = rl["c2_batch_256x1024"]["frac"]
+    out["c5_ms"] = rl["c5_shard_64x2048"]["ms_per_batch"]
+    out["c3_ms"] = rl["c3_grid_400x4096"]["wall_ms"]
+    out["potrf16k_ms"] = rl["potrf_n16384"]["ms"]
+    out["c2x256_ms"] = rl["c2_batch_256x1024"]["ms_per_batch"]
+    for k, v in roof.items():
+        if k not in out:
+            out[k] = v
+    rl["northstar_source"] = {
+        "trail16k_frac": "rooflines.trailing_update_n16384.whole_trailing_update (C4's banded data): "
+                         "sum_k m_k^2 nb = 1.4318e12 flop / the time of every trailing-update "
+                         "launch, sequential launches, HIP events per launch",
+        "trail16k_dense_frac": "rooflines.trailing_update_n16384_dense.whole_trailing_update",
+        "trail16k_bulk_launches": "rooflines.trailing_update_n16384[_dense].frac: the bulk "
+                                  "gemm_lds_kernel launches alone",
+        "gram4096_frac": "rooflines.gram_n4096_d2 (134 MB: Infinity-Cache resident, not an HBM "
+                         "figure)",
+        "gram16k_frac": "rooflines.gram_n16384_d1", "c5_frac": "rooflines.c5_shard_64x2048",
+        "c3_frac": "rooflines.c3_grid_400x4096", "c2x256_frac": "rooflines.c2_batch_256x1024",
+        "potrf16k_ms": "rooflines.potrf_n16384 (tile 256; engine block: "
+                       "rooflines.potrf_n16384_engine_block)",
+        "fitpost_n*_ms": "rooflines.fit_posterior_ms_at_n"}
+    return out
+
+
 def curve_fields(line, wk, solo_ms, world):
     """Top-level fields of an N > 1 line from which a reader builds the 1 -> N curve without
     any other file: the same workload's N = 1 throughput measured in this run (rank 0 passes
@@ -1086,11 +1176,18 @@ def main():
             "data": "synthetic",
             "config": {"workload": wk["desc"],
                        "value_is": "problems/s of the whole job on: " + wk["desc"],
-                       "curve_workload": make_workload_desc(CURVE_WORKLOAD, a.curve_batch),
+                       # the workload the 1 -> N curve is on: at N = 1 the curve's point rides
+                       # beside the headline (scale_point); an N > 1 line IS a curve point only
+                       # when it runs that workload (`--gpus N --workload c2` used to
+                       # claim the C5 description for a C2 measurement)
+                       "curve_workload": (make_workload_desc(CURVE_WORKLOAD, a.curve_batch)
+                                          if dist.world == 1 else wk["desc"]),
+                       "on_curve": dist.world == 1 or a.workload == CURVE_WORKLOAD,
                        "curve_note": "the 1 -> N scaling curve is on curve_workload: N = 1 reads "
                                      "scale_point.value of the --gpus 1 line (whose `value` is "
                                      "config.workload), N > 1 reads `value`; every N > 1 line "
-                                     "repeats the N = 1 point as n1_same_workload",
+                                     "repeats the N = 1 point as n1_same_workload; a line with "
+                                     "on_curve false ran another workload and is not a curve point",
                        "problems_per_gpu_per_step": wk["B"],
                        "bordered_system": ntot, "sharding": "independent problems per rank, "
                        "no data-path collective",
@@ -1135,35 +1232,8 @@ def main():
                 line["probes"] = {"error": str(e)}
             if not a.no_extras:
                 line["rooflines"] = extras(eng, a.nb)
-                # the north-star figures as flat scalars of `roofline` (a reader that keeps only
-                # scalar keys still sees them); each equals the object of the same name in
-                # `rooflines` and is reproducible from profiles/ 
-                rl = line["rooflines"]
-                roof = line["roofline"]
-                # 1.4318e12 flop / sum of ALL trailing kernel time (bulk launches on
-                # gemm_lds_kernel + the small ones + the one-launch steps' updates); the bulk
-                # launches' own rate stays beside it under its own name
-                roof["trailing_update_n16384_frac_dense"] = \
-                    rl["trailing_update_n16384_dense"]["whole_trailing_update"]["frac"]
-                roof["trailing_update_n16384_frac_c4_data"] = \
-                    rl["trailing_update_n16384"]["whole_trailing_update"]["frac"]
-                roof["trailing_update_n16384_frac_definition"] = (
-                    "sum_k m_k^2 nb = 1.4318e12 flop / the time of every trailing-update launch "
-                    "(sequential launches, HIP events per launch)")
-                roof["trailing_update_n16384_bulk_launches_frac_dense"] = \
-                    rl["trailing_update_n16384_dense"]["frac"]
-                roof["trailing_update_n16384_bulk_launches_frac_c4_data"] = \
-                    rl["trailing_update_n16384"]["frac"]
-                roof["gram_n4096_frac"] = rl["gram_n4096_d2"]["frac"]
-                roof["gram_n4096_frac_note"] = "134 MB: Infinity-Cache resident, not an HBM figure"
-                roof["gram_n16384_frac"] = rl["gram_n16384_d1"]["frac"]
-                roof["potrf_n16384_ms"] = rl["potrf_n16384"]["ms"]
-                roof["potrf_n16384_engine_block_ms"] = rl["potrf_n16384_engine_block"]["ms"]
-                for tag, key in (("c5_shard_64x2048", "ms_per_batch"),
-                                 ("c2_batch_256x1024", "ms_per_batch"),
-                                 ("c3_grid_400x4096", "wall_ms")):
-                    roof[tag + "_frac"] = rl[tag]["frac"]
-                    roof[tag + "_ms"] = rl[tag][key]
+                line["rooflines"]["fit_posterior_ms_at_n"] = fit_posterior_at_n(eng)
+                line["roofline"] = northstar_first(line["roofline"], line["rooflines"])
             if not a.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(wk)
                 line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

@@ -5,7 +5,7 @@ shape bench.py drives (plan / timers / launch profiler), so that the CPU suite c
 JSON lines bench.py prints at --gpus 1 and --gpus 2 (tests/test_sharding.py).  The numbers in
 those lines are meaningless (a "pass" is a sleep); the keys, the rank plumbing over gloo and
 the parity block are what the test reads.  Nothing in the product or in bench.py imports this
-file; bench.py's own children re-run it because it is ``sys.argv[0]``.
+file; bench.py's own children re-run it because it names itself in BQ_BENCH_LAUNCHER.
 """
 import os
 import sys
@@ -97,6 +97,7 @@ class BenchEngineDouble(object):
 
 
 if __name__ == "__main__":
+    os.environ["BQ_BENCH_LAUNCHER"] = os.path.abspath(__file__)
     pkg.Engine = BenchEngineDouble
     bench.device_count = lambda: int(os.environ.get("BQ_TEST_FAKE_DEVICES", "8"))
     bench.main()

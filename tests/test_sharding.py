@@ -191,6 +191,36 @@ def test_bench_lines_carry_the_same_curve_workload():
         assert line["config"]["value_is"].endswith(line["config"]["workload"])
 
 
+def test_north_star_scalars_lead_the_roofline_object():
+    """The driver's record keeps about the first twenty keys of `roofline` and cuts names at 40
+    characters (BENCH_r05.json lost the Gram fractions behind three long keys): the six north-star
+    scalars are among the first 16 keys, at most 32 characters each, and equal their sources."""
+    import bench
+    rl = {"trailing_update_n16384": {"frac": 0.74, "whole_trailing_update": {"frac": 0.69}},
+          "trailing_update_n16384_dense": {"frac": 0.70, "whole_trailing_update": {"frac": 0.66}},
+          "gram_n4096_d2": {"frac": 0.84}, "gram_n16384_d1": {"frac": 0.67},
+          "c5_shard_64x2048": {"frac": 0.57, "ms_per_batch": 5.6},
+          "c3_grid_400x4096": {"frac": 0.64, "wall_ms": 181.0},
+          "c2_batch_256x1024": {"frac": 0.48, "ms_per_batch": 4.2},
+          "potrf_n16384": {"ms": 27.2},
+          "fit_posterior_ms_at_n": {"n1024": {"ms": 0.25}, "n16384": {"ms": 28.0}}}
+    roof = {"kernel": "syrk_trailing_small", "bound": "mfma", "achieved": 3.4, "peak": 78.6,
+            "unit": "TFLOP/s", "frac": 0.043, "traffic": None, "note": "x" * 300,
+            "time_basis": "y" * 100, "class_ms_per_step": {"a": 1.0}}
+    out = bench.northstar_first(roof, rl)
+    keys = list(out)
+    for k in bench.NORTHSTAR_KEYS:
+        assert k in keys[:16] and len(k) <= 32, k
+    assert keys[:7] == ["kernel", "bound", "achieved", "peak", "unit", "frac", "traffic"]
+    assert out["trail16k_frac"] == 0.69 and out["trail16k_dense_frac"] == 0.66
+    assert out["gram4096_frac"] == 0.84 and out["gram16k_frac"] == 0.67
+    assert out["c5_frac"] == 0.57 and out["c3_frac"] == 0.64
+    assert out["fitpost_n1024_ms"] == 0.25 and out["fitpost_n16384_ms"] == 28.0
+    assert keys.index("note") > keys.index("c2x256_ms") and out["note"] == roof["note"]
+    assert all(len(k) <= 32 for k in keys[:24])
+    assert set(bench.NORTHSTAR_KEYS) <= set(rl["northstar_source"])
+
+
 @pytest.mark.gpu
 def test_bench_launches_its_own_ranks(engine):
     """``bench.py --gpus 2`` started bare spawns two ranks itself.  On a one-GPU box that
