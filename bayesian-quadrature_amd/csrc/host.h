@@ -38,10 +38,22 @@
 #include <string>
 #include <vector>
 
+// Guard bands (tests): with bq_set_guard(1) every device buffer allocated afterwards carries
+// BQ_GUARD_BYTES of 0xA5 behind its last byte; bq_plan_check_guards counts the bytes of a plan's
+// bands that a pass has overwritten (round 5 found a workspace sized for the wrong block width
+// only because the next allocation happened to fault).
+#define BQ_GUARD_BYTES 4096
+inline bool &devbuf_guard()
+{
+    static bool on = std::getenv("BQ_GUARD") && std::atoi(std::getenv("BQ_GUARD"));
+    return on;
+}
+
 // RAII device buffer
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    size_t guard = 0; // bytes of sentinel behind `bytes` (0: none)
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
@@ -52,18 +64,39 @@ struct DevBuf {
             (void)hipFree(p);
         p = nullptr;
         bytes = 0;
+        guard = 0;
     }
     hipError_t alloc(size_t b)
     {
         release();
         if (b == 0)
             b = 8;
-        hipError_t e = hipMalloc(&p, b);
-        if (e == hipSuccess)
+        const size_t g = devbuf_guard() ? BQ_GUARD_BYTES : 0;
+        hipError_t e = hipMalloc(&p, b + g);
+        if (e == hipSuccess && g)
+            e = hipMemset(static_cast<char *>(p) + b, 0xA5, g);
+        if (e == hipSuccess) {
             bytes = b;
-        else
+            guard = g;
+        } else {
+            if (p)
+                (void)hipFree(p);
             p = nullptr;
+        }
         return e;
+    }
+    // bytes of the guard band that no longer hold the sentinel (-1: the read failed)
+    long guard_damage() const
+    {
+        if (!p || !guard)
+            return 0;
+        unsigned char h[BQ_GUARD_BYTES];
+        if (hipMemcpy(h, static_cast<const char *>(p) + bytes, guard, hipMemcpyDeviceToHost) != hipSuccess)
+            return -1;
+        long bad = 0;
+        for (size_t i = 0; i < guard; ++i)
+            bad += h[i] != 0xA5;
+        return bad;
     }
     double *d() const { return static_cast<double *>(p); }
     int *i() const { return static_cast<int *>(p); }

@@ -121,6 +121,32 @@ extern "C" int bq_plan_bytes(bq_plan *p, size_t *bytes)
     return BQ_OK;
 }
 
+extern "C" int bq_set_guard(int on)
+{
+    devbuf_guard() = on != 0;
+    return BQ_OK;
+}
+
+extern "C" int bq_plan_check_guards(bq_ctx *c, bq_plan *p, int64_t *guarded, int64_t *damaged)
+{
+    if (!c || !p || !guarded || !damaged)
+        return BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *guarded = *damaged = 0;
+    for (const DevBuf *b : {&p->A, &p->pts, &p->y, &p->gp, &p->dinv, &p->panel, &p->info, &p->scal,
+                            &p->mean, &p->var}) {
+        if (!b->guard)
+            continue;
+        ++*guarded;
+        const long bad = b->guard_damage();
+        if (bad < 0)
+            return fail(c, BQ_ERR_HIP, "guard band read-back failed");
+        *damaged += bad;
+    }
+    return BQ_OK;
+}
+
 extern "C" int bq_plan_set_inputs(bq_ctx *c, bq_plan *p, const double *x, const double *y,
                                   const double *xo, const double *h, const double *w,
                                   const double *s)

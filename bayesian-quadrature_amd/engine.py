@@ -98,6 +98,11 @@ class Engine(object):
     def set_block(self, nb):
         self._check(self._lib.bq_set_block(self._ctx, int(nb)))
 
+    def set_guard(self, on):
+        """Test aid: device buffers allocated from now on carry a 4 KiB sentinel band
+        (Plan.check_guards reads them back).  Process-wide."""
+        self._check(self._lib.bq_set_guard(1 if on else 0))
+
     def set_lookahead(self, on, min_rows=None):
         """Look-ahead on / off; min_rows: rows of the bulk update below which the sweep goes
         sequential (None keeps the current setting, 0 = look-ahead to the end)."""
@@ -671,6 +676,14 @@ class Plan(object):
         v = C.c_size_t()
         self._eng._check(self._eng._lib.bq_plan_bytes(self._handle(), C.byref(v)))
         return int(v.value)
+
+    def check_guards(self):
+        """(buffers that carry a sentinel band, sentinel bytes overwritten) -- see
+        Engine.set_guard; synchronises."""
+        g, bad = C.c_int64(), C.c_int64()
+        self._eng._check(self._eng._lib.bq_plan_check_guards(self._eng._ctx, self._handle(),
+                                                             C.byref(g), C.byref(bad)))
+        return int(g.value), int(bad.value)
 
     def set_inputs(self, x, y, xo, h, w, s):
         """x: (P, d, n) or (P, n); y: (P, n); xo: (P, d, M) or (P, M);

@@ -295,6 +295,14 @@ int bq_plan_results(bq_ctx *ctx, bq_plan *plan, double *mean, double *var, doubl
                     int32_t *status);
 /* bytes of device memory the plan holds */
 int bq_plan_bytes(bq_plan *plan, size_t *bytes);
+/* Test aid.  bq_set_guard(1): every device buffer the library allocates from now on carries a
+ * 4 KiB sentinel band behind its last byte (also: BQ_GUARD=1 in the environment when the library
+ * is loaded).  bq_plan_check_guards synchronises and reports how many of the plan's buffers carry
+ * a band and how many sentinel bytes a pass has overwritten (0 for a correct launch sequence).
+ * No reference counterpart: the reference's workspaces are numpy arrays (linalg_c.pyx:55-93
+ * factors in place); this checks that the batched sweep's block rules size theirs correctly. */
+int bq_set_guard(int on);
+int bq_plan_check_guards(bq_ctx *ctx, bq_plan *plan, int64_t *guarded, int64_t *damaged);
 
 /* ---- hardware probes (tools/probe.py, bench.py peak denominators) --- */
 /* sustained v_mfma_f64_16x16x4_f64 rate in TFLOP/s over all CUs */

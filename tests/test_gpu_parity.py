@@ -1596,6 +1596,93 @@ def test_batch_dense_vs_oracle_and_variants(engine, oracle, batch, n, m):
         assert relmax(v2, var, scale=oracle.kernel_scale(2, h, w)) < 1e-12, env
 
 
+@pytest.mark.parametrize("n", [700, 1100, 2048])
+@pytest.mark.parametrize("batch", [63, 64, 65, 95, 96, 97, 191, 192, 256])
+def test_batch_rule_boundaries(engine, oracle, batch, n):
+    """The batched sweep picks its launch sequence from the batch size and the system size: the
+    outer block (448, 384 from 96 matrices), the diagonal factor (one-launch steps below 96
+    matrices, a workgroup per matrix from 96 on -- and below, for blocks with >= 1000 rows under
+    them), 128- or 64-tiles per product.  Either side of every boundary, on DENSE 2-D problems:
+    two problems against the oracle at 1e-10, and every workspace of the plan behind a 4 KiB
+    sentinel band that a correct launch sequence leaves alone (round 5 sized the block-inverse
+    records for the wrong block width at 96-191 matrices and nothing noticed).  The reference's
+    contract: a factor is correct however it is blocked (tests/test_linalg_c.py:22-37)."""
+    m = 40
+    x, y, xo, h, w, s = _dense_batch(batch, n, m, seed=batch + n)
+    engine.set_guard(True)
+    try:
+        plan = engine.plan(batch, 2, n, m)
+    finally:
+        engine.set_guard(False)
+    try:
+        plan.set_inputs(x, y, xo, h, w, s)
+        plan.run()
+        mean, var, logml, status = plan.results()
+        guarded, damaged = plan.check_guards()
+        # and a second pass over the same plan (the graph replay) leaves the bands alone too
+        plan.run()
+        mean2, var2, logml2, _ = plan.results()
+        guarded2, damaged2 = plan.check_guards()
+    finally:
+        plan.close()
+    assert guarded >= 8 and damaged == 0 and damaged2 == 0, (guarded, damaged, damaged2)
+    assert (status == 0).all()
+    assert np.array_equal(mean, mean2) and np.array_equal(var, var2) and np.array_equal(logml, logml2)
+    for i in (0, batch - 1):
+        Lo, ao, lmo = oracle.gp_fit(x[i], y[i], h, w, s)
+        mo, vo = oracle.gp_predict(x[i], h, w, Lo, ao, xo[i])
+        assert relmax(mean[i], mo) < RTOL
+        assert relmax(var[i], vo, scale=oracle.kernel_scale(2, h, w)) < RTOL
+        # (relative to the size of the log-ML's own terms: on these random problems the three
+        # terms, each of order n, can cancel to a value of order one -- [95-2048]: 1.33 -- and no
+        # two summation orders agree to 1e-10 of THAT)
+        assert abs(logml[i] - lmo) <= RTOL * max(abs(lmo), 0.5 * n * np.log(2 * np.pi))
+
+
+def test_guard_bands_are_reported(engine):
+    """The sentinel switch itself: a plan created under it reports its guarded buffers (all ten
+    workspaces) with no damage before any pass; a plan created without it reports none."""
+    engine.set_guard(True)
+    try:
+        plan = engine.plan(3, 1, 200, 8)
+    finally:
+        engine.set_guard(False)
+    try:
+        guarded, damaged = plan.check_guards()
+        assert guarded == 10 and damaged == 0
+    finally:
+        plan.close()
+    plain = engine.plan(3, 1, 200, 8)
+    try:
+        assert plain.check_guards() == (0, 0)
+    finally:
+        plain.close()
+
+
+def test_c2_batch_256_vs_oracle(engine, oracle):
+    """The benched `c2_batch_256x1024` (256 copies of C2 per pass: bench.py, batched_configs) --
+    a batch size no other test reaches -- problems 0 / 128 / 255 against the oracle at 1e-10, all
+    256 the same bits (the copies are identical problems)."""
+    c = wl.c2()
+    B = 256
+    plan = engine.plan(B, 1, 1024, 256)
+    try:
+        plan.set_inputs(np.repeat(c["x"][None], B, axis=0), np.repeat(c["y"][None], B, axis=0),
+                        np.repeat(c["xo"][None], B, axis=0), c["h"], c["w"], c["s"])
+        plan.run()
+        mean, var, logml, status = plan.results()
+    finally:
+        plan.close()
+    assert (status == 0).all()
+    Lo, ao, lmo = oracle.gp_fit(c["x"], c["y"], c["h"], c["w"], c["s"])
+    mo, vo = oracle.gp_predict(c["x"], c["h"], c["w"], Lo, ao, c["xo"])
+    for i in (0, 128, 255):
+        assert relmax(mean[i], mo) < RTOL
+        assert relmax(var[i], vo, scale=oracle.kernel_scale(1, c["h"], c["w"])) < RTOL
+        assert abs(logml[i] - lmo) <= RTOL * abs(lmo)
+    assert (mean == mean[0]).all() and (var == var[0]).all() and (logml == logml[0]).all()
+
+
 def test_batch_diag_first_reports_not_pd(engine):
     """A hopeless matrix in the batch (length scale far beyond the spacing, no noise: not positive
     definite in fp64) is reported with a non-zero status, its neighbours are untouched."""
