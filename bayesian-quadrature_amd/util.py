@@ -36,9 +36,22 @@ def fd_points(x0, step):
     return X, np.array([X[i + 1, i] - x0[i] for i in range(x0.size)])
 
 
-# what the last find_good_parameters did: wall times of fit_hypers are trajectory-dependent
-# (L-BFGS-B on 1e-8 finite differences of a rounding-noisy objective), so timing tools print the
-# iterations, evaluations and the final value beside them
+def cd_points(x0):
+    """The 2p + 1 points of a central-difference gradient at x0 -- x0, x0 + h_i e_i, x0 - h_i e_i
+    -- with scipy's '3-point' relative step h_i = eps^(1/3) max(1, |x0_i|), and the exactly
+    representable spans (x0 + h_i) - (x0 - h_i)."""
+    x0 = np.asarray(x0, dtype=np.float64)
+    h = np.finfo(np.float64).eps ** (1.0 / 3.0) * np.maximum(1.0, np.abs(x0))
+    p = x0.size
+    X = np.repeat(x0[None, :], 2 * p + 1, axis=0)
+    for i in range(p):
+        X[1 + i, i] = x0[i] + h[i]
+        X[1 + p + i, i] = x0[i] - h[i]
+    return X, np.array([X[1 + i, i] - X[1 + p + i, i] for i in range(p)])
+
+
+# what the last find_good_parameters did: wall times of fit_hypers are trajectory-dependent, so
+# timing tools print the iterations, evaluations and the final value beside them
 LAST_OPT = {}
 
 
@@ -46,23 +59,37 @@ def find_good_parameters(logpdf, x0, method, ntry=10, logpdf_batch=None):
     """Up to ``ntry`` restarts of scipy.optimize.minimize on -logpdf; returns the
     first optimum whose log-pdf exceeds MIN, else None.
 
-    ``logpdf_batch`` (S x p array -> S values), if given, evaluates the p + 1 points of every
-    2-point gradient in ONE batched device pass: the objective and its gradient are handed to
-    scipy together (``jac=True``), computed at exactly the points and with exactly the steps
-    scipy's own finite differences would have used -- the same optimisation, p + 1 times
-    fewer dependent device passes."""
-    step = _FD_STEP.get(method) if logpdf_batch is not None else None
+    Without ``logpdf_batch`` this is the reference's call (util.py:151-169): scipy differences
+    the objective itself, p + 1 sequential evaluations per gradient with an absolute forward step
+    of 1e-8 -- on an fp64 objective whose value carries ~1e-13 of rounding noise that gradient is
+    good to ~1e-5, and L-BFGS-B stops wherever on the flat top the noise sends it.
+
+    ``logpdf_batch`` (S x p array -> S values) evaluates the 2p + 1 points of a CENTRAL difference
+    in ONE batched device pass (a pass costs the same for 2p + 1 stacked systems as for p + 1) and
+    hands scipy the value and that gradient together (``jac=True``): step eps^(1/3), truncation
+    and noise both ~1e-8.  NOT the reference's trajectory -- a better-conditioned one over the
+    same objective: it ends at least as high (round 5's forward-difference batch ended at -1.114
+    where the sequential run reached -0.940 on the reference's fixture; tests/test_bq_object.py
+    bounds the gap now)."""
+    batched = logpdf_batch is not None
 
     def fun_and_grad(x):
-        X, dx = fd_points(x, step)
+        X, span = cd_points(x)
+        p = x.size
         with np.errstate(invalid="ignore"):
             f = -np.asarray(logpdf_batch(X), dtype=np.float64)
-            g = (f[1:] - f[0]) / dx
+            g = (f[1:1 + p] - f[1 + p:]) / span
+            # a side that left the domain (-inf log-pdf): the one-sided difference on the other
+            bad = ~np.isfinite(g)
+            if bad.any():
+                fw = (f[1:1 + p] - f[0]) / (X[np.arange(1, 1 + p), np.arange(p)] - x)
+                bw = (f[0] - f[1 + p:]) / (x - X[np.arange(1 + p, 1 + 2 * p), np.arange(p)])
+                g = np.where(bad, np.where(np.isfinite(fw), fw, bw), g)
         return f[0], g
 
     for i in range(ntry):
         logger.debug("Attempt #%d with %s", i + 1, method)
-        if step is not None:
+        if batched:
             res = optim.minimize(fun=fun_and_grad, x0=x0, method=method, jac=True)
         else:
             res = optim.minimize(fun=lambda x: -logpdf(x), x0=x0, method=method)

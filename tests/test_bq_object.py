@@ -379,9 +379,12 @@ def test_llh_batch_matches_closure(pkg):
 
 
 def test_fit_hypers_batched_gradient(pkg):
-    """fit_hypers hands scipy the 2-point gradient from ONE batched pass over the p + 1 points
-    scipy's own differencing would have visited (same points, same steps): the optimum it
-    reaches is the optimum of the sequential optimisation."""
+    """fit_hypers hands scipy the objective and a CENTRAL-difference gradient from ONE batched
+    pass over 2p + 1 points (util.cd_points): the batch evaluates what the closure evaluates point
+    by point, its gradient agrees with forward differences to their noise, and the optimum it
+    reaches is at least as high as the one scipy's own sequential forward differencing -- the
+    reference's call, util.py:151-169 -- reaches from the same start (the
+    forward-difference batch of round 5 ended 0.17 lower on this fixture)."""
     from bayesian_quadrature_amd import util
     npseed()
     bq = make_bq(pkg)
@@ -390,6 +393,11 @@ def test_fit_hypers_batched_gradient(pkg):
     X, dx = util.fd_points(p0, 1e-8)
     assert X.shape == (5, 4) and (X[0] == p0).all()
     assert all((X[i + 1] != p0).sum() == 1 and X[i + 1, i] - p0[i] == dx[i] for i in range(4))
+    Xc, span = util.cd_points(p0)
+    assert Xc.shape == (9, 4) and (Xc[0] == p0).all()
+    for i in range(4):
+        assert (Xc[1 + i] != p0).sum() == 1 and (Xc[5 + i] != p0).sum() == 1
+        assert Xc[1 + i, i] > p0[i] > Xc[5 + i, i] and span[i] == Xc[1 + i, i] - Xc[5 + i, i]
     # the gradient itself: the batched pass against the closure called point by point
     f = bq._make_llh_params(params)
     fseq = np.array([-f(x) for x in X])
@@ -399,6 +407,9 @@ def test_fit_hypers_batched_gradient(pkg):
     # (a difference of values that agree to rounding, divided by 1e-8: the two routes' gradients
     # agree to the noise of either, ~1e-15 |f| cond / 1e-8)
     assert np.abs(g_bat - g_seq).max() <= 2e-4 * max(1.0, np.abs(g_seq).max())
+    fc = -bq._make_llh_batch(params)(Xc)
+    g_cd = (fc[1:5] - fc[5:]) / span
+    assert np.abs(g_cd - g_seq).max() <= 2e-4 * max(1.0, np.abs(g_seq).max())
     llh0 = f(p0)
     seq = util.find_good_parameters(f, p0, "L-BFGS-B")
     llh_seq = f(seq)
@@ -407,15 +418,8 @@ def test_fit_hypers_batched_gradient(pkg):
     f2 = bq2._make_llh_params(params)
     bat = util.find_good_parameters(f2, p0, "L-BFGS-B", logpdf_batch=bq2._make_llh_batch(params))
     llh_bat = f2(bat)
-    # L-BFGS-B on finite-difference gradients stops anywhere on the flat top; both runs must
-    # have climbed most of the way the better one did
     assert llh_seq > llh0 and llh_bat > llh0
-    best = max(llh_seq, llh_bat)
-    assert min(llh_seq, llh_bat) - llh0 > 0.5 * (best - llh0)
-    if type(bq._pair(5)).__name__ == "PairDouble":
-        # identical arithmetic on the CPU double: the very same optimisation
-        assert abs(llh_bat - llh_seq) < 1e-6 * abs(llh_seq)
-        assert np.allclose(bat, seq, rtol=5e-4)
+    assert llh_bat >= llh_seq - 1e-3 * abs(llh_seq), (llh_bat, llh_seq)
 
 
 def test_choose_next_batched_vs_loop(pkg):

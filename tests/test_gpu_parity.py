@@ -1031,12 +1031,13 @@ def test_bq_expected_moments_gpu_vs_double(engine, oracle):
     assert np.allclose(d[5], g[5], rtol=1e-6, atol=1e-13)
 
 
-def test_one_shot_plan_vs_resident_fit_large(engine):
-    """N = 6144, M = 200 through the one-shot bordered plan -- the two-stream look-ahead sweep
+@pytest.mark.parametrize("n,M", [(6144, 200), (16384, 256)])
+def test_one_shot_plan_vs_resident_fit_large(engine, n, M):
+    """N = 6144, M = 200 and N = 16384, M = 256 (the largest size of bench.py's
+    fit_posterior_ms_at_n) through the one-shot bordered plan -- the two-stream look-ahead sweep
     whose bulk updates skip the border x border block, results read off the border rows -- and
     through a resident fit + bq_gp_predict (full updates of its own system, row sweeps with
     the explicit block inverses): two different routes to the same posterior and log-ML."""
-    n, M = 6144, 200
     c = wl.c4(n)
     rs = np.random.RandomState(11)
     y = wl.norm_logpdf(c["x"]) + 0.01 * rs.randn(n)

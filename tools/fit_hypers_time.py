@@ -1,4 +1,4 @@
-"""BQ.fit_hypers(['h', 'w']) with the 2-point gradient from one batched device pass per gradient
+"""BQ.fit_hypers(['h', 'w']) with the central-difference gradient from one batched device pass per gradient
 (bq_pair_llh) against scipy's own sequential differencing of the same objective, on the
 reference's fixture size and at ns = 1024; and one evaluation of the objective."""
 import os
@@ -33,10 +33,10 @@ for n in (9, 64, 1024):
         f(p0 * (1.0 + 1e-4 * (it + 1)))
     t_eval = (time.perf_counter() - t0) / 20 * 1e3
     fb = b._make_llh_batch(params)
-    fb(util.fd_points(p0, 1e-8)[0])
+    fb(util.cd_points(p0)[0])
     t0 = time.perf_counter()
     for it in range(20):
-        fb(util.fd_points(p0 * (1.0 + 1e-4 * (it + 1)), 1e-8)[0])
+        fb(util.cd_points(p0 * (1.0 + 1e-4 * (it + 1)))[0])
     t_grad = (time.perf_counter() - t0) / 20 * 1e3
     res = {}
     for mode in ("sequential", "batched"):
@@ -46,7 +46,7 @@ for n in (9, 64, 1024):
         p = util.find_good_parameters(f, b._current_params(params), "L-BFGS-B",
                                       logpdf_batch=b._make_llh_batch(params) if mode == "batched" else None)
         res[mode] = (time.perf_counter() - t0, f(p), dict(util.LAST_OPT))
-    print("n=%d (nc=%d): objective %.3f ms, value + gradient (5 points) in one pass %.3f ms; "
+    print("n=%d (nc=%d): objective %.3f ms, value + central gradient (9 points) in one pass %.3f ms; "
           "fit_hypers sequential %.1f ms (llh %.9f, %d iterations, %d evaluations), batched "
           "gradient %.1f ms (llh %.9f, %d iterations, %d passes): %.2fx wall, %.3f / %.3f ms per "
           "iteration"
