@@ -89,6 +89,8 @@ SIGNATURES = {
     "bq_plan_results": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _i32p]),
     "bq_plan_bytes": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
     "bq_set_guard": (C.c_int, [C.c_int]),
+    "bq_probe_xcd_hop": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_double), _i32p,
+                                   C.POINTER(C.c_int64)]),
     "bq_plan_check_guards": (C.c_int, [_vp, _vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "bq_probe_mfma_f64": (C.c_int, [_vp, _dp]),
     "bq_probe_fma_f64": (C.c_int, [_vp, _dp]),

@@ -281,3 +281,92 @@ __global__ __launch_bounds__(64 * NW) void potf2_probe_kernel(const double *__re
         potf2_body<NW>(A, lda, 0, dinv, info, lds, nullptr, 0, stamps);
     }
 }
+
+// ---------------------------------------------------------------------------
+// What a hand-off between two workgroups costs (could the C2 pass be ONE
+// launch resident on ONE XCD, its 16 steps handing over through that XCD's L2 instead of through
+// launch boundaries?).  Sixteen one-wave workgroups, eight ping-pong pairs; the producer writes
+// n16 x 1 KiB of payload and a flag, the consumer polls the flag, reads the payload and answers.
+//   mode 0: partners b and b + 8 (observed: the same XCD); plain payload stores, s_waitcnt,
+//           flag stored sc1; flag polled and payload read with sc1 loads (L1 bypassed, served by
+//           the XCD's L2) -- no buffer_wbl2, no buffer_inv
+//   mode 1: partners b and b + 1 (different XCDs); agent-scope release before the flag, agent-
+//           scope acquire after the poll -- the form every cross-XCD hand-off in this library uses
+//   mode 2: as 1 between partners b and b + 8 (what the fences cost inside one XCD)
+// Bounded spins: a partner that never answers raises *err and everyone leaves.
+// out[b] = wall-clock ticks (100 MHz) of block b's loop, xcc[b] = its XCC id, bad[b] = payload
+// words that did not carry the expected value.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void probe_hop_kernel(unsigned *flags, double *payload, int iters,
+                                                       int mode, int n16, long long *out, int *xcc,
+                                                       int *bad, int *err)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int pair = mode == 1 ? (b >> 1) : (b & 7), side = mode == 1 ? (b & 1) : (b >> 3);
+    unsigned *mine = flags + (2 * pair + side) * 64, *peer = flags + (2 * pair + 1 - side) * 64;
+    double *pmine = payload + (size_t)(2 * pair + side) * 128 * n16;
+    const double *ppeer = payload + (size_t)(2 * pair + 1 - side) * 128 * n16;
+    if (lane == 0) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        xcc[b] = (int)(id & 0xf);
+    }
+    int nbad = 0;
+    bool dead = false;
+    const long long t0 = wall_clock64();
+    for (int i = 1; i <= iters && !dead; ++i) {
+        for (int ph = 0; ph < 2; ++ph) {
+            if ((ph == 0) == (side == 0)) {
+                // produce
+                for (int q = 0; q < n16; ++q) {
+                    double *d = pmine + q * 128 + 2 * lane;
+                    d[0] = (double)i;
+                    d[1] = (double)(i + q);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (mode != 0)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0)
+                    __hip_atomic_store(mine, (unsigned)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                // consume
+                int spins = 0;
+                unsigned v;
+                do {
+                    v = __hip_atomic_load(peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = __builtin_amdgcn_readfirstlane(v);
+                    if (++spins > (1 << 20) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        dead = true;
+                        break;
+                    }
+                } while (v < (unsigned)i);
+                if (dead)
+                    break;
+                if (mode != 0)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                for (int q = 0; q < n16; ++q) {
+                    const double *s = ppeer + q * 128 + 2 * lane;
+                    double a, c;
+                    if (mode == 0) {
+                        a = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        c = __hip_atomic_load(s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        a = s[0];
+                        c = s[1];
+                    }
+                    nbad += (a != (double)i) + (c != (double)(i + q));
+                }
+            }
+        }
+    }
+    const long long t1 = wall_clock64();
+    if (dead && lane == 0)
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int off = 32; off; off >>= 1)
+        nbad += __shfl_down(nbad, off);
+    if (lane == 0) {
+        out[b] = t1 - t0;
+        bad[b] = nbad;
+    }
+}

@@ -365,6 +365,49 @@ extern "C" int bq_probe_launch(bq_ctx *c, int64_t n, double *us_per_launch)
     return BQ_OK;
 }
 
+// ns per hand-off (one direction) of probe_hop_kernel's eight ping-pong pairs, the pairs' XCC ids
+// and the payload words that arrived wrong; BQ_ERR_HIP if a partner never answered
+extern "C" int bq_probe_xcd_hop(bq_ctx *c, int mode, int64_t iters, int64_t kib, double *ns_per_hop,
+                                int32_t *xcc16, int64_t *bad_words)
+{
+    if (!c || !ns_per_hop || !xcc16 || !bad_words || mode < 0 || mode > 2 || iters < 1 ||
+        iters > 100000 || kib < 1 || kib > 64)
+        return c ? fail(c, BQ_ERR_BAD_ARG, "xcd_hop: mode 0..2, 1..100000 iterations, 1..64 KiB")
+                 : BQ_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf flags, pay, out, xcc, bad, err;
+    HIPCHK(c, flags.alloc(sizeof(unsigned) * 64 * 16));
+    HIPCHK(c, pay.alloc(sizeof(double) * 128 * (size_t)kib * 16));
+    HIPCHK(c, out.alloc(sizeof(long long) * 16));
+    HIPCHK(c, xcc.alloc(sizeof(int) * 16));
+    HIPCHK(c, bad.alloc(sizeof(int) * 16));
+    HIPCHK(c, err.alloc(sizeof(int)));
+    HIPCHK(c, hipMemsetAsync(flags.p, 0, flags.bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(pay.p, 0, pay.bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(err.p, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(probe_hop_kernel, dim3(16), dim3(64), 0, c->stream,
+                       static_cast<unsigned *>(flags.p), pay.d(), (int)iters, mode, (int)kib,
+                       static_cast<long long *>(out.p), xcc.i(), bad.i(), err.i());
+    HIPCHK(c, hipGetLastError());
+    long long ho[16];
+    int hb[16], he = 0;
+    HIPCHK(c, hipMemcpyAsync(ho, out.p, sizeof ho, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(xcc16, xcc.p, sizeof(int) * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hb, bad.p, sizeof hb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&he, err.p, sizeof he, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (he)
+        return fail(c, BQ_ERR_HIP, "xcd_hop: a partner never answered (bounded spin ran out)");
+    long long worst = 0;
+    *bad_words = 0;
+    for (int b = 0; b < 16; ++b) {
+        worst = std::max(worst, ho[b]);
+        *bad_words += hb[b];
+    }
+    *ns_per_hop = (double)worst * 10.0 / (2.0 * (double)iters); // 100 MHz ticks
+    return BQ_OK;
+}
+
 extern "C" int bq_probe_mfma_layout(bq_ctx *c, double *out256)
 {
     if (!c || !out256)

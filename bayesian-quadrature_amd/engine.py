@@ -456,6 +456,17 @@ class Engine(object):
             return float(ms.value)  # ms per call
         return np.transpose(Xf, (0, 2, 1)).copy()
 
+    def probe_xcd_hop(self, mode, iters=2000, kib=1):
+        """(ns per hand-off, XCC ids of the 16 workgroups, stale payload words) -- see
+        bq_probe_xcd_hop in include/bqhip.h."""
+        ns, bad = C.c_double(), C.c_int64()
+        xcc = np.zeros(16, dtype=np.int32)
+        self._check(self._lib.bq_probe_xcd_hop(self._ctx, int(mode), int(iters), int(kib),
+                                               C.byref(ns),
+                                               xcc.ctypes.data_as(C.POINTER(C.c_int32)),
+                                               C.byref(bad)))
+        return float(ns.value), xcc, int(bad.value)
+
     def probe_launch(self, n=2000):
         v = C.c_double()
         self._check(self._lib.bq_probe_launch(self._ctx, int(n), C.cast(C.byref(v), _dp)))

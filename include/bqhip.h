@@ -311,6 +311,15 @@ int bq_probe_mfma_f64(bq_ctx *ctx, double *tflops);
 int bq_probe_fma_f64(bq_ctx *ctx, double *tflops);
 /* streaming fp64 write / copy bandwidth in GB/s over `bytes` */
 int bq_probe_hbm(bq_ctx *ctx, size_t bytes, double *write_gbs, double *copy_gbs);
+/* ns per hand-off between two one-wave workgroups (eight ping-pong pairs, the slowest pair):
+ * mode 0 = partners on one XCD, plain payload stores + sc1 flag, sc1 loads (no cache maintenance);
+ * 1 = partners on different XCDs behind agent-scope release / acquire; 2 = as 1 on one XCD.  kib:
+ * KiB of payload per hand-off.  xcc16: the XCC id each of the 16 workgroups ran on; bad_words:
+ * payload words that arrived stale.  Bounded spins (status 3 if a partner never answers).
+ * Measurement behind docs/LABBOOK.md round 6 (the C2 chain as one launch); no reference
+ * counterpart (linalg_c.pyx:55-93 is one LAPACK call). */
+int bq_probe_xcd_hop(bq_ctx *ctx, int mode, int64_t iters, int64_t kib, double *ns_per_hop,
+                     int32_t *xcc16, int64_t *bad_words);
 /* C (m x n) -= P (m x k) Q (n x k)^T on scratch operands through the engine's own kernel
  * selection (lower: only the lower trapezoid; qt: Q given k-contiguous): average ms over `reps`
  * back-to-back launches -- the tuning probe behind tools/gemm_probe.py */
