@@ -818,9 +818,9 @@ def batched_configs(eng):
         "potrf_tflops_lower_bound": flops / (ms * 1e-3) / 1e12,
         "note": "wall-derived: (N^3/3 + M N^2) per problem over the HIP-event time of a "
                 "plan pass; the kernel classes of this shard and the MFMA utilisation of its "
-                "gemm_lds_kernel launches are in profiles/r05_c5_kernel_stats.csv and "
-                "profiles/r05_mfma_util.json; the pass's launch timeline in "
-                "profiles/r05_plan_timeline_c5.txt"}
+                "gemm_lds_kernel launches are in profiles/r06_c5_kernel_stats.csv and "
+                "profiles/r06_mfma_util.json; the pass's launch timeline in "
+                "profiles/r06_plan_timeline_c5.txt"}
     # the headline problem, 256 independent copies per step: what batching buys over the
     # latency-bound single problem of `value`
     c2 = wl.c2()
@@ -864,7 +864,7 @@ def batched_configs(eng):
                                "note": "wall-derived: N^3/3 per grid point over the host wall "
                                        "clock incl. the upload of the 400 parameter sets and the "
                                        "read-back of the 400 results; kernel classes of one chunk "
-                                       "in profiles/r05_c3_kernel_stats.csv"}
+                                       "in profiles/r06_c3_kernel_stats.csv"}
     return out
 
 

@@ -1,7 +1,7 @@
 """Condenses the rocprofv3 runs of tools/<tag>_profiles.sh into the small tables that are
 committed under profiles/ (run on the GPU box; results come back through gpurun_out/):
 
-    python3 tools/pmc_summary.py gpurun_out/r05p r05 [outdir]
+    python3 tools/pmc_summary.py gpurun_out/r06p r06 [outdir]
 
 Per pass P of tools/roofline_run.py (one rocprofv3 run each, never blended):
     <tag>_<P>_kernel_stats.csv     copy of the --stats summary of `t_<P>`
@@ -34,7 +34,8 @@ import shutil
 import sys
 
 PASSES = ("c2", "gram", "potrf256", "potrf256_dense", "potrf_engine", "trsv", "solve256", "predict",
-          "c5", "c5_nola", "c2x256", "c3", "calib")
+          "c5", "c5_nola", "c2x256", "c3", "calib", "fitpost_n1024", "fitpost_n2048", "fitpost_n4096",
+          "fitpost_n16384")
 PEAK = 78.6e12
 
 

@@ -1,16 +1,16 @@
 #!/bin/bash
-# Round-5 profile set.  One rocprofv3 run per pass of tools/roofline_run.py (never blended):
+# Round-6 profile set.  One rocprofv3 run per pass of tools/roofline_run.py (never blended):
 # kernel trace + stats for every pass, and -- in separate runs, counters only -- WRITE_SIZE /
 # FETCH_SIZE / the MFMA counters for the passes whose rooflines quote them.  The program goes
-# directly after `--`.  tools/pmc_summary.py condenses everything into profiles/r05_*.
+# directly after `--`.  tools/pmc_summary.py condenses everything into profiles/r06_*.
 set -o pipefail
-O=$PWD/gpurun_out/r05p
+O=$PWD/gpurun_out/r06p
 mkdir -p $O
 export TMPDIR=/tmp
 T="rocprofv3 --kernel-trace --stats --output-format csv"
 $T -d $O/bench -o bench -- python3 bench.py --steps 200 --warmup 10 > $O/bench_under_rocprof.json 2> $O/bench.err || { echo bench-prof-failed; tail -5 $O/bench.err; }
 echo bench-done
-for p in c2 gram potrf256 potrf256_dense potrf_engine trsv solve256 predict c5 c2x256 c3 calib; do
+for p in c2 gram potrf256 potrf256_dense potrf_engine trsv solve256 predict c5 c2x256 c3 calib fitpost_n1024 fitpost_n2048 fitpost_n4096 fitpost_n16384; do
   $T -d $O/t_$p -o t -- python3 tools/roofline_run.py $p > $O/t_$p.txt 2>&1 || echo trace-$p-failed
   echo trace-$p-done
 done
@@ -30,7 +30,7 @@ for p in potrf256 potrf256_dense c5; do
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/m_$p -o m -- python3 tools/roofline_run.py $p > $O/m_$p.txt 2>&1 || echo m-$p-failed
   echo mfma-$p-done
 done
-python3 tools/pmc_summary.py $O r05 > $O/summary.txt 2>&1 || { echo summary-failed; tail -20 $O/summary.txt; }
+python3 tools/pmc_summary.py $O r06 > $O/summary.txt 2>&1 || { echo summary-failed; tail -20 $O/summary.txt; }
 # the merge back is capped: keep the small tables only
 find $O -name "*agent_info.csv" -delete
 find $O -name "*kernel_trace.csv" -size +3M -delete
@@ -43,4 +43,11 @@ python tools/panel_solve_time.py > $O/panel_solve_time.txt 2>&1 || echo panel-so
 python tools/trsv_flow_check.py 2048 4096 16384 > $O/trsv_flow_check.txt 2>&1 || echo trsv-flow-failed
 python tools/choose_next_time.py > $O/choose_next_time.txt 2>&1 || echo choose-next-failed
 python tools/fit_hypers_time.py > $O/fit_hypers_time.txt 2>&1 || echo fit-hypers-failed
+# round 6: the panel solve under the socket's power cap (sustained rates, clock, watts), its
+# ablations (debug build), and what a hand-off costs inside one XCD
+bash tools/r06_shapes.sh > /dev/null 2>&1; cp gpurun_out/r06s/power5.txt $O/panel_solve_power.txt 2>/dev/null || echo shapes-failed
+(cd bayesian-quadrature_amd/csrc && make -j8 DEFS=-DBQ_TS_DBG OUT=../libbqhip_dbg.so > /dev/null 2>&1) && bash tools/r06_ablate.sh > /dev/null 2>&1; cp gpurun_out/r06s/ablate.txt $O/panel_solve_ablate.txt 2>/dev/null || echo ablate-failed
+rm -f bayesian-quadrature_amd/libbqhip_dbg.so
+python tools/xcd_hop.py > $O/xcd_hop.txt 2>&1 || echo xcd-hop-failed
+python tools/power_probe.py > $O/power_probe.txt 2>&1 || echo power-probe-failed
 python bench.py > $O/bench.json 2> $O/bench2.err; echo bench rc=$?

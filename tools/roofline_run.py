@@ -17,9 +17,11 @@ must be reproducible from the tracked profiles alone, so passes are never blende
   c2x256        256 copies of the C2 problem as one plan, 4 runs
   c3            one C3 chunk (100 grid points at N=4096 d=2), 2 runs
   calib         4 read-only passes over 1 GiB with 8-byte-per-lane loads (FETCH_SIZE calibration)
+  fitpost_n<N>  ONE problem at N (1024 / 2048 / 4096 / 16384), M = 256 through the bordered plan,
+                4 passes: the kernels behind bench.py's fit_posterior_ms_at_n
 
 Used under `rocprofv3 --kernel-trace --stats` and, in separate runs, `rocprofv3 --pmc ...`
-(tools/r04_profiles.sh); tools/pmc_summary.py turns the outputs into profiles/r04_*."""
+(tools/r06_profiles.sh); tools/pmc_summary.py turns the outputs into profiles/r06_*."""
 import os
 import sys
 
@@ -138,6 +140,17 @@ def main():
             t0 = time.perf_counter()
             e.logml_grid(c3["x"], c3["y"], c3["h"][:100], c3["w"][:100], c3["s"], chunk=100)
             print("c3 chunk rep", rep, "%.1f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
+    elif what.startswith("fitpost_n"):
+        n = int(what[len("fitpost_n"):])
+        c = wl.c2(n, 256)
+        plan = e.plan(1, 1, n, 256)
+        plan.set_inputs(c["x"][None], c["y"][None], c["xo"][None], c["h"], c["w"], c["s"])
+        for rep in range(4):
+            e.sync()
+            e.timer_start()
+            plan.run()
+            print(what, "rep", rep, "%.3f ms" % e.timer_stop_ms(), flush=True)
+        plan.close()
     elif what == "calib":
         print("read8 GB/s", e.probe_hbm_read8(1 << 30, 4))
     else:
