@@ -81,7 +81,7 @@ extern "C" int bq_probe_hbm(bq_ctx *c, size_t bytes, double *write_gbs, double *
 
 // `reps` launches of probe_read8_kernel over a `bytes`-sized buffer: a known byte count in the
 // single-vector sweeps' access pattern (8 B per lane, 512 contiguous bytes per wave), for the
-// calibration of rocprofv3's FETCH_SIZE on that pattern (tools/r03_profiles.sh)
+// calibration of rocprofv3's FETCH_SIZE on that pattern (tools/r06_profiles.sh, pass `calib`)
 extern "C" int bq_probe_hbm_read8(bq_ctx *c, size_t bytes, int64_t reps, double *read_gbs)
 {
     if (!c || bytes < 4096 || reps < 1)
