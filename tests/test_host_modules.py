@@ -269,6 +269,35 @@ def test_slice_sample_batched_is_the_same_chain(w):
                           logpdf_batch=lambda X: np.full(len(X), -np.inf))
 
 
+def test_find_good_parameters_central_difference_batch():
+    """util.find_good_parameters with a batched log-pdf: the 2p + 1 points of a central difference
+    per gradient in ONE call, the optimum of a smooth objective to the optimiser's tolerance, and a
+    one-sided difference where a side of the stencil has left the domain (log-pdf -inf there)."""
+    from bayesian_quadrature_amd import util
+    X, span = util.cd_points(np.array([2.0, -3.0e3, 0.0]))
+    h = np.finfo(np.float64).eps ** (1.0 / 3.0)
+    assert X.shape == (7, 3) and np.allclose(span, 2 * h * np.array([2.0, 3.0e3, 1.0]), rtol=1e-6)
+    shapes = []
+
+    def logpdf(x):
+        if x[0] <= 0.0:
+            return -np.inf
+        return float(-(np.log(x[0]) - 0.3) ** 2 - 2.0 * (x[1] + 1.5) ** 2 + 5.0)
+
+    def logpdf_batch(Xb):
+        shapes.append(Xb.shape)
+        return np.array([logpdf(x) for x in Xb])
+
+    got = util.find_good_parameters(logpdf, np.array([2.0, 0.5]), "L-BFGS-B", logpdf_batch=logpdf_batch)
+    assert set(shapes) == {(5, 2)}
+    assert np.allclose(got, [np.exp(0.3), -1.5], atol=2e-5)
+    assert util.LAST_OPT["logpdf"] > 5.0 - 1e-9
+    # a start so close to the wall that the backward point is outside: the forward difference is
+    # used for that coordinate and the run still climbs
+    got = util.find_good_parameters(logpdf, np.array([1e-6, 0.0]), "L-BFGS-B", logpdf_batch=logpdf_batch)
+    assert got is not None and logpdf(got) > logpdf(np.array([1e-6, 0.0]))
+
+
 def test_slice_sample_zero_probability_start():
     from bayesian_quadrature_amd import util
     with pytest.raises(RuntimeError):
