@@ -1124,6 +1124,40 @@ def test_predict_m1000_at_benched_size(engine, oracle):
     fit.close()
 
 
+@pytest.mark.parametrize("d,n,M,route", [(1, 2048, 100, "direct"), (1, 2500, 333, "direct"),
+                                         (2, 4096, 4200, "staged")])
+def test_predict_point_routes_at_large_npad(engine, oracle, d, n, M, route):
+    """Mean + variance on a resident fit with npad >= 2048 and M NOT a multiple of 64: the cross
+    Gram reads the prediction points straight out of the mapped staging buffer and writes its own
+    padding (`direct`, fit.hip) while the npad / 64 uncached passes over the points stay below
+    4 MiB, and takes them through one device copy above (`staged`: d M 8 B x 64 passes = 4.3 MB
+    here) -- ADVICE r05.  Both against the oracle at 1e-10; the covariance route (always staged)
+    gives the same mean and diagonal."""
+    rs = np.random.RandomState(n + M)
+    if d == 1:
+        c = wl.c4(n)
+        x, h, w, s = c["x"], c["h"], c["w"], c["s"]
+        y = wl.norm_logpdf(x) + 0.01 * rs.randn(n)
+        xo = np.sort(rs.uniform(-5.2, 5.2, M))
+    else:
+        c = wl.c3()
+        x, h, w, s = c["x"], float(c["h"][210]), c["w"][210], c["s"]
+        y = c["y"]
+        xo = rs.uniform(-5.0, 5.0, (2, M))
+    npad = -(-n // 64) * 64
+    assert (d * M * 8 * (npad // 64) <= (4 << 20)) == (route == "direct")
+    fit = engine.gp_fit(x, y, h, w, s)
+    Lo, ao, _ = oracle.gp_fit(x, y, h, w, s)
+    mo, vo = oracle.gp_predict(x, h, w, Lo, ao, xo)
+    m, v, _ = fit.predict(xo)
+    k0 = oracle.kernel_scale(d, h, w)
+    assert relmax(m, mo) < RTOL and relmax(v, vo, scale=k0) < RTOL
+    if M <= 512:
+        m2, v2, cov = fit.predict(xo, want_cov=True)
+        assert relmax(m2, m) < 1e-12 and relmax(np.diag(cov), v, scale=k0) < 1e-11
+    fit.close()
+
+
 def test_kernel_copies_match_the_copy_engine_route(engine):
     """BQ_SOLVE_KCOPY (default on): the small transfers of the latency-bound calls go through kernels
     on mapped pinned staging buffers instead of copy-engine operations and memsets, and the smallest
