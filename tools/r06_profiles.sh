@@ -48,6 +48,9 @@ python tools/fit_hypers_time.py > $O/fit_hypers_time.txt 2>&1 || echo fit-hypers
 bash tools/r06_shapes.sh > /dev/null 2>&1; cp gpurun_out/r06s/power5.txt $O/panel_solve_power.txt 2>/dev/null || echo shapes-failed
 (cd bayesian-quadrature_amd/csrc && make -j8 DEFS=-DBQ_TS_DBG OUT=../libbqhip_dbg.so > /dev/null 2>&1) && bash tools/r06_ablate.sh > /dev/null 2>&1; cp gpurun_out/r06s/ablate.txt $O/panel_solve_ablate.txt 2>/dev/null || echo ablate-failed
 rm -f bayesian-quadrature_amd/libbqhip_dbg.so
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_MFMA --output-format csv -d $O/pmc_sweep_a -o p -- python3 tools/panel_solve_one.py 2 2048 448 64 4 > $O/pmc_sweep_a.txt 2>&1 || echo pmc-sweep-a-failed
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sweep_b -o p -- python3 tools/panel_solve_one.py 2 2048 448 64 4 > $O/pmc_sweep_b.txt 2>&1 || echo pmc-sweep-b-failed
+python3 tools/pmc_avg.py trsm_sweep $O/pmc_sweep_a $O/pmc_sweep_b > $O/panel_solve_pmc.txt 2>&1 || echo pmc-sweep-summary-failed
 python tools/xcd_hop.py > $O/xcd_hop.txt 2>&1 || echo xcd-hop-failed
 python tools/power_probe.py > $O/power_probe.txt 2>&1 || echo power-probe-failed
 python bench.py > $O/bench.json 2> $O/bench2.err; echo bench rc=$?
