@@ -117,6 +117,8 @@ static int ctx_init(bq_ctx *c, int device)
         c->split_batch = std::atoi(e);
     if (const char *e = std::getenv("BQ_DIAG_FIRST"))
         c->diag_first = std::atoi(e);
+    if (const char *e = std::getenv("BQ_ASM_FUSE"))
+        c->asm_fuse = std::atoi(e);
     if (const char *e = std::getenv("BQ_DF_SWEEP"))
         c->df_sweep = std::atoi(e);
     if (const char *e = std::getenv("BQ_DF_WG"))

@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 #include "potf2.h"
+#include "seed.h"
 
 
 // one wave tile of C -= P Q^T (see gemm_sub_kernel); C, P, Q already point at the batch element
@@ -486,12 +487,14 @@ __global__ __launch_bounds__(256) void gemm_k64_kernel(double *__restrict__ C, l
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void global_cvoid_t;
 
-__global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C, long ldc,
-                                                          long cstride, const double *__restrict__ P,
-                                                          long ldp, long pstride,
-                                                          const double *__restrict__ Q, long ldq,
-                                                          long qstride, int m, int n, int k,
-                                                          int lower, int ncut)
+// SD > 0: C has not been written yet -- the accumulators start as minus the bordered system's own
+// entries (gram_seed_neg<SD>, points of dimension SD) instead of minus a loaded tile
+template <int SD>
+__device__ __forceinline__ void gemm_lds_body(double *__restrict__ C, long ldc, long cstride,
+                                              const double *__restrict__ P, long ldp, long pstride,
+                                              const double *__restrict__ Q, long ldq, long qstride,
+                                              int m, int n, int k, int lower, int ncut,
+                                              const GramSeed *sd)
 {
     // ncut: columns >= ncut of C are left alone (the border x border block of a bordered
     // system, which nothing reads: see plan_readout_kernel)
@@ -587,8 +590,12 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C
     const int nchunk = k / BQ_LDS_KC; // even
     BQ_LDS_FILL(0, 0)
     const Tile444<4, 4> ct(C, ldc, row0, col0, lane);
-    if (active)
-        ct.load_neg(acc);
+    if (active) {
+        if (SD > 0)
+            gram_seed_neg<(SD > 0 ? SD : 1), 4, 4>(acc, *sd, b, row0, col0, lane);
+        else
+            ct.load_neg(acc);
+    }
     for (int ch = 0; ch < nchunk; ch += 2) {
         BQ_LDS_CHUNK(0, ch)
         BQ_LDS_CHUNK(1, ch + 1)
@@ -602,6 +609,26 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C
     if (!active)
         return;
     ct.store_neg(acc, lower);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C, long ldc,
+                                                          long cstride, const double *__restrict__ P,
+                                                          long ldp, long pstride,
+                                                          const double *__restrict__ Q, long ldq,
+                                                          long qstride, int m, int n, int k,
+                                                          int lower, int ncut)
+{
+    gemm_lds_body<0>(C, ldc, cstride, P, ldp, pstride, Q, ldq, qstride, m, n, k, lower, ncut, nullptr);
+}
+
+// ... its tile of C computed, not loaded (the first product over a region the assembly left out)
+template <int SD>
+__global__ __launch_bounds__(256, 2) void gemm_lds_seed_kernel(
+    double *__restrict__ C, long ldc, long cstride, const double *__restrict__ P, long ldp,
+    long pstride, const double *__restrict__ Q, long ldq, long qstride, int m, int n, int k,
+    int lower, int ncut, GramSeed sd)
+{
+    gemm_lds_body<SD>(C, ldc, cstride, P, ldp, pstride, Q, ldq, qstride, m, n, k, lower, ncut, &sd);
 }
 
 
@@ -639,14 +666,15 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(double *__restrict__ C
 // trsm_blk_kernel scheme applied to the tile on its way out (through LDS into that kernel's
 // 16-rows-per-wave operand form): one launch and one pass over the slab less per 64 columns.
 // Lss: the slab's factored 64 x 64 diagonal block, wrec: its record of block inverses.
-template <bool QT, int KS = 1, bool TRSM = false>
+template <bool QT, int KS = 1, bool TRSM = false, int SD = 0>
 __device__ __forceinline__ void gemm_lds64_body(unsigned char *smem, double *__restrict__ C,
                                                 long ldc, const double *__restrict__ P, long ldp,
                                                 const double *__restrict__ Q, long ldq, int m,
                                                 int n, int k, int lower, int ncut, int bx, int by,
                                                 const double *__restrict__ Lss = nullptr,
                                                 long ldl = 0,
-                                                const double *__restrict__ wrec = nullptr)
+                                                const double *__restrict__ wrec = nullptr,
+                                                const GramSeed *sd = nullptr, int sb = 0)
 {
     const int t = threadIdx.x, lane = t & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -750,9 +778,12 @@ __device__ __forceinline__ void gemm_lds64_body(unsigned char *smem, double *__r
     // LDS-DMA removed a chunk takes 0.54 us, with it 0.52-0.55: the k loop is MFMA-bound at 80 %
     // of a CU's rate whether four waves walk it or eight; what the eight gain is the job tiles')
     BQ_L64_FILL(0, 0)
-    if (active && (KS == 1 || grp == 0))
-        ct.load_neg(acc);
-    else if (KS == 2) {
+    if (active && (KS == 1 || grp == 0)) {
+        if (SD > 0) // (the tile computed from the problem's points: see gemm_lds_body)
+            gram_seed_neg<(SD > 0 ? SD : 1), 2, 2>(acc, *sd, sb, row0, col0, lane);
+        else
+            ct.load_neg(acc);
+    } else if (KS == 2) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -876,6 +907,22 @@ __global__ __launch_bounds__(256 * KS, 4 / KS) void gemm_lds64_kernel(
         tri_decode(blockIdx.x, bx, by);
     gemm_lds64_body<QT, KS>(smem, C + (long)b * cstride, ldc, P + (long)b * pstride, ldp,
                             Q + (long)b * qstride, ldq, m, n, k, lower, ncut, bx, by);
+}
+
+template <int SD>
+__global__ __launch_bounds__(256, 4) void gemm_lds64_seed_kernel(
+    double *__restrict__ C, long ldc, long cstride, const double *__restrict__ P, long ldp,
+    long pstride, const double *__restrict__ Q, long ldq, long qstride, int m, int n, int k,
+    int lower, int ncut, GramSeed sd)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.z;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (lower == 2)
+        tri_decode(blockIdx.x, bx, by);
+    gemm_lds64_body<false, 1, false, SD>(smem, C + (long)b * cstride, ldc, P + (long)b * pstride,
+                                         ldp, Q + (long)b * qstride, ldq, m, n, k, lower, ncut, bx,
+                                         by, nullptr, 0, nullptr, &sd, b);
 }
 
 

@@ -2,6 +2,7 @@
 // Part of the libbqhip.so kernel set; compiled into k_gram.hip / k_panel.hip (host.h lists the units).
 #pragma once
 #include "common.h"
+#include "seed.h"
 
 // ---------------------------------------------------------------------------
 // Full symmetric Gram, K[i,j] = k(x_i,x_j) + s2 [i==j], any n (the path for sizes that are
@@ -205,19 +206,26 @@ __global__ __launch_bounds__(256) void gram_cross_pad_kernel(const double *__res
 // One 128 x 64 tile of the bordered system (pts, y, A: this problem's).  S0 != nullptr: the
 // tile's entries of rows >= 64 of column block 0 -- the unsolved first panel of the one-launch
 // slab sweep -- go to the sweep's scratch column as well (slab.h).
+// ib, jb: the tile's first row / column (default: from the block index); ilim, jlim: rows /
+// columns from there on are not written (a region of the system, assemble_region_kernel)
 template <int D>
 __device__ __forceinline__ void assemble_tile(const double *__restrict__ pts,
                                               const double *__restrict__ y, const GaussParams &g,
                                               double *__restrict__ A, long lda, const Layout &L,
-                                              double *__restrict__ S0, long lds)
+                                              double *__restrict__ S0, long lds, int ib = -1,
+                                              int jb = -1, int ilim = 0x7fffffff,
+                                              int jlim = 0x7fffffff)
 {
     const int t = threadIdx.x;
-    const int ib = blockIdx.x * 128, jb = blockIdx.y * 64;
+    if (ib < 0) {
+        ib = blockIdx.x * 128;
+        jb = blockIdx.y * 64;
+    }
     if (jb > ib + 127) // whole tile strictly above the diagonal
         return;
     const int i = ib + (t & 63) * 2;
     const int jbase = jb + (t >> 6) * 16;
-    if (i >= L.ntot)
+    if (i >= L.ntot || i >= ilim)
         return;
     bool pi[2];
     double xi[2][D];
@@ -231,7 +239,7 @@ __device__ __forceinline__ void assemble_tile(const double *__restrict__ pts,
     }
     for (int jj = 0; jj < 16; ++jj) {
         const int j = jbase + jj;
-        if (j >= L.ntot)
+        if (j >= L.ntot || j >= jlim)
             break;
         const bool pj = (j < L.n) || (j >= L.npad && j < L.npad + L.M);
         double xj[D];
@@ -240,20 +248,8 @@ __device__ __forceinline__ void assemble_tile(const double *__restrict__ pts,
             xj[k] = pj ? pts[k + (long)j * D] : 0.0;
         double v[2];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int ii = i + r;
-            double val;
-            if (pi[r] && pj) {
-                val = g.c * exp_gauss(gauss_q<D>(xi[r], xj, g));
-                if (ii == j && ii < L.n)
-                    val += g.s2;
-            } else if (ii == L.yrow) {
-                val = (j < L.n) ? y[j] : 0.0;
-            } else {
-                val = (ii == j) ? 1.0 : 0.0;
-            }
-            v[r] = val;
-        }
+        for (int r = 0; r < 2; ++r)
+            v[r] = bordered_entry<D>(i + r, j, pi[r], pj, xi[r], xj, g, L, y);
         double2_t vv = {v[0], v[1]};
         *reinterpret_cast<double2_t *>(A + i + (long)j * lda) = vv; // ntot, lda even
         if (S0 && jb == 0 && i >= 64)
@@ -272,4 +268,24 @@ __global__ __launch_bounds__(256) void assemble_kernel(const double *__restrict_
     const int b = blockIdx.z;
     assemble_tile<D>(pts + (long)b * pstride, y + (long)b * ystride, gp[(long)b * gpstride],
                      A + (long)b * astride, lda, L, nullptr, 0);
+}
+
+// Rows [r, r + m) x columns [c, c + n) of the bordered system (lower part: tiles strictly above
+// the diagonal skipped), for a product whose C was left out of the assembly and whose kernel
+// cannot seed its accumulators itself (launch_gemm).  r, c, m, n multiples of 64.
+// grid (ceil(m / 128), n / 64, batch).
+template <int D>
+__global__ __launch_bounds__(256) void assemble_region_kernel(const double *__restrict__ pts,
+                                                              long pstride,
+                                                              const double *__restrict__ y,
+                                                              long ystride,
+                                                              const GaussParams *__restrict__ gp,
+                                                              int gpstride, double *__restrict__ A,
+                                                              long lda, long astride, Layout L, int r,
+                                                              int c, int m, int n)
+{
+    const int b = blockIdx.z;
+    assemble_tile<D>(pts + (long)b * pstride, y + (long)b * ystride, gp[(long)b * gpstride],
+                     A + (long)b * astride, lda, L, nullptr, 0, r + (int)blockIdx.x * 128,
+                     c + (int)blockIdx.y * 64, r + m, c + n);
 }

@@ -150,6 +150,11 @@ struct bq_ctx {
     int slab_max = 4800;    // ... and the last rows of a larger one, from this many on (BQ_SLAB_MAX)
     int fold_readout = 1; // one-launch sweeps carry their read-out (SlabOut; BQ_FOLD_READOUT)
     SlabOut slab_out{};  // set (scal != nullptr) by a caller whose slab sweep carries its read-out
+    int asm_fuse = 1;    // a batched plan assembles only the first outer block's columns; the rest of
+                         // the system is computed inside the first products that touch it
+                         // (GramSeed; BQ_ASM_FUSE=0: the whole system is assembled first)
+    GramSeed gram_seed{}; // set (pts != nullptr) by a caller that assembled only dfirst_seed_cols()
+                         // columns: enqueue_potrf_dfirst seeds the first block's products with it
     int potf2_8w = 1;    // the one-launch steps' diagonal factor on eight waves where a step's workgroups
                          // have a CU each (BQ_POTF2_8W)
     int gemm_ksplit = 1; // eight-wave k-split forms of the 64-tile / job kernels (BQ_GEMM_KSPLIT)
@@ -334,9 +339,14 @@ struct FirstStep {
     int *info = nullptr;
     double *scal = nullptr; // SlabOut::scal: log|K| starts at zero here
 };
+// jcols > 0: only the first jcols columns (a multiple of 64) of every system
 int launch_assemble(bq_ctx *c, int d, const double *pts, long pstride, const double *y,
                     long ystride, const GaussParams *gp, int gpstride, double *A, long lda,
-                    long astride, Layout L, int batch, const FirstStep &fs = FirstStep());
+                    long astride, Layout L, int batch, const FirstStep &fs = FirstStep(),
+                    int jcols = 0);
+// rows [sd.r, sd.r + m) x columns [sd.c, sd.c + n) of the systems sd describes (lower part)
+int launch_assemble_region(bq_ctx *c, const GramSeed &sd, double *A, long lda, long astride, int m,
+                           int n, int batch);
 int launch_potf2(bq_ctx *c, double *A, long lda, long astride, int j0, double *dinv, long dstride,
                  int *info, int batch);
 int launch_potrf_wg(bq_ctx *c, double *A, long lda, long astride, int kb, double *rec, long rstride,
@@ -364,7 +374,8 @@ bool gemm_uses_lds(const bq_ctx *c, int m, int n, int k, int lower, int batch);
 int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const double *P, long ldp,
                 long pstride, const double *Q, long qsj, long qsk, long qstride, int m, int n,
                 int k, int lower, int batch, int fuse_j0 = -1, double *dinv = nullptr,
-                long dstride = 0, int *info = nullptr, int ccut = 0);
+                long dstride = 0, int *info = nullptr, int ccut = 0,
+                const GramSeed *seed = nullptr);
 bool gemm_trsm_ok(const bq_ctx *c, int m, int n, int k);
 int launch_gemm_trsm(bq_ctx *c, double *C, long ldc, long cstride, const double *P, long ldp,
                      long pstride, const double *Q, long ldq, long qstride, int m, int n, int k,
@@ -431,6 +442,9 @@ int flow_check(bq_ctx *c);
 
 // ---- potrf.hip ------------------------------------------------------------------------
 int auto_nb(const bq_ctx *c, int ntot, int batch);
+// columns a caller of enqueue_potrf_partial has to assemble before it when it hands the rest over
+// as c->gram_seed (the first outer block's), 0: the whole system (another sweep will run)
+int dfirst_seed_cols(const bq_ctx *c, int ntot, int ncols, int batch, size_t panel_ws_len);
 size_t panel_ws_doubles(int ntot, int batch);
 size_t sweep_ws_doubles(const bq_ctx *c, int ntot, int batch);
 bool panel_ws_useful(const bq_ctx *c, int ntot, int batch);

@@ -21,6 +21,10 @@ int gemm_init(bq_ctx *c)
     BQ_L64_ATTR((rows_fused_kernel<true, 2>), BQ_L64_BYTES);
     BQ_L64_ATTR(gemm_trsm64_kernel, BQ_L64_BYTES);
     BQ_L64_ATTR(trsm_sweep_kernel, BQ_L64_BYTES);
+    BQ_L64_ATTR(gemm_lds_seed_kernel<1>, BQ_LDS_BYTES);
+    BQ_L64_ATTR(gemm_lds_seed_kernel<2>, BQ_LDS_BYTES);
+    BQ_L64_ATTR(gemm_lds64_seed_kernel<1>, BQ_L64_BYTES);
+    BQ_L64_ATTR(gemm_lds64_seed_kernel<2>, BQ_L64_BYTES);
 #undef BQ_L64_ATTR
     return BQ_OK;
 }
@@ -99,13 +103,24 @@ bool gemm_uses_lds(const bq_ctx *c, int m, int n, int k, int lower, int batch)
 int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const double *P, long ldp,
                 long pstride, const double *Q, long qsj, long qsk, long qstride, int m, int n,
                 int k, int lower, int batch, int fuse_j0, double *dinv, long dstride, int *info,
-                int ccut)
+                int ccut, const GramSeed *seed)
 {
     // ccut > 0: columns >= ccut of C need no update (honoured by the LDS-staged kernel only)
     if (m <= 0 || n <= 0 || k <= 0)
         return BQ_OK;
     if ((m & 15) || (n & 15) || (k & 7))
         return fail(c, BQ_ERR_BAD_ARG, "gemm: m,n must be multiples of 16 and k of 8");
+    if (seed) {
+        // a product that cannot seed its own accumulators: its region of C is assembled first
+        const bool f444s = qsj == 1 && (m % 64) == 0 && (n % 64) == 0;
+        const int t = (f444s && fuse_j0 < 0) ? gemm_lds_tile(c, m, n, k, lower, batch) : 0;
+        if (!((t == 128 || t == 64) && (seed->d == 1 || seed->d == 2))) {
+            const int ncol = ccut > 0 ? std::min(n, ccut) : n;
+            BQCHK(launch_assemble_region(c, *seed, C - seed->r - (long)seed->c * ldc, ldc, cstride, m,
+                                         (ncol + 63) / 64 * 64, batch));
+            seed = nullptr;
+        }
+    }
     auto tiles = [&](int t) {
         long a = (long)((m + t - 1) / t) * ((n + t - 1) / t) * batch;
         return lower ? a / 2 + 1 : a;
@@ -141,6 +156,29 @@ int launch_gemm(bq_ctx *c, int cls, double *C, long ldc, long cstride, const dou
     } while (0)
     // a 64-column slab has no use for 128-column workgroup tiles (half of their waves idle)
     const int ldst = (f444 && fuse_j0 < 0) ? gemm_lds_tile(c, m, n, k, lower, batch) : 0;
+    // C left out of the assembly (seed): the LDS-staged kernels compute their tile of it from the
+    // problem's points (d <= 2); anything else gets the region written first
+    if (seed) {
+        const bool can = (ldst == 128 || ldst == 64) && (seed->d == 1 || seed->d == 2);
+        if (can) {
+            const int cut = ccut > 0 ? ccut : 0x7fffffff;
+            const dim3 g = grid_for(ldst);
+#define BQ_GEMM_SEED(K_, BYTES_)                                                                   \
+    hipLaunchKernelGGL(K_, g, dim3(256), BYTES_, c->cur, C, ldc, cstride, P, ldp, pstride, Q, qsk,  \
+                       qstride, m, n, k, mode, cut, *seed)
+            if (ldst == 128 && seed->d == 1)
+                BQ_GEMM_SEED(gemm_lds_seed_kernel<1>, BQ_LDS_BYTES);
+            else if (ldst == 128)
+                BQ_GEMM_SEED(gemm_lds_seed_kernel<2>, BQ_LDS_BYTES);
+            else if (seed->d == 1)
+                BQ_GEMM_SEED(gemm_lds64_seed_kernel<1>, BQ_L64_BYTES);
+            else
+                BQ_GEMM_SEED(gemm_lds64_seed_kernel<2>, BQ_L64_BYTES);
+#undef BQ_GEMM_SEED
+            HIPCHK(c, hipGetLastError());
+            return BQ_OK;
+        }
+    }
     if (ldst == 128) {
         dim3 g = grid_for(128);
         hipLaunchKernelGGL(gemm_lds_kernel, g, dim3(256), BQ_LDS_BYTES, c->cur, C, ldc, cstride, P,

@@ -11,9 +11,9 @@ namespace bqh {
 template <int D>
 void launch_assemble_d(bq_ctx *c, const double *pts, long pstride, const double *y, long ystride,
                        const GaussParams *gp, int gpstride, double *A, long lda, long astride,
-                       Layout L, int batch, const FirstStep &fs)
+                       Layout L, int batch, const FirstStep &fs, int jcols)
 {
-    dim3 grid((L.ntot + 127) / 128, (L.ntot + 63) / 64, batch);
+    dim3 grid((L.ntot + 127) / 128, ((jcols > 0 ? jcols : L.ntot) + 63) / 64, batch);
     const long wgs = (long)grid.x * grid.y * grid.z;
     if (fs.S0 && c->potf2_8w && wgs <= 2L * c->cus)
         hipLaunchKernelGGL((assemble_first_kernel<D, 8>), grid, dim3(512), 0, c->cur, pts, pstride, y,
@@ -30,20 +30,55 @@ void launch_assemble_d(bq_ctx *c, const double *pts, long pstride, const double 
 
 int launch_assemble(bq_ctx *c, int d, const double *pts, long pstride, const double *y,
                     long ystride, const GaussParams *gp, int gpstride, double *A, long lda,
-                    long astride, Layout L, int batch, const FirstStep &fs)
+                    long astride, Layout L, int batch, const FirstStep &fs, int jcols)
 {
-    Bracket br(c, BQ_K_GRAM, 8.0 * L.ntot * (L.ntot + 1.0) / 2.0 * batch);
+    if (jcols < 0 || (jcols & 63) || jcols > L.ntot || (jcols > 0 && fs.S0))
+        return fail(c, BQ_ERR_BAD_ARG, "assemble: column limit");
+    const double cols = jcols > 0 ? jcols : L.ntot;
+    Bracket br(c, BQ_K_GRAM, 8.0 * cols * (L.ntot - 0.5 * cols + 0.5) * batch);
     switch (d) {
-    case 1: launch_assemble_d<1>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
-    case 2: launch_assemble_d<2>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
-    case 3: launch_assemble_d<3>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
-    case 4: launch_assemble_d<4>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
-    case 5: launch_assemble_d<5>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
-    case 6: launch_assemble_d<6>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
-    case 7: launch_assemble_d<7>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
-    case 8: launch_assemble_d<8>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs); break;
+    case 1: launch_assemble_d<1>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs, jcols); break;
+    case 2: launch_assemble_d<2>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs, jcols); break;
+    case 3: launch_assemble_d<3>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs, jcols); break;
+    case 4: launch_assemble_d<4>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs, jcols); break;
+    case 5: launch_assemble_d<5>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs, jcols); break;
+    case 6: launch_assemble_d<6>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs, jcols); break;
+    case 7: launch_assemble_d<7>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs, jcols); break;
+    case 8: launch_assemble_d<8>(c, pts, pstride, y, ystride, gp, gpstride, A, lda, astride, L, batch, fs, jcols); break;
     default: return fail(c, BQ_ERR_BAD_ARG, "d must be in 1..%d", BQ_MAXD);
     }
+    HIPCHK(c, hipGetLastError());
+    return BQ_OK;
+}
+
+int launch_assemble_region(bq_ctx *c, const GramSeed &sd, double *A, long lda, long astride, int m,
+                           int n, int batch)
+{
+    if (m <= 0 || n <= 0)
+        return BQ_OK;
+    if ((m & 63) || (n & 63) || (sd.r & 63) || (sd.c & 63))
+        return fail(c, BQ_ERR_BAD_ARG, "assemble_region: multiples of 64");
+    Bracket br(c, BQ_K_GRAM, 8.0 * m * n * batch);
+    const dim3 grid((m + 127) / 128, n / 64, batch);
+#define BQ_ASM_REGION(D_)                                                                          \
+    case D_:                                                                                       \
+        hipLaunchKernelGGL(assemble_region_kernel<D_>, grid, dim3(256), 0, c->cur, sd.pts,         \
+                           sd.pstride, sd.y, sd.ystride, sd.gp, sd.gpstride, A, lda, astride, sd.L, \
+                           sd.r, sd.c, m, n);                                                      \
+        break;
+    switch (sd.d) {
+        BQ_ASM_REGION(1)
+        BQ_ASM_REGION(2)
+        BQ_ASM_REGION(3)
+        BQ_ASM_REGION(4)
+        BQ_ASM_REGION(5)
+        BQ_ASM_REGION(6)
+        BQ_ASM_REGION(7)
+        BQ_ASM_REGION(8)
+    default:
+        return fail(c, BQ_ERR_BAD_ARG, "d must be in 1..%d", BQ_MAXD);
+    }
+#undef BQ_ASM_REGION
     HIPCHK(c, hipGetLastError());
     return BQ_OK;
 }

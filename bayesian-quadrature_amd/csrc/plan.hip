@@ -254,9 +254,17 @@ int plan_enqueue(bq_ctx *c, bq_plan *p)
     } else {
         HIPCHK(c, hipMemsetAsync(p->info.p, 0, sizeof(int) * p->nprob, c->stream));
     }
+    // a batch that sweeps diagonal block first assembles only its first outer block's columns: the
+    // first products that touch the rest compute it themselves (GramSeed, potrf.hip)
+    const int jcols = fuse ? 0
+                           : dfirst_seed_cols(c, p->L.ntot, p->L.npad, p->nprob,
+                                              p->panel.bytes / sizeof(double));
     BQCHK(launch_assemble(c, p->d, p->pts.d(), (long)p->d * p->L.ntot, p->y.d(), p->L.npad,
                           static_cast<GaussParams *>(p->gp.p), 1, p->A.d(), p->lda, p->astride,
-                          p->L, p->nprob, fs));
+                          p->L, p->nprob, fs, jcols));
+    if (jcols > 0)
+        c->gram_seed = GramSeed{p->pts.d(), (long)p->d * p->L.ntot, p->y.d(), (long)p->L.npad,
+                                static_cast<const GaussParams *>(p->gp.p), 1, p->L, p->d, 0, 0};
     // A blocked sweep (outer block >= 128) reads its results off the border rows and skips the
     // border x border block in its trailing updates; the one-launch steps of small systems
     // update everything and read the Schur complement.
@@ -271,6 +279,7 @@ int plan_enqueue(bq_ctx *c, bq_plan *p)
                               p->dinv.d(), p->info.i(), p->panel.d(),
                               p->panel.bytes / sizeof(double), fuse, by_rows);
     c->slab_out = SlabOut{};
+    c->gram_seed = GramSeed{};
     BQCHK(st_sweep);
     if (folded)
         return BQ_OK;

@@ -411,6 +411,19 @@ int enqueue_panel_solve(bq_ctx *c, double *A, long lda, long astride, int batch,
     return enqueue_trsm_rec(c, A, lda, astride, batch, r0, m2, K0, 0, KB, rec, rstride, false);
 }
 
+// (the condition under which enqueue_potrf_partial takes enqueue_potrf_dfirst, and the sweep has at
+// least two outer blocks: with one there is no product that could seed what lies right of it)
+int dfirst_seed_cols(const bq_ctx *c, int ntot, int ncols, int batch, size_t panel_ws_len)
+{
+    if (!c->asm_fuse || (ntot & 63) || (ncols & 63) || ncols > ntot ||
+        !dfirst_applies(c, ntot, ncols, batch))
+        return 0;
+    const int NB = std::min(auto_nb(c, ntot, batch), ncols);
+    if (panel_ws_len < dfirst_ws_doubles(NB, batch) || NB >= ncols)
+        return 0;
+    return NB;
+}
+
 static int enqueue_potrf_dfirst(bq_ctx *c, double *A, long lda, long astride, int batch, int ntot,
                                 int ncols, int *info, double *ws, bool skip_border)
 {
@@ -440,6 +453,17 @@ static int enqueue_potrf_dfirst(bq_ctx *c, double *A, long lda, long astride, in
     };
     BQCHK(diag(0, NB, recs[0]));
     Sharing scope(c, la ? c->df_sharing : c->sharing);
+    // The caller assembled only the first NB columns (dfirst_seed_cols) and left the rest as a
+    // GramSeed: block 0's three products are the first to touch everything right of them, and they
+    // compute their tiles of the system instead of loading them -- the assembly of two thirds of a
+    // C5 system (an HBM-write-bound launch) and its read-back disappear.
+    const bool seeded = c->gram_seed.pts != nullptr;
+    auto seed_at = [&](int r, int cc) {
+        GramSeed sd = c->gram_seed;
+        sd.r = r;
+        sd.c = cc;
+        return sd;
+    };
     int par = 0;
     for (int K0 = 0; K0 < ncols; K0 += NB, par ^= 1) {
         const int KB = std::min(NB, ncols - K0), r0 = K0 + KB, m2 = ntot - r0;
@@ -475,9 +499,13 @@ static int enqueue_potrf_dfirst(bq_ctx *c, double *A, long lda, long astride, in
             if (st == BQ_OK && hipEventRecord(c->ev_top, c->aux) != hipSuccess)
                 st = fail(c, BQ_ERR_HIP, "hipEventRecord(ev_top)");
         }
-        if (st == BQ_OK)
+        const bool sd0 = seeded && K0 == 0;
+        if (st == BQ_OK) {
+            const GramSeed sd = seed_at(r0, r0);
             st = launch_gemm(c, BQ_K_SYRK, A + r0 + (long)r0 * lda, lda, astride, P, lda, astride, P,
-                             1, lda, astride, nw, nw, KB, 1, batch);
+                             1, lda, astride, nw, nw, KB, 1, batch, -1, nullptr, 0, nullptr, 0,
+                             sd0 ? &sd : nullptr);
+        }
         if (st == BQ_OK)
             st = diag(r0, nw, recs[par ^ 1]);
         if (la) {
@@ -503,12 +531,15 @@ static int enqueue_potrf_dfirst(bq_ctx *c, double *A, long lda, long astride, in
             // 176: what the deeper product gains, the factor that now hides behind the column
             // update alone gives back.)
             const bool sq = !(skip_border && r1 >= ncols);
+            const GramSeed sdc = seed_at(r1, r0), sds = seed_at(r1, r1);
             BQCHK(launch_gemm(c, BQ_K_SYRK, A + r1 + (long)r0 * lda, lda, astride, P1, lda, astride,
-                              P, 1, lda, astride, ntot - r1, nw, KB, 0, batch));
+                              P, 1, lda, astride, ntot - r1, nw, KB, 0, batch, -1, nullptr, 0,
+                              nullptr, 0, sd0 ? &sdc : nullptr));
             if (sq)
                 BQCHK(launch_gemm(c, BQ_K_SYRK, A + r1 + (long)r1 * lda, lda, astride, P1, lda,
                                   astride, P1, 1, lda, astride, ntot - r1, ntot - r1, KB, 1, batch,
-                                  -1, nullptr, 0, nullptr, skip_border ? ncols - r1 : 0));
+                                  -1, nullptr, 0, nullptr, skip_border ? ncols - r1 : 0,
+                                  sd0 ? &sds : nullptr));
         }
         if (la)
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_panel, 0));
@@ -542,6 +573,8 @@ int enqueue_potrf_partial(bq_ctx *c, double *A, long lda, long astride, int batc
         return enqueue_potrf_dfirst(c, A, lda, astride, batch, ntot, ncols, info, panel_ws,
                                     skip_border);
     }
+    if (c->gram_seed.pts)
+        return fail(c, BQ_ERR_BAD_ARG, "potrf: a partly assembled system on a sweep that cannot seed it");
     // large systems (a look-ahead's size) in a batch that fills the chip many times over run
     // as ONE sequential group: the product is power-bound (docs/LABBOOK.md section 4), beside it the
     // panel chain only takes clock away (C3, 100 x N = 4096: 189.8 ms with the look-ahead,

@@ -27,6 +27,20 @@ struct Layout {
     int n, npad, M, yrow, ntot; // yrow < 0: no y row
 };
 
+// A product C -= P Q^T whose C has not been written yet (round 6): instead of loading its tile of
+// C the kernel computes the tile's entries of the bordered system -- assemble_tile's values, bit
+// for bit -- from the problem's points.  r, c: the global row / column of C(0, 0) in that system.
+struct GramSeed {
+    const double *pts; // d x ntot per problem
+    long pstride;
+    const double *y;
+    long ystride;
+    const GaussParams *gp;
+    int gpstride;
+    Layout L;
+    int d, r, c;
+};
+
 // Read-out of a bordered system folded into the one-launch sweep (slab.h): the diagonal factors
 // add their share of log|K| to scal[4b + 1] as they go, and the LAST step's tiles -- the Schur
 // complement of the border -- store what finalize_kernel would read from it (no launch of its own).

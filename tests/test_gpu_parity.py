@@ -1718,6 +1718,43 @@ def test_c2_batch_256_vs_oracle(engine, oracle):
     assert (mean == mean[0]).all() and (var == var[0]).all() and (logml == logml[0]).all()
 
 
+@pytest.mark.parametrize("batch,n,m,d", [(3, 700, 20, 2), (12, 1100, 70, 2), (7, 900, 33, 3),
+                                         (100, 700, 40, 2), (64, 2048, 40, 1), (5, 3000, 33, 2)])
+def test_fused_assembly_same_bits(engine, oracle, batch, n, m, d):
+    """A batched plan assembles only its first outer block's columns; block 0's three products
+    compute the rest of the bordered system in their accumulators instead of loading it
+    (gram_seed_neg: the assembly's own arithmetic) -- or, where a product cannot (d > 2, a shape
+    that goes to a register-streaming kernel), its region is assembled right in front of it.
+    Either way the results carry the bits of the full assembly (BQ_ASM_FUSE=0), and problem 0
+    agrees with the oracle."""
+    import os
+    from bayesian_quadrature_amd import Engine
+    rs = np.random.RandomState(batch + n + d)
+    x = rs.uniform(-3, 3, (batch, d, n))
+    xo = rs.uniform(-3, 3, (batch, d, m))
+    y = sum(wl.norm_logpdf(x[:, k]) for k in range(d))
+    h, s = 1.3, 0.05
+    w = np.full(d, 6.0 / n ** (1.0 / d) * 1.5)
+    mean, var, logml, status = engine.batch_fit_predict(x, y, h, w, s, xo)
+    assert (status == 0).all()
+    os.environ["BQ_ASM_FUSE"] = "0"
+    try:
+        e2 = Engine(0)
+    finally:
+        del os.environ["BQ_ASM_FUSE"]
+    try:
+        m2, v2, l2, st2 = e2.batch_fit_predict(x, y, h, w, s, xo)
+    finally:
+        e2.close()
+    assert np.array_equal(mean, m2) and np.array_equal(var, v2) and np.array_equal(logml, l2)
+    assert np.array_equal(status, st2)
+    Lo, ao, lmo = oracle.gp_fit(x[0], y[0], h, w, s)
+    mo, vo = oracle.gp_predict(x[0], h, w, Lo, ao, xo[0])
+    assert relmax(mean[0], mo) < RTOL
+    assert relmax(var[0], vo, scale=oracle.kernel_scale(d, h, w)) < RTOL
+    assert abs(logml[0] - lmo) <= RTOL * max(abs(lmo), 0.5 * n * np.log(2 * np.pi))
+
+
 def test_batch_diag_first_reports_not_pd(engine):
     """A hopeless matrix in the batch (length scale far beyond the spacing, no noise: not positive
     definite in fp64) is reported with a non-zero status, its neighbours are untouched."""
